@@ -1,0 +1,308 @@
+/*
+ * navgpu.h — C-ABI of the MI355X-native costmap + DWA hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch/ROS types.  The thin C++
+ * plugin adapters (navigation_amd/plugin/, `nav_core::BaseLocalPlanner` and `costmap_2d::Layer`
+ * subclasses) and the fleet harness (bench.py, tests) call exactly these entry points.  Every
+ * entry point cites the reference interface it replaces (paths relative to the reference tree).
+ *
+ * Model: a *fleet* is N independent robot instances on one GPU, each with its own layered
+ * costmap (master grid + layer grids) and DWA planner state, all of one grid size.  A single
+ * robot is a fleet of 1.  Calls take an instance range [first, first+count) and are enqueued on
+ * the fleet's HIP stream; `navgpu_sync` (or any *_results/_download call) waits for them.
+ *
+ * Conventions: return 0 on success, negative navgpu_status on error (no exceptions, like the
+ * reference's bool / negative-cost error channel); the caller owns every buffer it passes;
+ * calls on one fleet must be serialised by the caller (the reference holds the costmap mutex
+ * around both virtual calls: costmap_2d/src/layered_costmap.cpp:83, move_base/src/move_base.cpp:947).
+ * There is NO CPU fallback: without a usable HIP device `navgpu_fleet_create` fails.
+ */
+#ifndef NAVGPU_H_
+#define NAVGPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  NAVGPU_OK = 0,
+  NAVGPU_ERR_INVALID = -1,   /* bad argument / range */
+  NAVGPU_ERR_NO_DEVICE = -2, /* no HIP device, or kernels not loadable on it */
+  NAVGPU_ERR_HIP = -3,       /* HIP runtime error (see navgpu_last_error) */
+  NAVGPU_ERR_CAPACITY = -4,  /* input exceeds a capacity given at creation */
+  NAVGPU_ERR_STATE = -5      /* call sequence violated (e.g. cycle before configure) */
+} navgpu_status;
+
+/* costmap_2d/include/costmap_2d/cost_values.h:42-45 */
+#define NAVGPU_NO_INFORMATION 255
+#define NAVGPU_LETHAL_OBSTACLE 254
+#define NAVGPU_INSCRIBED_INFLATED_OBSTACLE 253
+#define NAVGPU_FREE_SPACE 0
+
+/* layer plugins present in an instance's LayeredCostmap, in the reference's plugin order
+ * static -> obstacle|voxel -> inflation (costmap_2d/src/costmap_2d_ros.cpp:189-260) */
+#define NAVGPU_LAYER_STATIC 1
+#define NAVGPU_LAYER_OBSTACLE 2
+#define NAVGPU_LAYER_VOXEL 4 /* replaces OBSTACLE: VoxelLayer derives from ObstacleLayer */
+#define NAVGPU_LAYER_INFLATION 8
+
+/* device-resident grids of an instance (navgpu_grid_upload / _download / _device) */
+typedef enum {
+  NAVGPU_GRID_MASTER = 0,     /* LayeredCostmap::costmap_, uint8 [size_y][size_x]                        */
+  NAVGPU_GRID_STATIC = 1,     /* StaticLayer's costmap_, uint8                                           */
+  NAVGPU_GRID_OBSTACLE = 2,   /* ObstacleLayer/VoxelLayer's costmap_, uint8                              */
+  NAVGPU_GRID_VOXEL = 3,      /* VoxelGrid::data_, uint32 per column (voxel_grid.h:66-434)               */
+  NAVGPU_GRID_PATH_GOAL = 4,  /* MapGrid target_dist of path_costs_ (.x) and goal_costs_ (.y), uint32x2  */
+  NAVGPU_GRID_GOAL_FRONT = 5  /* MapGrid target_dist of goal_front_costs_, uint32                        */
+} navgpu_grid_id;
+
+typedef struct navgpu_fleet navgpu_fleet;
+
+typedef struct {
+  uint32_t n_instances;
+  uint32_t size_x, size_y;  /* cells; Costmap2D::size_x_/size_y_ (costmap_2d.h:60-466)                   */
+  double resolution;        /* m/cell                                                                   */
+  int32_t layers;           /* NAVGPU_LAYER_* bitmask                                                   */
+  int32_t track_unknown;    /* LayeredCostmap(track_unknown): master default 255 else 0 (layered_costmap.cpp:50-57) */
+  int32_t device;           /* HIP device ordinal                                                       */
+  uint32_t max_points;      /* capacity: cloud points per instance per update                           */
+  uint32_t max_observations;/* capacity: observations per instance per update                           */
+  uint32_t max_plan;        /* capacity: poses of the local plan handed to the planner                  */
+  uint32_t max_footprint;   /* capacity: footprint polygon vertices                                     */
+  uint32_t max_sim_steps;   /* capacity: trajectory points (ceil(sim_time/sim_granularity) or the
+                               per-sample bound when discretize_by_time = 0)                            */
+  int32_t keep_sample_costs;/* 1: keep every sample's total cost + status for navgpu_planner_samples    */
+} navgpu_fleet_desc;
+
+/* One sensor observation of one instance — costmap_2d::Observation (observation.h:46-103):
+ * origin_ (double xyz, global frame), cloud_ (float xyz, global frame), the two ranges.  This is
+ * where the reference's own tests inject data (ObstacleLayer::addStaticObservation,
+ * plugins/obstacle_layer.cpp:450-464; testing_helper.h:75-90). */
+typedef struct {
+  uint32_t instance;        /* absolute instance index                                                  */
+  uint32_t first_point;     /* index of this cloud's first point in the packed points_xyz array         */
+  uint32_t n_points;
+  uint32_t flags;           /* bit0 marking, bit1 clearing                                              */
+  double origin_x, origin_y, origin_z;
+  double obstacle_range, raytrace_range;
+} navgpu_observation;
+#define NAVGPU_OBS_MARKING 1
+#define NAVGPU_OBS_CLEARING 2
+
+/* ObstacleLayer / VoxelLayer parameters (cfg/ObstaclePlugin.cfg:7-18, cfg/VoxelPlugin.cfg:10-15) */
+typedef struct {
+  int32_t enabled;
+  int32_t footprint_clearing_enabled;
+  int32_t combination_method; /* 0 overwrite, 1 max (costmap_layer.cpp:62-124) */
+  int32_t z_voxels;           /* voxel only */
+  double max_obstacle_height;
+  double origin_z, z_resolution; /* voxel only */
+  int32_t unknown_threshold;  /* voxel only, as configured (the +16-z_voxels of voxel_layer.cpp:89 is applied inside) */
+  int32_t mark_threshold;     /* voxel only */
+} navgpu_obstacle_params;
+
+/* InflationLayer parameters (cfg/InflationPlugin.cfg:8-9) + the footprint's inscribed radius
+ * (LayeredCostmap::getInscribedRadius, set through InflationLayer::onFootprintChanged) */
+typedef struct {
+  int32_t enabled;
+  int32_t reserved;
+  double inflation_radius;
+  double cost_scaling_factor;
+  double inscribed_radius;
+} navgpu_inflation_params;
+
+/* base_local_planner::LocalPlannerLimits (local_planner_limits.h:44-124) + DWAPlannerConfig
+ * (dwa_local_planner/cfg/DWAPlanner.cfg:15-36) + the plain params of DWAPlanner's ctor
+ * (dwa_planner.cpp:131-181).  Field order is ABI. */
+typedef struct {
+  double max_trans_vel, min_trans_vel;
+  double max_vel_x, min_vel_x, max_vel_y, min_vel_y;
+  double max_rot_vel, min_rot_vel;
+  double acc_lim_x, acc_lim_y, acc_lim_theta;
+  double sim_time, sim_granularity, angular_sim_granularity, sim_period;
+  double path_distance_bias, goal_distance_bias, occdist_scale;
+  double forward_point_distance, cheat_factor;
+  double oscillation_reset_dist, oscillation_reset_angle;
+  int32_t vx_samples, vy_samples, vth_samples;
+  int32_t use_dwa;            /* only 1 (DWA window, no continued acceleration) is accelerated   */
+  int32_t discretize_by_time; /* SimpleTrajectoryGenerator::initialise(..., discretize_by_time)  */
+  int32_t sum_scores;         /* ObstacleCostFunction::setSumScores                               */
+  int32_t allow_unknown;      /* explicit (reference reads an uninitialised member)  */
+  int32_t reserved;
+} navgpu_dwa_config;
+
+/* Robot state for one planner cycle, already narrowed to float the way DWAPlanner::findBestPath
+ * builds its Eigen::Vector3f pos / vel (dwa_planner.cpp:303-304). */
+typedef struct {
+  float pos[3];             /* x, y, yaw in the costmap's global frame */
+  float vel[3];             /* vx, vy, vtheta                           */
+  uint32_t plan_first;      /* first pose of this instance in the packed plan_xy array */
+  uint32_t plan_count;      /* poses (>= 1); the transformed+pruned local plan          */
+} navgpu_robot_state;
+
+/* Result of DWAPlanner::findBestPath (dwa_planner.cpp:292-371) for one instance. */
+typedef struct {
+  int32_t best_index;       /* sample slot of the winner (x-outer, y, theta-inner order), -1 if none */
+  int32_t n_samples;        /* sample slots generated this cycle                                      */
+  int32_t n_scored;         /* slots the generator accepted                                           */
+  int32_t n_valid;          /* slots with total cost >= 0                                             */
+  int32_t n_points;         /* points of the winning trajectory                                       */
+  uint32_t oscillation_flags;/* the 12 sticky flags after updateOscillationFlags (bit order: navgpu.h) */
+  float xv, yv, thetav;     /* result_traj_.{xv_,yv_,thetav_}                                         */
+  float reserved;
+  double cost;              /* result_traj_.cost_ (-7 pre-set when nothing is valid)                  */
+  double drive[3];          /* drive_velocities: (xv, yv, thetav) or zeros when cost < 0             */
+} navgpu_plan_result;
+
+/* oscillation flag bits (OscillationCostFunction members, oscillation_cost_function.cpp:81-97) */
+#define NAVGPU_OSC_STRAFE_POS_ONLY (1u << 0)
+#define NAVGPU_OSC_STRAFE_NEG_ONLY (1u << 1)
+#define NAVGPU_OSC_STRAFING_POS (1u << 2)
+#define NAVGPU_OSC_STRAFING_NEG (1u << 3)
+#define NAVGPU_OSC_ROT_POS_ONLY (1u << 4)
+#define NAVGPU_OSC_ROT_NEG_ONLY (1u << 5)
+#define NAVGPU_OSC_ROTATING_POS (1u << 6)
+#define NAVGPU_OSC_ROTATING_NEG (1u << 7)
+#define NAVGPU_OSC_FORWARD_POS_ONLY (1u << 8)
+#define NAVGPU_OSC_FORWARD_NEG_ONLY (1u << 9)
+#define NAVGPU_OSC_FORWARD_POS (1u << 10)
+#define NAVGPU_OSC_FORWARD_NEG (1u << 11)
+
+/* per-sample status written when keep_sample_costs = 1 */
+#define NAVGPU_SAMPLE_REJECTED 0 /* generateTrajectory returned false (simple_trajectory_generator.cpp:193-200,250) */
+#define NAVGPU_SAMPLE_SCORED 1
+
+/* ------------------------------------------------------------------------------------------ */
+/* lifetime                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+const char* navgpu_version(void);
+const char* navgpu_strerror(int status);
+const char* navgpu_last_error(void); /* text of the last HIP failure on this thread */
+int navgpu_device_count(void);
+
+/* replaces: `new Costmap2DROS(...)` + plugin createInstance/initialize for the hot-path layers
+ * (costmap_2d/src/costmap_2d_ros.cpp:63-167) and `DWAPlannerROS::initialize`
+ * (dwa_local_planner/src/dwa_planner_ros.cpp:94-129), for n_instances robots at once. */
+int navgpu_fleet_create(const navgpu_fleet_desc* desc, navgpu_fleet** out);
+int navgpu_fleet_destroy(navgpu_fleet* fleet);
+int navgpu_sync(navgpu_fleet* fleet);
+void* navgpu_stream(navgpu_fleet* fleet); /* the fleet's hipStream_t */
+
+/* Costmap2D origin per instance (costmap_2d.h origin_x_/origin_y_); origins_xy = count x {x,y}.
+ * replaces: LayeredCostmap::resizeMap origin arguments (layered_costmap.cpp:67-77) */
+int navgpu_fleet_set_origin(navgpu_fleet* fleet, uint32_t first, uint32_t count, const double* origins_xy);
+
+/* raw grid access.  host buffers are count x size_y x size_x elements of the grid's type.
+ * replaces: Costmap2D::getCharMap() (costmap_2d.cpp:187-190), VoxelGrid::getData() */
+int navgpu_grid_upload(navgpu_fleet* fleet, int grid, uint32_t first, uint32_t count, const void* host);
+int navgpu_grid_download(navgpu_fleet* fleet, int grid, uint32_t first, uint32_t count, void* host);
+int navgpu_grid_device(navgpu_fleet* fleet, int grid, void** device_ptr, size_t* instance_stride_bytes);
+/* Costmap2D::resetMaps() on the given grid (default value of that grid) */
+int navgpu_grid_reset(navgpu_fleet* fleet, int grid, uint32_t first, uint32_t count);
+
+/* ------------------------------------------------------------------------------------------ */
+/* costmap layers                                                                             */
+/* ------------------------------------------------------------------------------------------ */
+/* replaces: StaticLayer::incomingMap (plugins/static_layer.cpp:167-228): occupancy is the
+ * nav_msgs/OccupancyGrid int8 data of one map, interpreted with interpretValue (:149-163) on the
+ * device and broadcast to [first, first+count). */
+int navgpu_static_set_map(navgpu_fleet* fleet, uint32_t first, uint32_t count, const int8_t* occupancy,
+                          int32_t track_unknown_space, int32_t use_maximum, int32_t trinary_costmap,
+                          int32_t lethal_cost_threshold, int32_t unknown_cost_value);
+
+/* replaces: ObstacleLayer::reconfigureCB / VoxelLayer::reconfigureCB */
+int navgpu_obstacle_configure(navgpu_fleet* fleet, const navgpu_obstacle_params* params);
+/* replaces: InflationLayer::setInflationParameters + onFootprintChanged + computeCaches
+ * (plugins/inflation_layer.cpp:160-170,295-328,362-376).  The (R+2)^2 distance/cost tables are
+ * built on the host in fp64 with libm exactly as the reference does, then uploaded. */
+int navgpu_inflation_configure(navgpu_fleet* fleet, const navgpu_inflation_params* params);
+/* replaces: LayeredCostmap::setFootprint (layered_costmap.cpp:164-174) for [first,first+count).
+ * footprint_xy = n_vertices x {x,y} in the robot frame.  Does NOT change inscribed_radius of the
+ * inflation layer (pass it through navgpu_inflation_configure, as the adapter does). */
+int navgpu_set_footprint(navgpu_fleet* fleet, uint32_t first, uint32_t count, const double* footprint_xy,
+                         uint32_t n_vertices);
+
+/* H2D staging of one update cycle's observations (host -> HBM).  poses = count x {x,y,yaw}.
+ * replaces: ObstacleLayer::getMarkingObservations / getClearingObservations (:466-496) */
+int navgpu_costmap_stage(navgpu_fleet* fleet, uint32_t first, uint32_t count, const double* robot_poses,
+                         const navgpu_observation* observations, uint32_t n_observations,
+                         const float* points_xyz, uint32_t n_points_total);
+/* replaces: LayeredCostmap::updateMap(robot_x, robot_y, robot_yaw) (layered_costmap.cpp:79-150):
+ * updateBounds of every layer (raytrace clearing, marking, footprint touch, inflation box union),
+ * window reset, updateCosts of every layer — all on the device, boxes never visit the host. */
+int navgpu_costmap_update(navgpu_fleet* fleet, uint32_t first, uint32_t count);
+/* boxes = count x {x0, xn, y0, yn}: LayeredCostmap::getBounds (layered_costmap.h:131-137) */
+int navgpu_costmap_bounds(navgpu_fleet* fleet, uint32_t first, uint32_t count, int32_t* boxes);
+
+/* layer-granular calls for the costmap_2d::Layer adapters (layer.h:50-130).  boxes = count x
+ * {min_i, min_j, max_i, max_j} as handed to Layer::updateCosts, or NULL to use the boxes the
+ * last navgpu_costmap_update computed on the device.
+ * replaces: InflationLayer::updateCosts (plugins/inflation_layer.cpp:172-266) */
+int navgpu_inflate(navgpu_fleet* fleet, uint32_t first, uint32_t count, const int32_t* boxes);
+/* replaces: ObstacleLayer::updateBounds / VoxelLayer::updateBounds on the staged observations;
+ * bounds_inout = count x {min_x, min_y, max_x, max_y} */
+int navgpu_obstacle_update_bounds(navgpu_fleet* fleet, uint32_t first, uint32_t count, double* bounds_inout);
+/* replaces: ObstacleLayer::updateCosts (plugins/obstacle_layer.cpp:427-448) */
+int navgpu_obstacle_update_costs(navgpu_fleet* fleet, uint32_t first, uint32_t count, const int32_t* boxes);
+
+/* ------------------------------------------------------------------------------------------ */
+/* DWA local planner                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+/* replaces: DWAPlanner::reconfigure (dwa_planner.cpp:52-116) */
+int navgpu_planner_configure(navgpu_fleet* fleet, const navgpu_dwa_config* config);
+/* replaces: DWAPlanner::setPlan (dwa_planner.cpp:204-207): resets the oscillation flags */
+int navgpu_planner_set_plan(navgpu_fleet* fleet, uint32_t first, uint32_t count);
+/* H2D staging of one control cycle (host -> HBM): robot states and the packed local plans
+ * (plan_xy = n_plan_total x {x,y}).  Also performs DWAPlanner::updatePlanAndLocalCosts
+ * (dwa_planner.cpp:240-286): nose goal and alignment on/off are evaluated here on the host in
+ * fp64 libm, the same arithmetic the reference runs once per cycle. */
+int navgpu_planner_stage(navgpu_fleet* fleet, uint32_t first, uint32_t count, const navgpu_robot_state* states,
+                         const double* plan_xy, uint32_t n_plan_total);
+/* replaces: DWAPlanner::findBestPath (dwa_planner.cpp:292-371) =
+ * SimpleTrajectoryGenerator::initialise + SimpleScoredSamplingPlanner::findBestTrajectory
+ * (4 x MapGridCostFunction::prepare, rollout + six critics per sample, first-strict-minimum) +
+ * OscillationCostFunction::updateOscillationFlags. */
+int navgpu_planner_cycle(navgpu_fleet* fleet, uint32_t first, uint32_t count);
+int navgpu_planner_results(navgpu_fleet* fleet, uint32_t first, uint32_t count, navgpu_plan_result* results);
+/* winning trajectory of one instance: xyth = n_points x {x,y,theta}; returns n_points or <0 */
+int navgpu_planner_trajectory(navgpu_fleet* fleet, uint32_t instance, double* xyth, uint32_t capacity_points);
+/* every sample slot of one instance (needs keep_sample_costs): total cost with all critics summed
+ * (no early-out; negative = the first failing critic's code) and NAVGPU_SAMPLE_* status */
+int navgpu_planner_samples(navgpu_fleet* fleet, uint32_t instance, double* costs, int32_t* status,
+                           float* velocities_xyz, uint32_t capacity);
+/* replaces: DWAPlanner::checkTrajectory (dwa_planner.cpp:213-237) for one instance; uses the
+ * staged state of that instance.  *ok = 1 when the single sample scores >= 0. */
+int navgpu_planner_check_trajectory(navgpu_fleet* fleet, uint32_t instance, const float vel_samples[3], int32_t* ok);
+/* OscillationCostFunction state access (persists across cycles per instance) */
+int navgpu_planner_get_oscillation(navgpu_fleet* fleet, uint32_t first, uint32_t count, uint32_t* flags,
+                                   float* prev_stationary_pos_xyz);
+int navgpu_planner_set_oscillation(navgpu_fleet* fleet, uint32_t first, uint32_t count, const uint32_t* flags,
+                                   const float* prev_stationary_pos_xyz);
+
+/* ------------------------------------------------------------------------------------------ */
+/* measurement                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+typedef enum {
+  NAVGPU_K_OBSTACLE = 0, /* raytrace + mark + bounds                      */
+  NAVGPU_K_MERGE = 1,    /* window reset + static/obstacle merge          */
+  NAVGPU_K_INFLATE = 2,  /* inflation                                     */
+  NAVGPU_K_BFS = 3,      /* MapGrid wavefronts                            */
+  NAVGPU_K_SCORE = 4,    /* rollout + critics                             */
+  NAVGPU_K_SELECT = 5,   /* argmin + result + oscillation update          */
+  NAVGPU_K_COUNT = 6
+} navgpu_kernel_id;
+/* HIP-event timing of the kernels on the fleet's stream.  While enabled every launch of the
+ * listed kernels is bracketed by two hipEventRecord calls; read() synchronises and returns the
+ * accumulated device time (ms) and launch count since the last reset. */
+int navgpu_profile_enable(navgpu_fleet* fleet, int32_t enable);
+int navgpu_profile_reset(navgpu_fleet* fleet);
+int navgpu_profile_read(navgpu_fleet* fleet, int32_t kernel, double* total_ms, uint64_t* launches);
+const char* navgpu_kernel_name(int32_t kernel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAVGPU_H_ */
