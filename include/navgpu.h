@@ -55,8 +55,9 @@ typedef enum {
   NAVGPU_GRID_STATIC = 1,     /* StaticLayer's costmap_, uint8                                           */
   NAVGPU_GRID_OBSTACLE = 2,   /* ObstacleLayer/VoxelLayer's costmap_, uint8                              */
   NAVGPU_GRID_VOXEL = 3,      /* VoxelGrid::data_, uint32 per column (voxel_grid.h:66-434)               */
-  NAVGPU_GRID_PATH_GOAL = 4,  /* MapGrid target_dist of path_costs_ (.x) and goal_costs_ (.y), uint32x2  */
-  NAVGPU_GRID_GOAL_FRONT = 5  /* MapGrid target_dist of goal_front_costs_, uint32                        */
+  NAVGPU_GRID_PATH = 4,       /* MapGrid target_dist of path_costs_ (== alignment_costs_), uint32        */
+  NAVGPU_GRID_GOAL = 5,       /* MapGrid target_dist of goal_costs_, uint32                              */
+  NAVGPU_GRID_GOAL_FRONT = 6  /* MapGrid target_dist of goal_front_costs_, uint32                        */
 } navgpu_grid_id;
 
 typedef struct navgpu_fleet navgpu_fleet;

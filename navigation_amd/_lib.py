@@ -1,0 +1,165 @@
+"""ctypes declarations for include/navgpu.h (one-to-one)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+LAYER_STATIC, LAYER_OBSTACLE, LAYER_VOXEL, LAYER_INFLATION = 1, 2, 4, 8
+GRID_MASTER, GRID_STATIC, GRID_OBSTACLE, GRID_VOXEL, GRID_PATH, GRID_GOAL, GRID_GOAL_FRONT = range(7)
+OBS_MARKING, OBS_CLEARING = 1, 2
+K_OBSTACLE, K_MERGE, K_INFLATE, K_BFS, K_SCORE, K_SELECT = range(6)
+KERNELS = ("k_obstacle", "k_merge", "k_inflate", "k_bfs", "k_score", "k_select")
+
+
+class NavgpuError(RuntimeError):
+    pass
+
+
+class FleetDesc(C.Structure):
+    _fields_ = [("n_instances", C.c_uint32), ("size_x", C.c_uint32), ("size_y", C.c_uint32),
+                ("resolution", C.c_double), ("layers", C.c_int32), ("track_unknown", C.c_int32),
+                ("device", C.c_int32), ("max_points", C.c_uint32), ("max_observations", C.c_uint32),
+                ("max_plan", C.c_uint32), ("max_footprint", C.c_uint32), ("max_sim_steps", C.c_uint32),
+                ("keep_sample_costs", C.c_int32)]
+
+
+class Observation(C.Structure):
+    _fields_ = [("instance", C.c_uint32), ("first_point", C.c_uint32), ("n_points", C.c_uint32),
+                ("flags", C.c_uint32), ("origin_x", C.c_double), ("origin_y", C.c_double),
+                ("origin_z", C.c_double), ("obstacle_range", C.c_double), ("raytrace_range", C.c_double)]
+
+
+class ObstacleParams(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("footprint_clearing_enabled", C.c_int32),
+                ("combination_method", C.c_int32), ("z_voxels", C.c_int32), ("max_obstacle_height", C.c_double),
+                ("origin_z", C.c_double), ("z_resolution", C.c_double), ("unknown_threshold", C.c_int32),
+                ("mark_threshold", C.c_int32)]
+
+
+class InflationParams(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("reserved", C.c_int32), ("inflation_radius", C.c_double),
+                ("cost_scaling_factor", C.c_double), ("inscribed_radius", C.c_double)]
+
+
+class DwaConfig(C.Structure):
+    """navgpu_dwa_config; defaults are the reference's (DWAPlanner.cfg:15-36, local_planner_limits)."""
+    _fields_ = [(n, C.c_double) for n in (
+        "max_trans_vel", "min_trans_vel", "max_vel_x", "min_vel_x", "max_vel_y", "min_vel_y",
+        "max_rot_vel", "min_rot_vel", "acc_lim_x", "acc_lim_y", "acc_lim_theta",
+        "sim_time", "sim_granularity", "angular_sim_granularity", "sim_period",
+        "path_distance_bias", "goal_distance_bias", "occdist_scale",
+        "forward_point_distance", "cheat_factor", "oscillation_reset_dist", "oscillation_reset_angle")] + [
+        (n, C.c_int32) for n in (
+            "vx_samples", "vy_samples", "vth_samples", "use_dwa", "discretize_by_time", "sum_scores",
+            "allow_unknown", "reserved")]
+
+    DEFAULTS = dict(max_trans_vel=0.55, min_trans_vel=0.1, max_vel_x=0.55, min_vel_x=0.0, max_vel_y=0.1,
+                    min_vel_y=-0.1, max_rot_vel=1.0, min_rot_vel=0.4, acc_lim_x=2.5, acc_lim_y=2.5,
+                    acc_lim_theta=3.2, sim_time=1.7, sim_granularity=0.025, angular_sim_granularity=0.1,
+                    sim_period=0.05, path_distance_bias=32.0, goal_distance_bias=24.0, occdist_scale=0.01,
+                    forward_point_distance=0.325, cheat_factor=1.0, oscillation_reset_dist=0.05,
+                    oscillation_reset_angle=0.2, vx_samples=3, vy_samples=10, vth_samples=20, use_dwa=1,
+                    discretize_by_time=0, sum_scores=0, allow_unknown=1, reserved=0)
+
+    def __init__(self, **kw):
+        super().__init__()
+        d = dict(self.DEFAULTS)
+        d.update(kw)
+        for k, v in d.items():
+            setattr(self, k, v)
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class RobotState(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("vel", C.c_float * 3), ("plan_first", C.c_uint32),
+                ("plan_count", C.c_uint32)]
+
+
+class PlanResult(C.Structure):
+    _fields_ = [("best_index", C.c_int32), ("n_samples", C.c_int32), ("n_scored", C.c_int32),
+                ("n_valid", C.c_int32), ("n_points", C.c_int32), ("oscillation_flags", C.c_uint32),
+                ("xv", C.c_float), ("yv", C.c_float), ("thetav", C.c_float), ("reserved", C.c_float),
+                ("cost", C.c_double), ("drive", C.c_double * 3)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libnavgpu.so")
+
+
+def build():
+    """hipcc --offload-arch=gfx950 build of libnavgpu.so (cross-compiles without a GPU)."""
+    subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc")], check=True)
+
+
+# every symbol include/navgpu.h declares: (name, restype, argtypes)
+vp, u32, i32, dbl = C.c_void_p, C.c_uint32, C.c_int32, C.c_double
+SYMBOLS = [
+    ("navgpu_version", C.c_char_p, []),
+    ("navgpu_strerror", C.c_char_p, [C.c_int]),
+    ("navgpu_last_error", C.c_char_p, []),
+    ("navgpu_device_count", C.c_int, []),
+    ("navgpu_fleet_create", C.c_int, [C.POINTER(FleetDesc), C.POINTER(vp)]),
+    ("navgpu_fleet_destroy", C.c_int, [vp]),
+    ("navgpu_sync", C.c_int, [vp]),
+    ("navgpu_stream", vp, [vp]),
+    ("navgpu_fleet_set_origin", C.c_int, [vp, u32, u32, vp]),
+    ("navgpu_grid_upload", C.c_int, [vp, C.c_int, u32, u32, vp]),
+    ("navgpu_grid_download", C.c_int, [vp, C.c_int, u32, u32, vp]),
+    ("navgpu_grid_device", C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+    ("navgpu_grid_reset", C.c_int, [vp, C.c_int, u32, u32]),
+    ("navgpu_static_set_map", C.c_int, [vp, u32, u32, vp, i32, i32, i32, i32, i32]),
+    ("navgpu_obstacle_configure", C.c_int, [vp, C.POINTER(ObstacleParams)]),
+    ("navgpu_inflation_configure", C.c_int, [vp, C.POINTER(InflationParams)]),
+    ("navgpu_set_footprint", C.c_int, [vp, u32, u32, vp, u32]),
+    ("navgpu_costmap_stage", C.c_int, [vp, u32, u32, vp, vp, u32, vp, u32]),
+    ("navgpu_costmap_update", C.c_int, [vp, u32, u32]),
+    ("navgpu_costmap_bounds", C.c_int, [vp, u32, u32, vp]),
+    ("navgpu_inflate", C.c_int, [vp, u32, u32, vp]),
+    ("navgpu_obstacle_update_bounds", C.c_int, [vp, u32, u32, vp]),
+    ("navgpu_obstacle_update_costs", C.c_int, [vp, u32, u32, vp]),
+    ("navgpu_planner_configure", C.c_int, [vp, C.POINTER(DwaConfig)]),
+    ("navgpu_planner_set_plan", C.c_int, [vp, u32, u32]),
+    ("navgpu_planner_stage", C.c_int, [vp, u32, u32, vp, vp, u32]),
+    ("navgpu_planner_cycle", C.c_int, [vp, u32, u32]),
+    ("navgpu_planner_results", C.c_int, [vp, u32, u32, vp]),
+    ("navgpu_planner_trajectory", C.c_int, [vp, u32, vp, u32]),
+    ("navgpu_planner_samples", C.c_int, [vp, u32, vp, vp, vp, u32]),
+    ("navgpu_planner_check_trajectory", C.c_int, [vp, u32, vp, C.POINTER(i32)]),
+    ("navgpu_planner_get_oscillation", C.c_int, [vp, u32, u32, vp, vp]),
+    ("navgpu_planner_set_oscillation", C.c_int, [vp, u32, u32, vp, vp]),
+    ("navgpu_profile_enable", C.c_int, [vp, i32]),
+    ("navgpu_profile_reset", C.c_int, [vp]),
+    ("navgpu_profile_read", C.c_int, [vp, i32, C.POINTER(dbl), C.POINTER(C.c_uint64)]),
+    ("navgpu_kernel_name", C.c_char_p, [i32]),
+]
+
+
+def lib():
+    """Load libnavgpu.so.  Raises (never falls back) when the HIP extension is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise NavgpuError(f"{path} is missing: build it with navigation_amd.build() / __graft_entry__.build(); "
+                          "there is no CPU fallback")
+    L = C.CDLL(path)
+    for name, res, args in SYMBOLS:
+        fn = getattr(L, name)  # AttributeError if the header and the library ever diverge
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+def check(rc, what=""):
+    if rc < 0:
+        L = lib()
+        raise NavgpuError(f"{what}: {L.navgpu_strerror(rc).decode()} ({rc}) {L.navgpu_last_error().decode()}")
+    return rc

@@ -1,0 +1,720 @@
+// HIP kernels (gfx950) for the costmap half of the hot path:
+//   k_obstacle : ObstacleLayer/VoxelLayer::updateBounds  (raytrace clearing, marking, bounds) +
+//                InflationLayer/StaticLayer::updateBounds + LayeredCostmap box + footprint clearing
+//   k_merge    : Costmap2D::resetMap window + StaticLayer/ObstacleLayer::updateCosts merges
+//   k_inflate  : InflationLayer::updateCosts as an order-independent windowed exact EDT
+// Reference citations are on each kernel.  Compiled with -ffp-contract=off: every fp64 expression
+// must round exactly like the reference's x86-64 build.
+#include "navgpu_device.h"
+
+namespace navgpu {
+
+// ------------------------------------------------------------------------------------------------
+// small fills / static map interpretation
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fill_u8(uint8_t* dst, uint8_t v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  uint32_t w = v * 0x01010101u;
+  uint4 q = make_uint4(w, w, w, w);
+  size_t n16 = n / 16;
+  for (size_t k = i; k < n16; k += stride) reinterpret_cast<uint4*>(dst)[k] = q;
+  for (size_t k = n16 * 16 + i; k < n; k += stride) dst[k] = v;
+}
+__global__ void k_fill_u32(uint32_t* dst, uint32_t v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t k = i; k < n; k += stride) dst[k] = v;
+}
+void launch_fill_u8(uint8_t* dst, uint8_t v, size_t n, hipStream_t s) {
+  if (!n) return;
+  size_t blocks = (n / 16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_fill_u8, dim3((unsigned)blocks), dim3(256), 0, s, dst, v, n);
+}
+void launch_fill_u32(uint32_t* dst, uint32_t v, size_t n, hipStream_t s) {
+  if (!n) return;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)blocks), dim3(256), 0, s, dst, v, n);
+}
+
+// StaticLayer::interpretValue (plugins/static_layer.cpp:149-163) applied to an OccupancyGrid and
+// broadcast to `count` instances (incomingMap :210-220).
+__global__ void k_static_interpret(uint8_t* dst, const int8_t* occ, uint32_t cells, uint32_t cells_padded, uint32_t count,
+                                   int track_unknown_space, int trinary, int lethal_threshold, int unknown_cost_value) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cells) return;
+  uint8_t value = (uint8_t)occ[i];
+  uint8_t lethal_thr = (uint8_t)lethal_threshold;
+  uint8_t unknown = (uint8_t)unknown_cost_value;
+  uint8_t out;
+  if (track_unknown_space && value == unknown)
+    out = kNoInfo;
+  else if (!track_unknown_space && value == unknown)
+    out = kFree;
+  else if (value >= lethal_thr)
+    out = kLethal;
+  else if (trinary)
+    out = kFree;
+  else {
+    double scale = (double)value / lethal_thr;
+    out = (uint8_t)(scale * kLethal);
+  }
+  for (uint32_t k = 0; k < count; ++k) dst[(size_t)k * cells_padded + i] = out;
+}
+void launch_static_interpret(uint8_t* dst, const int8_t* occ, uint32_t cells, uint32_t cells_padded, uint32_t count,
+                             int track_unknown_space, int trinary, int lethal_threshold, int unknown_cost_value, hipStream_t s) {
+  hipLaunchKernelGGL(k_static_interpret, dim3((cells + 255) / 256), dim3(256), 0, s, dst, occ, cells, cells_padded, count,
+                     track_unknown_space, trinary, lethal_threshold, unknown_cost_value);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bresenham walkers
+// ------------------------------------------------------------------------------------------------
+// Costmap2D::raytraceLine + bresenham2D (costmap_2d.h:359-417): `at(offset)` on every visited cell
+template <class F>
+__device__ __forceinline__ void raytrace2d(uint32_t nx, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t max_length,
+                                           F&& at) {
+  int dx = (int)x1 - (int)x0, dy = (int)y1 - (int)y0;
+  uint32_t abs_dx = dx < 0 ? -dx : dx, abs_dy = dy < 0 ? -dy : dy;
+  int offset_dx = dx > 0 ? 1 : -1;  // sign(0) == -1 (costmap_2d.h:414-417)
+  int offset_dy = (dy > 0 ? 1 : -1) * (int)nx;
+  uint32_t offset = y0 * nx + x0;
+  double dist = sqrt((double)dx * (double)dx + (double)dy * (double)dy);  // exact integers: == hypot(dx, dy)
+  double scale = (dist == 0.0) ? 1.0 : fmin(1.0, (double)max_length / dist);
+  uint32_t abs_da, abs_db, lim;
+  int offset_a, offset_b;
+  if (abs_dx >= abs_dy) {
+    abs_da = abs_dx;
+    abs_db = abs_dy;
+    offset_a = offset_dx;
+    offset_b = offset_dy;
+  } else {
+    abs_da = abs_dy;
+    abs_db = abs_dx;
+    offset_a = offset_dy;
+    offset_b = offset_dx;
+  }
+  lim = (uint32_t)(scale * abs_da);
+  int error_b = abs_da / 2;
+  uint32_t end = lim < abs_da ? lim : abs_da;
+  for (uint32_t i = 0; i < end; ++i) {
+    at(offset);
+    offset += offset_a;
+    error_b += abs_db;
+    if ((uint32_t)error_b >= abs_da) {
+      offset += offset_b;
+      error_b -= abs_da;
+    }
+  }
+  at(offset);
+}
+
+// VoxelGrid::raytraceLine + bresenham3D (voxel_grid.h:226-308): `at(offset, z_mask)`
+template <class F>
+__device__ __forceinline__ void raytrace3d(uint32_t nx, double x0, double y0, double z0, double x1, double y1, double z1,
+                                           uint32_t max_length, F&& at) {
+  int dx = int(x1) - int(x0), dy = int(y1) - int(y0), dz = int(z1) - int(z0);
+  uint32_t abs_dx = dx < 0 ? -dx : dx, abs_dy = dy < 0 ? -dy : dy, abs_dz = dz < 0 ? -dz : dz;
+  int offset_dx = dx > 0 ? 1 : -1;
+  int offset_dy = (dy > 0 ? 1 : -1) * (int)nx;
+  int offset_dz = dz > 0 ? 1 : -1;
+  uint32_t z_mask = ((1u << 16) | 1u) << (uint32_t)z0;
+  uint32_t offset = (uint32_t)y0 * nx + (uint32_t)x0;
+  double dist = sqrt((x0 - x1) * (x0 - x1) + (y0 - y1) * (y0 - y1) + (z0 - z1) * (z0 - z1));
+  double scale = fmin(1.0, (double)max_length / dist);
+  // axis roles: 0 = grid offset, 1 = z mask
+  uint32_t abs_da, abs_db, abs_dc;
+  int off_a, off_b, off_c, role_a, role_b, role_c;
+  uint32_t mmax = abs_dy > abs_dz ? abs_dy : abs_dz;
+  if (abs_dx >= mmax) {
+    abs_da = abs_dx; abs_db = abs_dy; abs_dc = abs_dz;
+    off_a = offset_dx; off_b = offset_dy; off_c = offset_dz;
+    role_a = 0; role_b = 0; role_c = 1;
+  } else if (abs_dy >= abs_dz) {
+    abs_da = abs_dy; abs_db = abs_dx; abs_dc = abs_dz;
+    off_a = offset_dy; off_b = offset_dx; off_c = offset_dz;
+    role_a = 0; role_b = 0; role_c = 1;
+  } else {
+    abs_da = abs_dz; abs_db = abs_dx; abs_dc = abs_dy;
+    off_a = offset_dz; off_b = offset_dx; off_c = offset_dy;
+    role_a = 1; role_b = 0; role_c = 0;
+  }
+  auto step = [&](int role, int v) {
+    if (role == 0)
+      offset += v;
+    else {
+      if (v > 0)
+        z_mask <<= 1;
+      else
+        z_mask >>= 1;
+    }
+  };
+  uint32_t lim = (uint32_t)(scale * abs_da);
+  uint32_t end = lim < abs_da ? lim : abs_da;
+  int error_b = abs_da / 2, error_c = abs_da / 2;
+  for (uint32_t i = 0; i < end; ++i) {
+    at(offset, z_mask);
+    step(role_a, off_a);
+    error_b += abs_db;
+    error_c += abs_dc;
+    if ((uint32_t)error_b >= abs_da) {
+      step(role_b, off_b);
+      error_b -= abs_da;
+    }
+    if ((uint32_t)error_c >= abs_da) {
+      step(role_c, off_c);
+      error_c -= abs_da;
+    }
+  }
+  at(offset, z_mask);
+}
+
+__device__ __forceinline__ uint32_t cellDistance(double world_dist, double res) {  // costmap_2d.cpp:181-185
+  double c = fmax(0.0, ceil(world_dist / res));
+  return (uint32_t)c;
+}
+// VoxelGrid::bitsBelowThreshold (voxel_grid.h:151-164) == popcount(n) <= thr
+__device__ __forceinline__ bool bitsBelowThreshold(uint32_t n, uint32_t thr) { return (uint32_t)__popc(n) <= thr; }
+
+struct BoundsAcc {
+  double min_x, min_y, max_x, max_y;
+  __device__ __forceinline__ void touch(double x, double y) {  // CostmapLayer::touch: std::min(x, *min_x) ...
+    min_x = (min_x < x) ? min_x : x;
+    min_y = (min_y < y) ? min_y : y;
+    max_x = (max_x < x) ? x : max_x;
+    max_y = (max_y < y) ? y : max_y;
+  }
+};
+
+__device__ __forceinline__ void enforceBounds(const Geom& g, double wx, double wy, int& mx, int& my) {  // costmap_2d.cpp:228-262
+  if (wx < g.ox)
+    mx = 0;
+  else if (wx > g.res * (g.nx - 1) + g.ox)
+    mx = g.nx - 1;
+  else
+    mx = (int)((wx - g.ox) / g.res);
+  if (wy < g.oy)
+    my = 0;
+  else if (wy > g.res * (g.ny - 1) + g.oy)
+    my = g.ny - 1;
+  else
+    my = (int)((wy - g.oy) / g.res);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_obstacle: one 256-thread workgroup per robot instance.
+//   ObstacleLayer::updateBounds   plugins/obstacle_layer.cpp:340-413 (+ raytraceFreespace :498-576,
+//                                 updateRaytraceBounds :602-610, updateFootprint :415-425)
+//   VoxelLayer::updateBounds      plugins/voxel_layer.cpp:116-213 (+ raytraceFreespace :266-383)
+//   StaticLayer::updateBounds     plugins/static_layer.cpp:263-283
+//   InflationLayer::updateBounds  plugins/inflation_layer.cpp:125-158
+//   LayeredCostmap::updateMap     src/layered_costmap.cpp:96-135 (bounds -> cell box)
+//   ObstacleLayer::updateCosts    plugins/obstacle_layer.cpp:432-435 (footprint polygon clearing,
+//                                 Costmap2D::setConvexPolygonCost src/costmap_2d.cpp:315-428)
+// Ordering kept from the reference: every clearing ray before any mark (workgroup barrier
+// between the phases); all rays write FREE_SPACE so write-write races are benign.  The voxel
+// clear phase is split in two (column bits with atomics, then the dependent 2-D byte from the
+// final column state) which is equivalent because bits only ever get cleared during the phase.
+// ------------------------------------------------------------------------------------------------
+template <bool VOXEL>
+__global__ __launch_bounds__(256) void k_obstacle(CostmapDev cm, uint32_t first, const double* bounds_io_in, double* bounds_io_out,
+                                                  int only_bounds) {
+  const uint32_t inst = first + blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  Geom g{cm.origin[2 * inst], cm.origin[2 * inst + 1], cm.res, cm.nx, cm.ny};
+  uint8_t* layer = cm.obst + (size_t)inst * cm.cells_padded;
+  uint32_t* vox = VOXEL ? cm.voxel + (size_t)inst * cm.cells_padded : nullptr;
+  InstCostmapState* st = cm.state + inst;
+
+  __shared__ double red[4][4];
+  __shared__ int s_box_valid;
+  __shared__ uint32_t colmin[1024], colmax[1024];
+  __shared__ uint32_t s_vx[kMaxFootprint], s_vy[kMaxFootprint];
+  __shared__ int s_poly_ok;
+
+  BoundsAcc b{1e30, 1e30, -1e30, -1e30};
+  if (tid == 0) {
+    if (bounds_io_in) {
+      b.min_x = bounds_io_in[4 * blockIdx.x + 0];
+      b.min_y = bounds_io_in[4 * blockIdx.x + 1];
+      b.max_x = bounds_io_in[4 * blockIdx.x + 2];
+      b.max_y = bounds_io_in[4 * blockIdx.x + 3];
+    }
+    if (!only_bounds && (cm.layers & NAVGPU_LAYER_STATIC) && st->static_has_updated_data) {
+      // mapToWorld(x_, y_) and (x_+width_, y_+height_) with the whole map as the updated window
+      double wx = g.ox + (0 + 0.5) * g.res, wy = g.oy + (0 + 0.5) * g.res;
+      b.min_x = (wx < b.min_x) ? wx : b.min_x;  // std::min(wx, *min_x)
+      b.min_y = (wy < b.min_y) ? wy : b.min_y;
+      wx = g.ox + (g.nx + 0.5) * g.res;
+      wy = g.oy + (g.ny + 0.5) * g.res;
+      b.max_x = (b.max_x < wx) ? wx : b.max_x;
+      b.max_y = (b.max_y < wy) ? wy : b.max_y;
+      st->static_has_updated_data = 0;
+    }
+  }
+
+  const bool has_obs_layer = (cm.layers & (NAVGPU_LAYER_OBSTACLE | NAVGPU_LAYER_VOXEL)) && cm.obs_enabled;
+  const uint32_t ob = inst * cm.max_obs, oe = ob + cm.obs_count[inst];
+  const float* inst_points = cm.points + (size_t)inst * cm.max_points * 3;
+  const uint32_t unknown_thr = VOXEL ? (uint32_t)(cm.unknown_threshold + (16 - cm.z_voxels)) : 0;  // voxel_layer.cpp:89
+  const uint32_t mark_thr = VOXEL ? (uint32_t)cm.mark_threshold : 0;
+  const uint32_t size_z = VOXEL ? (uint32_t)(cm.z_voxels > 16 ? 16 : cm.z_voxels) : 0;
+
+  if (has_obs_layer) {
+    // ---------------- phase 1: clearing observations
+    for (int pass = 0; pass < (VOXEL ? 2 : 1); ++pass) {
+      for (uint32_t o = ob; o < oe; ++o) {
+        const ObsCsr obs = cm.obs[o];
+        if (!(obs.flags & NAVGPU_OBS_CLEARING)) continue;
+        const float* pts = inst_points + (size_t)obs.first_point * 3;
+        if (!VOXEL) {
+          uint32_t x0, y0;
+          if (!worldToMap(g, obs.ox, obs.oy, x0, y0)) continue;
+          const double map_end_x = g.ox + g.nx * g.res, map_end_y = g.oy + g.ny * g.res;
+          if (tid == 0) b.touch(obs.ox, obs.oy);
+          const uint32_t cell_range = cellDistance(obs.raytrace_range, g.res);
+          for (uint32_t p = tid; p < obs.n_points; p += blockDim.x) {
+            double wx = pts[3 * p], wy = pts[3 * p + 1];
+            const double ox = obs.ox, oy = obs.oy;
+            double a = wx - ox, bb = wy - oy;
+            if (wx < g.ox) {
+              double t = (g.ox - ox) / a;
+              wx = g.ox;
+              wy = oy + bb * t;
+            }
+            if (wy < g.oy) {
+              double t = (g.oy - oy) / bb;
+              wx = ox + a * t;
+              wy = g.oy;
+            }
+            if (wx > map_end_x) {
+              double t = (map_end_x - ox) / a;
+              wx = map_end_x - .001;
+              wy = oy + bb * t;
+            }
+            if (wy > map_end_y) {
+              double t = (map_end_y - oy) / bb;
+              wx = ox + a * t;
+              wy = map_end_y - .001;
+            }
+            uint32_t x1, y1;
+            if (!worldToMap(g, wx, wy, x1, y1)) continue;
+            raytrace2d(g.nx, x0, y0, x1, y1, cell_range, [&](uint32_t off) { layer[off] = kFree; });
+            double dx = wx - ox, dy = wy - oy;
+            double full = hyp2(dx, dy);
+            double scale = fmin(1.0, obs.raytrace_range / full);
+            b.touch(ox + dx * scale, oy + dy * scale);
+          }
+        } else {
+          if (obs.n_points == 0) continue;
+          const double ox = obs.ox, oy = obs.oy, oz = obs.oz;
+          // worldToMap3DFloat (voxel_layer.h:107-118)
+          if (ox < g.ox || oy < g.oy || oz < cm.origin_z) continue;
+          const double sensor_x = (ox - g.ox) / g.res, sensor_y = (oy - g.oy) / g.res, sensor_z = (oz - cm.origin_z) / cm.z_resolution;
+          if (!(sensor_x < g.nx && sensor_y < g.ny && sensor_z < size_z)) continue;
+          const double map_end_x = g.ox + (g.nx - 1 + 0.5) * g.res;  // origin + getSizeInMetersX()
+          const double map_end_y = g.oy + (g.ny - 1 + 0.5) * g.res;
+          const uint32_t cell_range = cellDistance(obs.raytrace_range, g.res);
+          for (uint32_t p = tid; p < obs.n_points; p += blockDim.x) {
+            double wpx = pts[3 * p], wpy = pts[3 * p + 1], wpz = pts[3 * p + 2];
+            double distance = sqrt((ox - wpx) * (ox - wpx) + (oy - wpy) * (oy - wpy) + (oz - wpz) * (oz - wpz));
+            double scaling_fact = fmax(fmin(1.0, (distance - 2 * g.res) / distance), 0.0);
+            wpx = scaling_fact * (wpx - ox) + ox;
+            wpy = scaling_fact * (wpy - oy) + oy;
+            wpz = scaling_fact * (wpz - oz) + oz;
+            double a = wpx - ox, bb = wpy - oy, c = wpz - oz, t = 1.0;
+            if (wpz > cm.max_obstacle_height)
+              t = fmax(0.0, fmin(t, (cm.max_obstacle_height - 0.01 - oz) / c));
+            else if (wpz < cm.origin_z)
+              t = fmin(t, (cm.origin_z - oz) / c);
+            if (wpx < g.ox) t = fmin(t, (g.ox - ox) / a);
+            if (wpy < g.oy) t = fmin(t, (g.oy - oy) / bb);
+            if (wpx > map_end_x) t = fmin(t, (map_end_x - ox) / a);
+            if (wpy > map_end_y) t = fmin(t, (map_end_y - oy) / bb);
+            wpx = ox + a * t;
+            wpy = oy + bb * t;
+            wpz = oz + c * t;
+            if (wpx < g.ox || wpy < g.oy || wpz < cm.origin_z) continue;
+            double px = (wpx - g.ox) / g.res, py = (wpy - g.oy) / g.res, pz = (wpz - cm.origin_z) / cm.z_resolution;
+            if (!(px < g.nx && py < g.ny && pz < size_z)) continue;
+            // clearVoxelLineInMap endpoint check (voxel_grid.cpp:131-136) is implied by the two tests above
+            if (pass == 0) {
+              raytrace3d(g.nx, sensor_x, sensor_y, sensor_z, px, py, pz, cell_range,
+                         [&](uint32_t off, uint32_t zm) { atomicAnd(&vox[off], ~zm); });
+              double dx = wpx - ox, dy = wpy - oy;
+              double full = hyp2(dx, dy);
+              double scale = fmin(1.0, obs.raytrace_range / full);
+              b.touch(ox + dx * scale, oy + dy * scale);
+            } else {
+              raytrace3d(g.nx, sensor_x, sensor_y, sensor_z, px, py, pz, cell_range, [&](uint32_t off, uint32_t) {
+                uint32_t col = vox[off];
+                uint32_t unknown_bits = (uint16_t)(col >> 16) ^ (uint16_t)col;
+                uint32_t marked_bits = col >> 16;
+                if (bitsBelowThreshold(marked_bits, mark_thr))
+                  layer[off] = bitsBelowThreshold(unknown_bits, unknown_thr) ? kFree : kNoInfo;
+              });
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // ---------------- phase 2: marking observations
+    for (uint32_t o = ob; o < oe; ++o) {
+      const ObsCsr obs = cm.obs[o];
+      if (!(obs.flags & NAVGPU_OBS_MARKING)) continue;
+      const float* pts = inst_points + (size_t)obs.first_point * 3;
+      const double sq_obstacle_range = obs.obstacle_range * obs.obstacle_range;
+      for (uint32_t p = tid; p < obs.n_points; p += blockDim.x) {
+        const float fx = pts[3 * p], fy = pts[3 * p + 1], fz = pts[3 * p + 2];
+        double px = fx, py = fy, pz = fz;
+        if (pz > cm.max_obstacle_height) continue;
+        double sq_dist = (px - obs.ox) * (px - obs.ox) + (py - obs.oy) * (py - obs.oy) + (pz - obs.oz) * (pz - obs.oz);
+        if (sq_dist >= sq_obstacle_range) continue;
+        if (!VOXEL) {
+          uint32_t mx, my;
+          if (!worldToMap(g, px, py, mx, my)) continue;
+          layer[my * g.nx + mx] = kLethal;
+          b.touch(px, py);
+        } else {
+          double wz = (pz < cm.origin_z) ? cm.origin_z : pz;  // voxel_layer.cpp:169-173
+          if (px < g.ox || py < g.oy || wz < cm.origin_z) continue;
+          double fxm = (px - g.ox) / g.res, fym = (py - g.oy) / g.res, fzm = (wz - cm.origin_z) / cm.z_resolution;
+          if (!(fxm < 2147483648.0) || !(fym < 2147483648.0) || !(fzm < 2147483648.0)) continue;
+          uint32_t mx = (uint32_t)(int)fxm, my = (uint32_t)(int)fym, mz = (uint32_t)(int)fzm;
+          if (!(mx < g.nx && my < g.ny && mz < (uint32_t)cm.z_voxels)) continue;  // worldToMap3D uses size_z_ as configured
+          if (mz >= size_z) continue;                                             // VoxelGrid::markVoxelInMap bound (voxel_grid.h:102)
+          uint32_t full_mask = ((uint32_t)1 << mz << 16) | (1u << mz);
+          uint32_t old = atomicOr(&vox[my * g.nx + mx], full_mask);
+          uint32_t marked_bits = (old | full_mask) >> 16;
+          if (!bitsBelowThreshold(marked_bits, mark_thr)) {
+            layer[my * g.nx + mx] = kLethal;
+            b.touch(px, py);
+          }
+        }
+      }
+    }
+    // ---------------- updateFootprint: touch the transformed footprint
+    if (cm.footprint_clearing) {
+      uint32_t nfp = cm.fp_n[inst];
+      if (tid < nfp) b.touch(cm.fp_world[((size_t)inst * kMaxFootprint + tid) * 2], cm.fp_world[((size_t)inst * kMaxFootprint + tid) * 2 + 1]);
+    }
+  }
+
+  // ---------------- workgroup reduction of the bounds (min/max are exact, order-free)
+  for (int off = 32; off > 0; off >>= 1) {
+    double o0 = __shfl_down(b.min_x, off), o1 = __shfl_down(b.min_y, off), o2 = __shfl_down(b.max_x, off), o3 = __shfl_down(b.max_y, off);
+    b.min_x = (o0 < b.min_x) ? o0 : b.min_x;
+    b.min_y = (o1 < b.min_y) ? o1 : b.min_y;
+    b.max_x = (b.max_x < o2) ? o2 : b.max_x;
+    b.max_y = (b.max_y < o3) ? o3 : b.max_y;
+  }
+  if ((tid & 63) == 0) {
+    red[tid >> 6][0] = b.min_x;
+    red[tid >> 6][1] = b.min_y;
+    red[tid >> 6][2] = b.max_x;
+    red[tid >> 6][3] = b.max_y;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) {
+      b.min_x = (red[w][0] < b.min_x) ? red[w][0] : b.min_x;
+      b.min_y = (red[w][1] < b.min_y) ? red[w][1] : b.min_y;
+      b.max_x = (b.max_x < red[w][2]) ? red[w][2] : b.max_x;
+      b.max_y = (b.max_y < red[w][3]) ? red[w][3] : b.max_y;
+    }
+    if (only_bounds) {
+      bounds_io_out[4 * blockIdx.x + 0] = b.min_x;
+      bounds_io_out[4 * blockIdx.x + 1] = b.min_y;
+      bounds_io_out[4 * blockIdx.x + 2] = b.max_x;
+      bounds_io_out[4 * blockIdx.x + 3] = b.max_y;
+      s_box_valid = 0;
+    } else {
+      if (cm.layers & NAVGPU_LAYER_INFLATION) {  // InflationLayer::updateBounds
+        if (st->need_reinflation) {
+          st->last_min_x = b.min_x;
+          st->last_min_y = b.min_y;
+          st->last_max_x = b.max_x;
+          st->last_max_y = b.max_y;
+          b.min_x = -3.4028234663852886e38;  // -std::numeric_limits<float>::max()
+          b.min_y = -3.4028234663852886e38;
+          b.max_x = 3.4028234663852886e38;
+          b.max_y = 3.4028234663852886e38;
+          st->need_reinflation = 0;
+        } else {
+          double tminx = st->last_min_x, tminy = st->last_min_y, tmaxx = st->last_max_x, tmaxy = st->last_max_y;
+          st->last_min_x = b.min_x;
+          st->last_min_y = b.min_y;
+          st->last_max_x = b.max_x;
+          st->last_max_y = b.max_y;
+          b.min_x = ((b.min_x < tminx) ? b.min_x : tminx) - cm.inflation_radius;  // std::min(tmp_min_x, *min_x)
+          b.min_y = ((b.min_y < tminy) ? b.min_y : tminy) - cm.inflation_radius;
+          b.max_x = ((tmaxx < b.max_x) ? b.max_x : tmaxx) + cm.inflation_radius;
+          b.max_y = ((tmaxy < b.max_y) ? b.max_y : tmaxy) + cm.inflation_radius;
+        }
+      }
+      st->bounds[0] = b.min_x;
+      st->bounds[1] = b.min_y;
+      st->bounds[2] = b.max_x;
+      st->bounds[3] = b.max_y;
+      int x0, xn, y0, yn;
+      enforceBounds(g, b.min_x, b.min_y, x0, y0);
+      enforceBounds(g, b.max_x, b.max_y, xn, yn);
+      x0 = x0 > 0 ? x0 : 0;
+      xn = ((int)g.nx < xn + 1) ? (int)g.nx : xn + 1;
+      y0 = y0 > 0 ? y0 : 0;
+      yn = ((int)g.ny < yn + 1) ? (int)g.ny : yn + 1;
+      st->box[0] = x0;
+      st->box[1] = xn;
+      st->box[2] = y0;
+      st->box[3] = yn;
+      st->box_valid = !(xn < x0 || yn < y0);
+      s_box_valid = st->box_valid;
+    }
+  }
+  __syncthreads();
+
+  // ---------------- ObstacleLayer::updateCosts head: clear the robot footprint polygon in the layer grid.
+  // setConvexPolygonCost == per column x, every cell between the lowest and the highest outline
+  // cell of that column (the bubble sort + pairwise walk of convexFillCells yields exactly this
+  // because each outline column holds >= 2 entries of a closed outline; tests/test_polygon_fill).
+  if (has_obs_layer && cm.footprint_clearing && s_box_valid) {
+    const uint32_t nfp = cm.fp_n[inst];
+    if (tid == 0) s_poly_ok = nfp >= 3;
+    __syncthreads();
+    if (tid < nfp) {
+      uint32_t mx, my;
+      bool ok = worldToMap(g, cm.fp_world[((size_t)inst * kMaxFootprint + tid) * 2], cm.fp_world[((size_t)inst * kMaxFootprint + tid) * 2 + 1], mx, my);
+      s_vx[tid] = mx;
+      s_vy[tid] = my;
+      if (!ok) atomicAnd(&s_poly_ok, 0);
+    }
+    __syncthreads();
+    if (s_poly_ok) {
+      uint32_t minx = 0xFFFFFFFFu, maxx = 0;
+      for (uint32_t i = 0; i < nfp; ++i) {
+        minx = s_vx[i] < minx ? s_vx[i] : minx;
+        maxx = s_vx[i] > maxx ? s_vx[i] : maxx;
+      }
+      const uint32_t span = maxx - minx + 1;
+      if (span <= 1024) {
+        for (uint32_t c = tid; c < span; c += blockDim.x) {
+          colmin[c] = 0xFFFFFFFFu;
+          colmax[c] = 0;
+        }
+        __syncthreads();
+        if (tid < nfp) {
+          uint32_t e1 = (tid + 1 == nfp) ? 0 : tid + 1;
+          raytrace2d(g.nx, s_vx[tid], s_vy[tid], s_vx[e1], s_vy[e1], 0xFFFFFFFFu, [&](uint32_t off) {
+            uint32_t y = off / g.nx, x = off - y * g.nx;
+            atomicMin(&colmin[x - minx], y);
+            atomicMax(&colmax[x - minx], y);
+          });
+        }
+        __syncthreads();
+        for (uint32_t c = tid >> 4; c < span; c += blockDim.x >> 4) {
+          uint32_t lo = colmin[c], hi = colmax[c];
+          if (lo == 0xFFFFFFFFu) continue;
+          for (uint32_t y = lo + (tid & 15); y <= hi; y += 16) layer[y * g.nx + minx + c] = kFree;
+        }
+      }
+    }
+  }
+}
+
+void launch_obstacle(const CostmapDev& cm, uint32_t first, uint32_t count, const double* bounds_in, int only_bounds, hipStream_t s) {
+  // bounds_in doubles as the in/out buffer in only_bounds mode
+  double* bounds_out = const_cast<double*>(bounds_in);
+  if (cm.layers & NAVGPU_LAYER_VOXEL)
+    hipLaunchKernelGGL(k_obstacle<true>, dim3(count), dim3(256), 0, s, cm, first, bounds_in, bounds_out, only_bounds);
+  else
+    hipLaunchKernelGGL(k_obstacle<false>, dim3(count), dim3(256), 0, s, cm, first, bounds_in, bounds_out, only_bounds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_merge: Costmap2D::resetMap (costmap_2d.cpp:93-99) over the box, then StaticLayer::updateCosts
+// (static_layer.cpp:285-299: updateWithTrueOverwrite | updateWithMax) and ObstacleLayer::updateCosts
+// (obstacle_layer.cpp:437-447: updateWithOverwrite | updateWithMax, costmap_layer.cpp:62-124),
+// fused per byte.  16 cells per thread: three 16-byte reads and one 16-byte write, fully coalesced.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_merge(CostmapDev cm, uint32_t first, const int32_t* boxes, int static_received) {
+  const uint32_t inst = first + blockIdx.y;
+  int x0, xn, y0, yn;
+  if (boxes) {
+    x0 = boxes[4 * blockIdx.y + 0];
+    y0 = boxes[4 * blockIdx.y + 1];
+    xn = boxes[4 * blockIdx.y + 2];
+    yn = boxes[4 * blockIdx.y + 3];
+  } else {
+    const InstCostmapState* st = cm.state + inst;
+    if (!st->box_valid) return;
+    x0 = st->box[0];
+    xn = st->box[1];
+    y0 = st->box[2];
+    yn = st->box[3];
+  }
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;  // 16-cell group
+  const uint32_t base = q * 16;
+  if (base >= cm.cells) return;
+  // rows touched by this group
+  const int row_first = base / cm.nx, row_last = (min(base + 15, cm.cells - 1)) / cm.nx;
+  if (row_last < y0 || row_first >= yn) return;
+  const size_t off = (size_t)inst * cm.cells_padded + base;
+  uint4 mv = *reinterpret_cast<const uint4*>(cm.master + off);
+  const bool has_static = (cm.layers & NAVGPU_LAYER_STATIC) && static_received;
+  const bool has_obst = (cm.layers & (NAVGPU_LAYER_OBSTACLE | NAVGPU_LAYER_VOXEL)) && cm.obs_enabled;
+  uint4 sv = has_static ? *reinterpret_cast<const uint4*>(cm.stat + off) : make_uint4(0, 0, 0, 0);
+  uint4 lv = has_obst ? *reinterpret_cast<const uint4*>(cm.obst + off) : make_uint4(0, 0, 0, 0);
+  uint32_t mw[4] = {mv.x, mv.y, mv.z, mv.w}, sw[4] = {sv.x, sv.y, sv.z, sv.w}, lw[4] = {lv.x, lv.y, lv.z, lv.w};
+  int y = row_first;
+  int x = base - row_first * cm.nx;
+  bool changed = false;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (base + k < cm.cells && x >= x0 && x < xn && y >= y0 && y < yn) {
+      const int sh = (k & 3) * 8;
+      uint8_t m = cm.master_default;  // resetMap
+      if (has_static) {
+        uint8_t sc = (sw[k >> 2] >> sh) & 0xFF;
+        if (!cm.static_use_maximum)
+          m = sc;
+        else if (sc != kNoInfo && (m == kNoInfo || m < sc))
+          m = sc;
+      }
+      if (has_obst) {
+        uint8_t lc = (lw[k >> 2] >> sh) & 0xFF;
+        if (lc != kNoInfo) {
+          if (cm.combination_method == 0)
+            m = lc;
+          else if (cm.combination_method == 1 && (m == kNoInfo || m < lc))
+            m = lc;
+        }
+      }
+      mw[k >> 2] = (mw[k >> 2] & ~(0xFFu << sh)) | ((uint32_t)m << sh);
+      changed = true;
+    }
+    if (++x == (int)cm.nx) {
+      x = 0;
+      ++y;
+    }
+  }
+  if (changed) *reinterpret_cast<uint4*>(cm.master + off) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+}
+
+void launch_merge(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s) {
+  uint32_t groups = (cm.cells + 15) / 16;
+  dim3 grid((groups + 255) / 256, count);
+  hipLaunchKernelGGL(k_merge, grid, dim3(256), 0, s, cm, first, boxes, cm.static_received);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_inflate: InflationLayer::updateCosts (plugins/inflation_layer.cpp:172-266) restated as an
+// order-independent windowed exact Euclidean transform: a cell takes
+//     max over LETHAL seeds s inside the grown box, |c - s| <= R, of cached_costs_[|dx|][|dy|]
+// ( == the cost of the nearest seed, the tables being monotone in distance ), merged with the
+// old value by the reference rule (:243-247).  Separable: pass A finds, per row, the nearest
+// seed column distance; pass B takes the max over the 2R+1 rows through the cost table.
+// Tile = 64x64 output cells per 256-thread workgroup, (64+2R)^2 seed flags staged in LDS.
+// Bit-exact against oracle updateCostsExact(); >= the reference's priority-queue result, which
+// itself depends on std::priority_queue tie order (SURVEY §7 hard part 1).
+// ------------------------------------------------------------------------------------------------
+constexpr int kTile = 64;
+__global__ __launch_bounds__(256) void k_inflate(CostmapDev cm, uint32_t first, const int32_t* boxes) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const uint32_t inst = first + blockIdx.z;
+  const int R = (int)cm.R;
+  int min_i, min_j, max_i, max_j;
+  if (boxes) {
+    min_i = boxes[4 * blockIdx.z + 0];
+    min_j = boxes[4 * blockIdx.z + 1];
+    max_i = boxes[4 * blockIdx.z + 2];
+    max_j = boxes[4 * blockIdx.z + 3];
+  } else {
+    const InstCostmapState* st = cm.state + inst;
+    if (!st->box_valid) return;
+    min_i = st->box[0];
+    max_i = st->box[1];
+    min_j = st->box[2];
+    max_j = st->box[3];
+  }
+  // grown + clamped box (:205-213)
+  min_i = max(0, min_i - R);
+  min_j = max(0, min_j - R);
+  max_i = min((int)cm.nx, max_i + R);
+  max_j = min((int)cm.ny, max_j + R);
+  const int tx0 = blockIdx.x * kTile, ty0 = blockIdx.y * kTile;
+  // seeds that can reach this tile lie in [tx0-R, tx0+kTile+R) x [ty0-R, ty0+kTile+R)
+  if (tx0 - R >= max_i || tx0 + kTile + R <= min_i || ty0 - R >= max_j || ty0 + kTile + R <= min_j) return;
+
+  const int W = kTile + 2 * R;           // halo'd tile edge
+  const int WS = (W + 3) & ~3;           // padded row stride of the seed flags
+  uint8_t* seed = lds;                   // [W][WS]
+  uint8_t* hd = seed + W * WS;           // [W][kTile] nearest seed |dx| per row, 255 = none within R
+  uint8_t* lut = hd + W * kTile;         // [(R+2)^2]
+  __shared__ int s_any;
+  const uint32_t tid = threadIdx.x;
+  uint8_t* master = cm.master + (size_t)inst * cm.cells_padded;
+  if (tid == 0) s_any = 0;
+  for (int i = tid; i < (R + 2) * (R + 2); i += blockDim.x) lut[i] = cm.lut[i];
+  __syncthreads();
+  int any = 0;
+  for (int i = tid; i < W * W; i += blockDim.x) {
+    int ly = i / W, lx = i - ly * W;
+    int gx = tx0 - R + lx, gy = ty0 - R + ly;
+    uint8_t f = 0;
+    if (gx >= min_i && gx < max_i && gy >= min_j && gy < max_j) f = master[gy * cm.nx + gx] == kLethal;
+    seed[ly * WS + lx] = f;
+    any |= f;
+  }
+  if (any) s_any = 1;
+  __syncthreads();
+  if (!s_any) return;
+  // pass A
+  for (int i = tid; i < W * kTile; i += blockDim.x) {
+    int ly = i / kTile, c = i - ly * kTile;
+    const uint8_t* row = seed + ly * WS + c + R;
+    uint8_t best = 255;
+    for (int d = 0; d <= R; ++d) {
+      if (row[d] | row[-d]) {
+        best = (uint8_t)d;
+        break;
+      }
+    }
+    hd[i] = best;
+  }
+  __syncthreads();
+  // pass B + merge
+  const int n = R + 2;
+  for (int i = tid; i < kTile * kTile; i += blockDim.x) {
+    int ry = i / kTile, c = i - ry * kTile;
+    int gx = tx0 + c, gy = ty0 + ry;
+    if (gx >= (int)cm.nx || gy >= (int)cm.ny) continue;
+    uint8_t cost = 0;
+    for (int dy = -R; dy <= R; ++dy) {
+      uint8_t h = hd[(ry + R + dy) * kTile + c];
+      if (h != 255) {
+        int ady = dy < 0 ? -dy : dy;
+        uint8_t cc = lut[h * n + ady];
+        cost = cc > cost ? cc : cost;  // lut holds 0 beyond the radius
+      }
+    }
+    if (cost == 0) continue;  // max(old, 0) == old and the 255-rule needs cost >= 253
+    uint8_t old = master[gy * cm.nx + gx];
+    uint8_t nv = (old == kNoInfo && cost >= kInscribed) ? cost : (old > cost ? old : cost);
+    if (nv != old) master[gy * cm.nx + gx] = nv;
+  }
+}
+
+void launch_inflate(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s) {
+  if (!cm.infl_enabled) return;
+  const int R = (int)cm.R;
+  const int W = kTile + 2 * R, WS = (W + 3) & ~3;
+  size_t lds = (size_t)W * WS + (size_t)W * kTile + (size_t)(R + 2) * (R + 2);
+  dim3 grid((cm.nx + kTile - 1) / kTile, (cm.ny + kTile - 1) / kTile, count);
+  hipLaunchKernelGGL(k_inflate, grid, dim3(256), lds, s, cm, first, boxes);
+}
+
+}  // namespace navgpu

@@ -1,0 +1,148 @@
+// Internal header shared by the HIP kernels and the C-ABI host code (gfx950 only).
+// Data layout in HBM (all SoA over instances, instance-major):
+//   master/static/obstacle : uint8  [n][cells_padded]   row-major, index = my*size_x + mx
+//   voxel                  : uint32 [n][cells_padded]
+//   path / goal / goal_front: uint32 [n][cells]   MapGrid target_dist of path_costs_ (shared by
+//                            alignment_costs_, same target poses), goal_costs_, goal_front_costs_
+// MapGrid distances are stored as uint32 (the reference keeps doubles that only ever hold
+// integers <= size_x*size_y+1; map_cell.h:44-64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/navgpu.h"
+
+namespace navgpu {
+
+constexpr uint8_t kNoInfo = 255, kLethal = 254, kInscribed = 253, kFree = 0;
+constexpr int kMaxFootprint = 32;  // vertices kept in registers/LDS by the kernels
+
+struct InstCostmapState {  // per-instance state that persists across update cycles (device resident)
+  double last_min_x, last_min_y, last_max_x, last_max_y;  // InflationLayer::last_* (inflation_layer.cpp:63-66)
+  int32_t need_reinflation;                               // InflationLayer::need_reinflation_
+  int32_t static_has_updated_data;                        // StaticLayer::has_updated_data_
+  int32_t box[4];                                         // x0, xn, y0, yn of the last updateMap
+  int32_t box_valid;                                      // 0 when xn < x0 || yn < y0 (layered_costmap.cpp:128-135)
+  int32_t pad;
+  double bounds[4];                                       // min_x, min_y, max_x, max_y after all updateBounds
+};
+
+struct ObsCsr {  // one observation, device form
+  uint32_t first_point, n_points, flags, pad;
+  double ox, oy, oz;
+  double obstacle_range, raytrace_range;
+};
+
+struct CostmapDev {
+  uint32_t nx, ny, cells, cells_padded;
+  double res;
+  int32_t layers, track_unknown;
+  uint8_t master_default, obstacle_default;
+  // layer params
+  int32_t obs_enabled, footprint_clearing, combination_method, static_use_maximum, static_received;
+  double max_obstacle_height;
+  // voxel
+  int32_t z_voxels, unknown_threshold, mark_threshold;
+  double origin_z, z_resolution;
+  // inflation
+  int32_t infl_enabled;
+  uint32_t R;  // cell_inflation_radius_
+  double inflation_radius;
+  // buffers
+  double* origin;      // [n][2]
+  uint8_t *master, *stat, *obst;
+  uint32_t* voxel;
+  uint8_t* lut;        // (R+2)^2 cost table with 0 where cached distance > R
+  InstCostmapState* state;  // [n]
+  // staged cycle inputs
+  double* pose;        // [n][3]
+  double* fp_world;    // [n][kMaxFootprint][2] transformed footprint (host fp64 libm, footprint.cpp:103-118)
+  uint32_t* fp_n;      // [n]
+  ObsCsr* obs;         // [n][max_obs] observations of the staged cycle (first_point relative to the instance block)
+  uint32_t* obs_count; // [n]
+  float* points;       // [n][max_points][3] xyz
+  uint32_t max_obs, max_points;
+};
+
+struct PlannerDev {
+  uint32_t nx, ny, cells;
+  double res;
+  double* origin;  // [n][2] (shared with the costmap)
+  const uint8_t* master;
+  uint32_t cells_padded;
+  navgpu_dwa_config cfg;
+  // derived once per configure (dwa_planner.cpp:64-75)
+  double scale_path, scale_goal, scale_obstacle;
+  uint32_t max_plan, max_sim_steps, max_axis;  // max_axis = per-axis sample capacity
+  uint32_t max_samples, score_blocks;
+  // staged inputs
+  navgpu_robot_state* state;  // [n]
+  double* plan;               // [n][max_plan][2]
+  uint32_t* plan_count;       // [n]
+  double* front_last;         // [n][2] last pose of front_global_plan (nose goal)
+  int32_t* align_on;          // [n] alignment_costs_ scale != 0
+  double* fp_spec;            // [n][kMaxFootprint][2] robot-frame footprint
+  uint32_t* fp_n;             // [n]
+  // per-cycle work buffers
+  float* axis_samples;        // [n][3][max_axis]
+  int32_t* axis_count;        // [n][4]  (nx, ny, nth, total)
+  uint32_t *path, *goal, *goal_front;  // [n][cells] each
+  uint32_t win;               // edge (cells) of the costmap window staged in LDS by k_score
+  double* sample_cost;        // [n][max_samples] or null
+  int32_t* sample_status;     // [n][max_samples] or null
+  double* part_cost;          // [n][score_blocks]
+  int32_t* part_index;        // [n][score_blocks]
+  int32_t* counters;          // [n][2] scored, valid
+  uint32_t* osc_flags;        // [n]
+  float* osc_prev;            // [n][3]
+  navgpu_plan_result* result; // [n]
+  double* traj;               // [n][max_sim_steps][3]
+};
+
+// ---- launchers (defined in the .hip files) ---------------------------------------------------
+void launch_obstacle(const CostmapDev& cm, uint32_t first, uint32_t count, const double* bounds_in, int only_bounds,
+                     hipStream_t s);
+void launch_merge(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s);
+void launch_inflate(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s);
+void launch_static_interpret(uint8_t* dst, const int8_t* occ, uint32_t cells, uint32_t cells_padded, uint32_t count,
+                             int track_unknown_space, int trinary, int lethal_threshold, int unknown_cost_value, hipStream_t s);
+void launch_fill_u8(uint8_t* dst, uint8_t v, size_t n, hipStream_t s);
+void launch_fill_u32(uint32_t* dst, uint32_t v, size_t n, hipStream_t s);
+
+void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
+void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
+void launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s);
+void launch_select(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
+size_t bfs_lds_bytes(uint32_t nx, uint32_t ny);
+
+// ---- device helpers ---------------------------------------------------------------------------
+struct Geom {
+  double ox, oy, res;
+  uint32_t nx, ny;
+};
+
+// Costmap2D::worldToMap (costmap_2d.cpp:208-220).  The explicit NaN / range guards reproduce what
+// the x86 `(int)double` conversion yields for out-of-range values (0x80000000 -> "not in map").
+__device__ __forceinline__ bool worldToMap(const Geom& g, double wx, double wy, uint32_t& mx, uint32_t& my) {
+  if (wx < g.ox || wy < g.oy) return false;
+  double fx = (wx - g.ox) / g.res;
+  double fy = (wy - g.oy) / g.res;
+  if (!(fx < 2147483648.0) || !(fy < 2147483648.0)) return false;
+  mx = (uint32_t)(int)fx;
+  my = (uint32_t)(int)fy;
+  return mx < g.nx && my < g.ny;
+}
+
+// |(x, y)| for generic doubles: sqrt of the correctly summed squares (within 1 ulp of libm hypot)
+__device__ __forceinline__ double hyp2(double x, double y) {
+  double a = x * x, b = y * y;
+  double s = a + b;
+  double h = sqrt(s);
+  if (h == 0.0) return 0.0;
+  double bb = s - a;
+  double e = (a - (s - bb)) + (b - bb);
+  double r = __builtin_fma(-h, h, s);
+  return h + (r + e) / (2.0 * h);
+}
+
+}  // namespace navgpu

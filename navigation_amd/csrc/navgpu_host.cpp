@@ -1,0 +1,846 @@
+// C-ABI host side of libnavgpu.so (include/navgpu.h).  Owns device memory, the fleet's HIP
+// stream and the launch sequence; the only arithmetic done here is the per-cycle, per-instance
+// scalar bookkeeping the reference also does once per cycle on the host (footprint transform,
+// nose goal, inflation cost table) — in fp64 with libm, like the reference.
+// There is no CPU fallback: every data-parallel step is a HIP kernel.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "navgpu_device.h"
+
+using namespace navgpu;
+
+namespace {
+thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) {                                                                        \
+      g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                            \
+      return NAVGPU_ERR_HIP;                                                                       \
+    }                                                                                              \
+  } while (0)
+
+struct EventPair {
+  int kernel;
+  hipEvent_t a, b;
+};
+}  // namespace
+
+struct navgpu_fleet {
+  navgpu_fleet_desc desc{};
+  hipStream_t stream = nullptr;
+  CostmapDev cm{};
+  PlannerDev pl{};
+  bool planner_configured = false, inflation_configured = false, planner_staged = false;
+  std::vector<void*> allocs;
+  // host mirrors
+  std::vector<double> h_origin;                 // [n][2]
+  std::vector<double> h_fp_spec;                // [n][kMaxFootprint][2]
+  std::vector<uint32_t> h_fp_n;                 // [n]
+  navgpu_inflation_params infl{};
+  navgpu_obstacle_params obsp{};
+  double fp_radius = 0.0;                       // largest vertex distance over all instances
+  // scratch device buffers
+  double* d_bounds_tmp = nullptr;               // [n][4]
+  int32_t* d_boxes_tmp = nullptr;               // [n][4]
+  float* d_explicit = nullptr;                  // [3]
+  int8_t* d_occ = nullptr;
+  // profiling
+  bool profiling = false;
+  std::vector<EventPair> events;
+  std::vector<EventPair> free_events;
+  double prof_ms[NAVGPU_K_COUNT] = {0};
+  uint64_t prof_n[NAVGPU_K_COUNT] = {0};
+
+  template <class T>
+  int alloc(T** p, size_t count) {
+    void* q = nullptr;
+    size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {
+      g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+      return NAVGPU_ERR_HIP;
+    }
+    e = hipMemsetAsync(q, 0, bytes, stream);
+    if (e != hipSuccess) {
+      g_last_error = std::string("hipMemsetAsync: ") + hipGetErrorString(e);
+      return NAVGPU_ERR_HIP;
+    }
+    allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return NAVGPU_OK;
+  }
+  void release(void* q) {
+    if (!q) return;
+    auto it = std::find(allocs.begin(), allocs.end(), q);
+    if (it != allocs.end()) allocs.erase(it);
+    hipFree(q);
+  }
+  bool rangeOk(uint32_t first, uint32_t count) const { return count > 0 && first < desc.n_instances && count <= desc.n_instances - first; }
+
+  int beginKernel(int k, EventPair* ep) {
+    if (!profiling) return NAVGPU_OK;
+    if (free_events.empty()) {
+      EventPair n{};
+      HIP_TRY(hipEventCreate(&n.a));
+      HIP_TRY(hipEventCreate(&n.b));
+      free_events.push_back(n);
+    }
+    *ep = free_events.back();
+    free_events.pop_back();
+    ep->kernel = k;
+    HIP_TRY(hipEventRecord(ep->a, stream));
+    return NAVGPU_OK;
+  }
+  int endKernel(EventPair* ep) {
+    if (!profiling) return NAVGPU_OK;
+    HIP_TRY(hipEventRecord(ep->b, stream));
+    events.push_back(*ep);
+    if (events.size() > 8192) return foldEvents();
+    return NAVGPU_OK;
+  }
+  int foldEvents() {
+    if (events.empty()) return NAVGPU_OK;
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (auto& e : events) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+      prof_ms[e.kernel] += ms;
+      prof_n[e.kernel] += 1;
+      free_events.push_back(e);
+    }
+    events.clear();
+    return NAVGPU_OK;
+  }
+};
+
+#define PROFILED(fleet, kid, launch_expr)            \
+  do {                                               \
+    EventPair ep_{};                                 \
+    int rc_ = (fleet)->beginKernel((kid), &ep_);     \
+    if (rc_) return rc_;                             \
+    launch_expr;                                     \
+    rc_ = (fleet)->endKernel(&ep_);                  \
+    if (rc_) return rc_;                             \
+  } while (0)
+
+static int checkLaunch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_last_error = std::string("kernel launch: ") + hipGetErrorString(e);
+    return NAVGPU_ERR_HIP;
+  }
+  return NAVGPU_OK;
+}
+
+extern "C" {
+
+const char* navgpu_version(void) { return "navgpu 0.1 (gfx950)"; }
+const char* navgpu_strerror(int status) {
+  switch (status) {
+    case NAVGPU_OK: return "ok";
+    case NAVGPU_ERR_INVALID: return "invalid argument";
+    case NAVGPU_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case NAVGPU_ERR_HIP: return "HIP runtime error";
+    case NAVGPU_ERR_CAPACITY: return "input exceeds a capacity given at fleet creation";
+    case NAVGPU_ERR_STATE: return "call sequence violated";
+    default: return "unknown status";
+  }
+}
+const char* navgpu_last_error(void) { return g_last_error.c_str(); }
+int navgpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+const char* navgpu_kernel_name(int32_t k) {
+  static const char* names[NAVGPU_K_COUNT] = {"k_obstacle", "k_merge", "k_inflate", "k_bfs", "k_score", "k_select"};
+  return (k >= 0 && k < NAVGPU_K_COUNT) ? names[k] : "?";
+}
+
+int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
+  if (!d || !out || d->n_instances == 0 || d->size_x == 0 || d->size_y == 0 || !(d->resolution > 0)) return NAVGPU_ERR_INVALID;
+  if (d->max_footprint > (uint32_t)kMaxFootprint) return NAVGPU_ERR_CAPACITY;
+  if ((uint64_t)d->size_x * d->size_y > (1ull << 30)) return NAVGPU_ERR_CAPACITY;
+  const uint32_t words = d->size_y * ((d->size_x + 31) / 32);
+  if (words > 20u * 1024u || bfs_lds_bytes(d->size_x, d->size_y) > 160u * 1024u - 4096u) {
+    g_last_error = "grid too large for the LDS-resident wavefront kernel";
+    return NAVGPU_ERR_CAPACITY;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || d->device < 0 || d->device >= ndev) {
+    g_last_error = "no HIP device";
+    return NAVGPU_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(d->device));
+  auto* f = new navgpu_fleet();
+  f->desc = *d;
+  if (f->desc.max_observations == 0) f->desc.max_observations = 1;
+  if (f->desc.max_points == 0) f->desc.max_points = 1;
+  if (f->desc.max_plan == 0) f->desc.max_plan = 1;
+  if (f->desc.max_sim_steps == 0) f->desc.max_sim_steps = 64;
+  const uint32_t n = d->n_instances;
+  if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) {
+    g_last_error = "hipStreamCreate failed";
+    delete f;
+    return NAVGPU_ERR_NO_DEVICE;
+  }
+  CostmapDev& cm = f->cm;
+  cm.nx = d->size_x;
+  cm.ny = d->size_y;
+  cm.cells = d->size_x * d->size_y;
+  cm.cells_padded = (cm.cells + 63) & ~63u;
+  cm.res = d->resolution;
+  cm.layers = d->layers;
+  cm.track_unknown = d->track_unknown;
+  cm.master_default = d->track_unknown ? kNoInfo : kFree;    // layered_costmap.cpp:53-57
+  cm.obstacle_default = d->track_unknown ? kNoInfo : kFree;  // obstacle_layer.cpp:60-64
+  cm.obs_enabled = 1;
+  cm.footprint_clearing = 1;
+  cm.combination_method = 1;
+  cm.max_obstacle_height = 2.0;
+  cm.z_voxels = 10;
+  cm.unknown_threshold = 15;
+  cm.mark_threshold = 0;
+  cm.origin_z = 0.0;
+  cm.z_resolution = 0.2;
+  cm.max_obs = f->desc.max_observations;
+  cm.max_points = f->desc.max_points;
+  int rc = 0;
+#define A(ptr, cnt)                        \
+  if ((rc = f->alloc(&(ptr), (cnt))) != 0) { \
+    navgpu_fleet_destroy(f);               \
+    return rc;                             \
+  }
+  A(cm.origin, (size_t)n * 2);
+  A(cm.master, (size_t)n * cm.cells_padded);
+  if (d->layers & NAVGPU_LAYER_STATIC) A(cm.stat, (size_t)n * cm.cells_padded);
+  if (d->layers & (NAVGPU_LAYER_OBSTACLE | NAVGPU_LAYER_VOXEL)) A(cm.obst, (size_t)n * cm.cells_padded);
+  if (d->layers & NAVGPU_LAYER_VOXEL) A(cm.voxel, (size_t)n * cm.cells_padded);
+  A(cm.lut, 66 * 66);
+  A(cm.state, n);
+  A(cm.pose, (size_t)n * 3);
+  A(cm.fp_world, (size_t)n * kMaxFootprint * 2);
+  A(cm.fp_n, n);
+  A(cm.obs, (size_t)n * cm.max_obs);
+  A(cm.obs_count, n);
+  A(cm.points, (size_t)n * cm.max_points * 3);
+  A(f->d_bounds_tmp, (size_t)n * 4);
+  A(f->d_boxes_tmp, (size_t)n * 4);
+  A(f->d_explicit, 4);
+  PlannerDev& pl = f->pl;
+  pl.nx = cm.nx;
+  pl.ny = cm.ny;
+  pl.cells = cm.cells;
+  pl.cells_padded = cm.cells_padded;
+  pl.res = cm.res;
+  pl.origin = cm.origin;
+  pl.master = cm.master;
+  pl.max_plan = f->desc.max_plan;
+  pl.max_sim_steps = f->desc.max_sim_steps;
+  A(pl.state, n);
+  A(pl.plan, (size_t)n * pl.max_plan * 2);
+  A(pl.plan_count, n);
+  A(pl.front_last, (size_t)n * 2);
+  A(pl.align_on, n);
+  A(pl.fp_spec, (size_t)n * kMaxFootprint * 2);
+  A(pl.fp_n, n);
+  A(pl.axis_count, (size_t)n * 4);
+  A(pl.path, (size_t)n * pl.cells);
+  A(pl.goal, (size_t)n * pl.cells);
+  A(pl.goal_front, (size_t)n * pl.cells);
+  A(pl.counters, (size_t)n * 2);
+  A(pl.osc_flags, n);
+  A(pl.osc_prev, (size_t)n * 3);
+  A(pl.result, n);
+  A(pl.traj, (size_t)n * pl.max_sim_steps * 3);
+#undef A
+  f->h_origin.assign((size_t)n * 2, 0.0);
+  f->h_fp_spec.assign((size_t)n * kMaxFootprint * 2, 0.0);
+  f->h_fp_n.assign(n, 0);
+  // grids start at their default values (Costmap2D ctor -> resetMaps)
+  launch_fill_u8(cm.master, cm.master_default, (size_t)n * cm.cells_padded, f->stream);
+  if (cm.obst) launch_fill_u8(cm.obst, cm.obstacle_default, (size_t)n * cm.cells_padded, f->stream);
+  if (cm.voxel) launch_fill_u32(cm.voxel, 0x0000FFFFu, (size_t)n * cm.cells_padded, f->stream);  // voxel_grid.cpp:54
+  // InflationLayer ctor: last_* = -/+FLT_MAX (inflation_layer.cpp:63-66)
+  std::vector<InstCostmapState> st(n);
+  for (auto& s : st) {
+    memset(&s, 0, sizeof(s));
+    s.last_min_x = -FLT_MAX;
+    s.last_min_y = -FLT_MAX;
+    s.last_max_x = FLT_MAX;
+    s.last_max_y = FLT_MAX;
+  }
+  hipError_t e = hipMemcpyAsync(cm.state, st.data(), sizeof(InstCostmapState) * n, hipMemcpyHostToDevice, f->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(f->stream);
+  if (e != hipSuccess || checkLaunch() != NAVGPU_OK) {
+    if (e != hipSuccess) g_last_error = std::string("fleet init: ") + hipGetErrorString(e);
+    navgpu_fleet_destroy(f);
+    return NAVGPU_ERR_NO_DEVICE;  // kernels not loadable on this device (not gfx950) or device lost
+  }
+  *out = f;
+  return NAVGPU_OK;
+}
+
+int navgpu_fleet_destroy(navgpu_fleet* f) {
+  if (!f) return NAVGPU_ERR_INVALID;
+  if (f->stream) hipStreamSynchronize(f->stream);
+  for (auto& e : f->events) {
+    hipEventDestroy(e.a);
+    hipEventDestroy(e.b);
+  }
+  for (auto& e : f->free_events) {
+    hipEventDestroy(e.a);
+    hipEventDestroy(e.b);
+  }
+  for (void* p : f->allocs) hipFree(p);
+  if (f->stream) hipStreamDestroy(f->stream);
+  delete f;
+  return NAVGPU_OK;
+}
+int navgpu_sync(navgpu_fleet* f) {
+  if (!f) return NAVGPU_ERR_INVALID;
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  return NAVGPU_OK;
+}
+void* navgpu_stream(navgpu_fleet* f) { return f ? (void*)f->stream : nullptr; }
+
+int navgpu_fleet_set_origin(navgpu_fleet* f, uint32_t first, uint32_t count, const double* xy) {
+  if (!f || !xy || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  memcpy(&f->h_origin[(size_t)first * 2], xy, sizeof(double) * 2 * count);
+  HIP_TRY(hipMemcpyAsync(f->cm.origin + (size_t)first * 2, xy, sizeof(double) * 2 * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  return NAVGPU_OK;
+}
+
+static int gridInfo(navgpu_fleet* f, int grid, void** base, size_t* elem, size_t* stride_elems, size_t* used_elems) {
+  CostmapDev& cm = f->cm;
+  PlannerDev& pl = f->pl;
+  switch (grid) {
+    case NAVGPU_GRID_MASTER: *base = cm.master; *elem = 1; *stride_elems = cm.cells_padded; break;
+    case NAVGPU_GRID_STATIC: *base = cm.stat; *elem = 1; *stride_elems = cm.cells_padded; break;
+    case NAVGPU_GRID_OBSTACLE: *base = cm.obst; *elem = 1; *stride_elems = cm.cells_padded; break;
+    case NAVGPU_GRID_VOXEL: *base = cm.voxel; *elem = 4; *stride_elems = cm.cells_padded; break;
+    case NAVGPU_GRID_PATH: *base = pl.path; *elem = 4; *stride_elems = pl.cells; break;
+    case NAVGPU_GRID_GOAL: *base = pl.goal; *elem = 4; *stride_elems = pl.cells; break;
+    case NAVGPU_GRID_GOAL_FRONT: *base = pl.goal_front; *elem = 4; *stride_elems = pl.cells; break;
+    default: return NAVGPU_ERR_INVALID;
+  }
+  *used_elems = cm.cells;
+  if (!*base) return NAVGPU_ERR_STATE;  // layer not part of this fleet
+  return NAVGPU_OK;
+}
+int navgpu_grid_upload(navgpu_fleet* f, int grid, uint32_t first, uint32_t count, const void* host) {
+  if (!f || !host || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  void* base;
+  size_t elem, stride, used;
+  int rc = gridInfo(f, grid, &base, &elem, &stride, &used);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy2DAsync((char*)base + (size_t)first * stride * elem, stride * elem, host, used * elem, used * elem, count,
+                           hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  return NAVGPU_OK;
+}
+int navgpu_grid_download(navgpu_fleet* f, int grid, uint32_t first, uint32_t count, void* host) {
+  if (!f || !host || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  void* base;
+  size_t elem, stride, used;
+  int rc = gridInfo(f, grid, &base, &elem, &stride, &used);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy2DAsync(host, used * elem, (char*)base + (size_t)first * stride * elem, stride * elem, used * elem, count,
+                           hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  return NAVGPU_OK;
+}
+int navgpu_grid_device(navgpu_fleet* f, int grid, void** ptr, size_t* stride_bytes) {
+  if (!f || !ptr) return NAVGPU_ERR_INVALID;
+  void* base;
+  size_t elem, stride, used;
+  int rc = gridInfo(f, grid, &base, &elem, &stride, &used);
+  if (rc) return rc;
+  *ptr = base;
+  if (stride_bytes) *stride_bytes = stride * elem;
+  return NAVGPU_OK;
+}
+int navgpu_grid_reset(navgpu_fleet* f, int grid, uint32_t first, uint32_t count) {
+  if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  CostmapDev& cm = f->cm;
+  switch (grid) {
+    case NAVGPU_GRID_MASTER: launch_fill_u8(cm.master + (size_t)first * cm.cells_padded, cm.master_default, (size_t)count * cm.cells_padded, f->stream); break;
+    case NAVGPU_GRID_OBSTACLE:
+      if (!cm.obst) return NAVGPU_ERR_STATE;
+      launch_fill_u8(cm.obst + (size_t)first * cm.cells_padded, cm.obstacle_default, (size_t)count * cm.cells_padded, f->stream);
+      if (cm.voxel) launch_fill_u32(cm.voxel + (size_t)first * cm.cells_padded, 0x0000FFFFu, (size_t)count * cm.cells_padded, f->stream);  // VoxelLayer::resetMaps
+      break;
+    case NAVGPU_GRID_VOXEL:
+      if (!cm.voxel) return NAVGPU_ERR_STATE;
+      launch_fill_u32(cm.voxel + (size_t)first * cm.cells_padded, 0x0000FFFFu, (size_t)count * cm.cells_padded, f->stream);
+      break;
+    default: return NAVGPU_ERR_INVALID;
+  }
+  return checkLaunch();
+}
+
+// ------------------------------------------------------------------------------------------------ layers
+int navgpu_static_set_map(navgpu_fleet* f, uint32_t first, uint32_t count, const int8_t* occ, int32_t track_unknown_space,
+                          int32_t use_maximum, int32_t trinary, int32_t lethal_cost_threshold, int32_t unknown_cost_value) {
+  if (!f || !occ || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  CostmapDev& cm = f->cm;
+  if (!cm.stat) return NAVGPU_ERR_STATE;
+  if (!f->d_occ) {
+    int rc = f->alloc(&f->d_occ, cm.cells);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(f->d_occ, occ, cm.cells, hipMemcpyHostToDevice, f->stream));
+  int lethal = std::max(std::min(lethal_cost_threshold, 100), 0);  // static_layer.cpp:80
+  launch_static_interpret(cm.stat + (size_t)first * cm.cells_padded, f->d_occ, cm.cells, cm.cells_padded, count, track_unknown_space,
+                          trinary, lethal, unknown_cost_value, f->stream);
+  cm.static_use_maximum = use_maximum;
+  cm.static_received = 1;
+  // has_updated_data_ = true for these instances
+  std::vector<InstCostmapState> st(count);
+  HIP_TRY(hipMemcpyAsync(st.data(), cm.state + first, sizeof(InstCostmapState) * count, hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  for (auto& s : st) s.static_has_updated_data = 1;
+  HIP_TRY(hipMemcpyAsync(cm.state + first, st.data(), sizeof(InstCostmapState) * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  return checkLaunch();
+}
+
+int navgpu_obstacle_configure(navgpu_fleet* f, const navgpu_obstacle_params* p) {
+  if (!f || !p) return NAVGPU_ERR_INVALID;
+  if (p->z_voxels < 0 || p->z_voxels > 16) return NAVGPU_ERR_INVALID;
+  CostmapDev& cm = f->cm;
+  f->obsp = *p;
+  cm.obs_enabled = p->enabled;
+  cm.footprint_clearing = p->footprint_clearing_enabled;
+  cm.combination_method = p->combination_method;
+  cm.max_obstacle_height = p->max_obstacle_height;
+  if (cm.layers & NAVGPU_LAYER_VOXEL) {
+    cm.z_voxels = p->z_voxels;
+    cm.origin_z = p->origin_z;
+    cm.z_resolution = p->z_resolution;
+    cm.unknown_threshold = p->unknown_threshold;
+    cm.mark_threshold = p->mark_threshold;
+  }
+  return NAVGPU_OK;
+}
+
+int navgpu_inflation_configure(navgpu_fleet* f, const navgpu_inflation_params* p) {
+  if (!f || !p) return NAVGPU_ERR_INVALID;
+  CostmapDev& cm = f->cm;
+  // cellDistance (costmap_2d.cpp:181-185)
+  double cells_dist = std::max(0.0, ceil(p->inflation_radius / cm.res));
+  if (cells_dist > 64) return NAVGPU_ERR_CAPACITY;
+  const uint32_t R = (uint32_t)cells_dist;
+  const uint32_t n = R + 2;
+  // computeCaches (inflation_layer.cpp:295-328) + computeCost (inflation_layer.h:114-129), fp64 libm on the host
+  std::vector<uint8_t> lut((size_t)n * n);
+  for (uint32_t i = 0; i < n; ++i)
+    for (uint32_t j = 0; j < n; ++j) {
+      double distance = hypot(i, j);
+      uint8_t cost = 0;
+      if (distance == 0)
+        cost = kLethal;
+      else if (distance * cm.res <= p->inscribed_radius)
+        cost = kInscribed;
+      else {
+        double euclidean_distance = distance * cm.res;
+        double factor = exp(-1.0 * p->cost_scaling_factor * (euclidean_distance - p->inscribed_radius));
+        cost = (uint8_t)((kInscribed - 1) * factor);
+      }
+      // enqueue() drops cells whose cached distance exceeds the cell radius (inflation_layer.cpp:286)
+      if (distance > R) cost = 0;
+      lut[(size_t)i * n + j] = cost;
+    }
+  // the exact-EDT kernel takes the max over candidate seeds; that equals "cost of the nearest
+  // seed" only if the table is monotone in distance — true for cost_scaling_factor >= 0.
+  if (p->cost_scaling_factor < 0) {
+    g_last_error = "cost_scaling_factor < 0 is not supported";
+    return NAVGPU_ERR_INVALID;
+  }
+  HIP_TRY(hipMemcpyAsync(cm.lut, lut.data(), lut.size(), hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  const bool changed = !f->inflation_configured || f->infl.inflation_radius != p->inflation_radius ||
+                       f->infl.cost_scaling_factor != p->cost_scaling_factor || f->infl.inscribed_radius != p->inscribed_radius ||
+                       f->infl.enabled != p->enabled;
+  f->infl = *p;
+  f->inflation_configured = true;
+  cm.R = R;
+  cm.inflation_radius = p->inflation_radius;
+  cm.infl_enabled = p->enabled;
+  if (changed) {  // need_reinflation_ = true (setInflationParameters / onFootprintChanged / reconfigureCB)
+    const uint32_t nI = f->desc.n_instances;
+    std::vector<InstCostmapState> st(nI);
+    HIP_TRY(hipMemcpyAsync(st.data(), cm.state, sizeof(InstCostmapState) * nI, hipMemcpyDeviceToHost, f->stream));
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    for (auto& s : st) s.need_reinflation = 1;
+    HIP_TRY(hipMemcpyAsync(cm.state, st.data(), sizeof(InstCostmapState) * nI, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipStreamSynchronize(f->stream));
+  }
+  return NAVGPU_OK;
+}
+
+static void updateWindow(navgpu_fleet* f) {
+  // costmap window staged in LDS by k_score: everything a trajectory's footprint or shifted
+  // point can touch.  Results never depend on it (cells outside fall back to global loads).
+  const navgpu_dwa_config& c = f->pl.cfg;
+  double vmax;
+  if (c.max_trans_vel >= 0)
+    vmax = c.max_trans_vel + 1e-4;
+  else
+    vmax = hypot(std::max(fabs(c.min_vel_x), fabs(c.max_vel_x)), std::max(fabs(c.min_vel_y), fabs(c.max_vel_y)));
+  double reach = vmax * c.sim_time + std::max(f->fp_radius, fabs(c.forward_point_distance));
+  double cells = ceil(reach / f->pl.res) + 2;
+  uint32_t win = (uint32_t)std::min(cells * 2 + 1, 240.0);
+  f->pl.win = win;
+}
+
+int navgpu_set_footprint(navgpu_fleet* f, uint32_t first, uint32_t count, const double* xy, uint32_t nv) {
+  if (!f || !f->rangeOk(first, count) || (nv && !xy)) return NAVGPU_ERR_INVALID;
+  if (nv > f->desc.max_footprint || nv > (uint32_t)kMaxFootprint) return NAVGPU_ERR_CAPACITY;
+  for (uint32_t i = first; i < first + count; ++i) {
+    f->h_fp_n[i] = nv;
+    for (uint32_t k = 0; k < nv * 2; ++k) f->h_fp_spec[(size_t)i * kMaxFootprint * 2 + k] = xy[k];
+  }
+  for (uint32_t k = 0; k < nv; ++k) f->fp_radius = std::max(f->fp_radius, hypot(xy[2 * k], xy[2 * k + 1]));
+  if (f->fp_radius / f->cm.res > 500) return NAVGPU_ERR_CAPACITY;  // polygon column span must fit the 1024-column LDS table
+  HIP_TRY(hipMemcpyAsync(f->pl.fp_spec + (size_t)first * kMaxFootprint * 2, &f->h_fp_spec[(size_t)first * kMaxFootprint * 2],
+                         sizeof(double) * kMaxFootprint * 2 * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(f->pl.fp_n + first, &f->h_fp_n[first], sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  if (f->planner_configured) updateWindow(f);
+  return NAVGPU_OK;
+}
+
+int navgpu_costmap_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const double* poses, const navgpu_observation* obs,
+                         uint32_t n_obs, const float* points, uint32_t n_points_total) {
+  if (!f || !poses || !f->rangeOk(first, count) || (n_obs && (!obs || (!points && n_points_total)))) return NAVGPU_ERR_INVALID;
+  CostmapDev& cm = f->cm;
+  std::vector<ObsCsr> h_obs((size_t)count * cm.max_obs);
+  std::vector<uint32_t> h_cnt(count, 0), h_pts_used(count, 0);
+  std::vector<float> h_pts((size_t)count * cm.max_points * 3, 0.f);
+  for (uint32_t k = 0; k < n_obs; ++k) {
+    const navgpu_observation& o = obs[k];
+    if (o.instance < first || o.instance >= first + count) return NAVGPU_ERR_INVALID;
+    const uint32_t li = o.instance - first;
+    if (h_cnt[li] >= cm.max_obs || h_pts_used[li] + o.n_points > cm.max_points) return NAVGPU_ERR_CAPACITY;
+    if ((uint64_t)o.first_point + o.n_points > n_points_total) return NAVGPU_ERR_INVALID;
+    ObsCsr& d = h_obs[(size_t)li * cm.max_obs + h_cnt[li]++];
+    d.first_point = h_pts_used[li];
+    d.n_points = o.n_points;
+    d.flags = o.flags;
+    d.pad = 0;
+    d.ox = o.origin_x;
+    d.oy = o.origin_y;
+    d.oz = o.origin_z;
+    d.obstacle_range = o.obstacle_range;
+    d.raytrace_range = o.raytrace_range;
+    if (o.n_points)
+      memcpy(&h_pts[((size_t)li * cm.max_points + h_pts_used[li]) * 3], points + (size_t)o.first_point * 3, sizeof(float) * 3 * o.n_points);
+    h_pts_used[li] += o.n_points;
+  }
+  // transformFootprint (footprint.cpp:103-118) per instance, fp64 libm
+  std::vector<double> h_fpw((size_t)count * kMaxFootprint * 2, 0.0);
+  for (uint32_t li = 0; li < count; ++li) {
+    const uint32_t i = first + li;
+    const double x = poses[3 * li], y = poses[3 * li + 1], th = poses[3 * li + 2];
+    const double cos_th = cos(th), sin_th = sin(th);
+    for (uint32_t v = 0; v < f->h_fp_n[i]; ++v) {
+      const double sx = f->h_fp_spec[((size_t)i * kMaxFootprint + v) * 2], sy = f->h_fp_spec[((size_t)i * kMaxFootprint + v) * 2 + 1];
+      h_fpw[((size_t)li * kMaxFootprint + v) * 2] = x + (sx * cos_th - sy * sin_th);
+      h_fpw[((size_t)li * kMaxFootprint + v) * 2 + 1] = y + (sx * sin_th + sy * cos_th);
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(cm.pose + (size_t)first * 3, poses, sizeof(double) * 3 * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(cm.obs + (size_t)first * cm.max_obs, h_obs.data(), sizeof(ObsCsr) * h_obs.size(), hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(cm.obs_count + first, h_cnt.data(), sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(cm.points + (size_t)first * cm.max_points * 3, h_pts.data(), sizeof(float) * h_pts.size(), hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(cm.fp_world + (size_t)first * kMaxFootprint * 2, h_fpw.data(), sizeof(double) * h_fpw.size(), hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(cm.fp_n + first, &f->h_fp_n[first], sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));  // host vectors go out of scope
+  return NAVGPU_OK;
+}
+
+int navgpu_costmap_update(navgpu_fleet* f, uint32_t first, uint32_t count) {
+  if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  CostmapDev& cm = f->cm;
+  if ((cm.layers & NAVGPU_LAYER_INFLATION) && !f->inflation_configured) return NAVGPU_ERR_STATE;
+  PROFILED(f, NAVGPU_K_OBSTACLE, launch_obstacle(cm, first, count, nullptr, 0, f->stream));
+  PROFILED(f, NAVGPU_K_MERGE, launch_merge(cm, first, count, nullptr, f->stream));
+  if (cm.layers & NAVGPU_LAYER_INFLATION) PROFILED(f, NAVGPU_K_INFLATE, launch_inflate(cm, first, count, nullptr, f->stream));
+  return checkLaunch();
+}
+
+int navgpu_costmap_bounds(navgpu_fleet* f, uint32_t first, uint32_t count, int32_t* boxes) {
+  if (!f || !boxes || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  std::vector<InstCostmapState> st(count);
+  HIP_TRY(hipMemcpyAsync(st.data(), f->cm.state + first, sizeof(InstCostmapState) * count, hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  for (uint32_t i = 0; i < count; ++i)
+    for (int k = 0; k < 4; ++k) boxes[4 * i + k] = st[i].box[k];
+  return NAVGPU_OK;
+}
+
+int navgpu_inflate(navgpu_fleet* f, uint32_t first, uint32_t count, const int32_t* boxes) {
+  if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  if (!f->inflation_configured) return NAVGPU_ERR_STATE;
+  const int32_t* d_boxes = nullptr;
+  if (boxes) {
+    HIP_TRY(hipMemcpyAsync(f->d_boxes_tmp, boxes, sizeof(int32_t) * 4 * count, hipMemcpyHostToDevice, f->stream));
+    d_boxes = f->d_boxes_tmp;
+  }
+  PROFILED(f, NAVGPU_K_INFLATE, launch_inflate(f->cm, first, count, d_boxes, f->stream));
+  if (boxes) HIP_TRY(hipStreamSynchronize(f->stream));  // d_boxes_tmp is reused by the next call
+  return checkLaunch();
+}
+
+int navgpu_obstacle_update_bounds(navgpu_fleet* f, uint32_t first, uint32_t count, double* bounds) {
+  if (!f || !bounds || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  if (!f->cm.obst) return NAVGPU_ERR_STATE;
+  HIP_TRY(hipMemcpyAsync(f->d_bounds_tmp, bounds, sizeof(double) * 4 * count, hipMemcpyHostToDevice, f->stream));
+  PROFILED(f, NAVGPU_K_OBSTACLE, launch_obstacle(f->cm, first, count, f->d_bounds_tmp, 1, f->stream));
+  HIP_TRY(hipMemcpyAsync(bounds, f->d_bounds_tmp, sizeof(double) * 4 * count, hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  return checkLaunch();
+}
+
+int navgpu_obstacle_update_costs(navgpu_fleet* f, uint32_t first, uint32_t count, const int32_t* boxes) {
+  if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  const int32_t* d_boxes = nullptr;
+  if (boxes) {
+    HIP_TRY(hipMemcpyAsync(f->d_boxes_tmp, boxes, sizeof(int32_t) * 4 * count, hipMemcpyHostToDevice, f->stream));
+    d_boxes = f->d_boxes_tmp;
+  }
+  PROFILED(f, NAVGPU_K_MERGE, launch_merge(f->cm, first, count, d_boxes, f->stream));
+  if (boxes) HIP_TRY(hipStreamSynchronize(f->stream));
+  return checkLaunch();
+}
+
+// ------------------------------------------------------------------------------------------------ planner
+int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
+  if (!f || !c) return NAVGPU_ERR_INVALID;
+  if (!(c->sim_time > 0) || !(c->sim_granularity > 0) || !(c->angular_sim_granularity > 0)) return NAVGPU_ERR_INVALID;
+  PlannerDev& pl = f->pl;
+  navgpu_dwa_config cfg = *c;
+  if (cfg.vx_samples <= 0) cfg.vx_samples = 1;  // dwa_planner.cpp:89-105
+  if (cfg.vy_samples <= 0) cfg.vy_samples = 1;
+  if (cfg.vth_samples <= 0) cfg.vth_samples = 1;
+  const uint32_t max_axis = (uint32_t)std::max(std::max(cfg.vx_samples, cfg.vy_samples), std::max(cfg.vth_samples, 2)) + 1;
+  if (max_axis > 128) return NAVGPU_ERR_CAPACITY;
+  // step-count capacity (simple_trajectory_generator.cpp:202-212)
+  double steps;
+  if (cfg.discretize_by_time)
+    steps = ceil(cfg.sim_time / cfg.sim_granularity);
+  else {
+    double vmax = cfg.max_trans_vel >= 0 ? cfg.max_trans_vel + 1e-4
+                                         : hypot(std::max(fabs(cfg.min_vel_x), fabs(cfg.max_vel_x)), std::max(fabs(cfg.min_vel_y), fabs(cfg.max_vel_y)));
+    steps = ceil(std::max(vmax * cfg.sim_time / cfg.sim_granularity, fabs(cfg.max_rot_vel) * cfg.sim_time / cfg.angular_sim_granularity)) + 1;
+  }
+  if (steps > pl.max_sim_steps) {
+    g_last_error = "max_sim_steps too small for this sim_time / granularity";
+    return NAVGPU_ERR_CAPACITY;
+  }
+  const uint32_t nI = f->desc.n_instances;
+  const uint32_t ax = (uint32_t)(std::max(cfg.vx_samples, 2) + 1), ay = (uint32_t)(std::max(cfg.vy_samples, 2) + 1),
+                 at = (uint32_t)(std::max(cfg.vth_samples, 2) + 1);
+  const uint32_t max_samples = ax * ay * at;
+  const uint32_t score_blocks = (max_samples + 255) / 256;
+  if (max_axis != pl.max_axis || max_samples != pl.max_samples) {
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    f->release(pl.axis_samples);
+    f->release(pl.part_cost);
+    f->release(pl.part_index);
+    f->release(pl.sample_cost);
+    f->release(pl.sample_status);
+    pl.axis_samples = nullptr;
+    pl.part_cost = nullptr;
+    pl.part_index = nullptr;
+    pl.sample_cost = nullptr;
+    pl.sample_status = nullptr;
+    int rc;
+    if ((rc = f->alloc(&pl.axis_samples, (size_t)nI * 3 * max_axis))) return rc;
+    if ((rc = f->alloc(&pl.part_cost, (size_t)nI * score_blocks))) return rc;
+    if ((rc = f->alloc(&pl.part_index, (size_t)nI * score_blocks))) return rc;
+    if (f->desc.keep_sample_costs) {
+      if ((rc = f->alloc(&pl.sample_cost, (size_t)nI * max_samples))) return rc;
+      if ((rc = f->alloc(&pl.sample_status, (size_t)nI * max_samples))) return rc;
+    }
+    pl.max_axis = max_axis;
+    pl.max_samples = max_samples;
+    pl.score_blocks = score_blocks;
+  }
+  pl.cfg = cfg;
+  // DWAPlanner::reconfigure scales (dwa_planner.cpp:64-75)
+  pl.scale_path = pl.res * cfg.path_distance_bias * 0.5;
+  pl.scale_goal = pl.res * cfg.goal_distance_bias * 0.5;
+  pl.scale_obstacle = pl.res * cfg.occdist_scale;
+  f->planner_configured = true;
+  updateWindow(f);
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  return NAVGPU_OK;
+}
+
+int navgpu_planner_set_plan(navgpu_fleet* f, uint32_t first, uint32_t count) {
+  if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  HIP_TRY(hipMemsetAsync(f->pl.osc_flags + first, 0, sizeof(uint32_t) * count, f->stream));  // resetOscillationFlags
+  return NAVGPU_OK;
+}
+
+int navgpu_planner_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const navgpu_robot_state* states, const double* plan_xy,
+                         uint32_t n_plan_total) {
+  if (!f || !states || !plan_xy || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  if (!f->planner_configured) return NAVGPU_ERR_STATE;
+  PlannerDev& pl = f->pl;
+  const navgpu_dwa_config& c = pl.cfg;
+  std::vector<double> h_plan((size_t)count * pl.max_plan * 2, 0.0), h_front((size_t)count * 2);
+  std::vector<uint32_t> h_cnt(count);
+  std::vector<int32_t> h_align(count);
+  for (uint32_t li = 0; li < count; ++li) {
+    const navgpu_robot_state& s = states[li];
+    if (s.plan_count == 0) return NAVGPU_ERR_INVALID;  // the ROS wrapper rejects empty plans before this point
+    if (s.plan_count > pl.max_plan) return NAVGPU_ERR_CAPACITY;
+    if ((uint64_t)s.plan_first + s.plan_count > n_plan_total) return NAVGPU_ERR_INVALID;
+    memcpy(&h_plan[(size_t)li * pl.max_plan * 2], plan_xy + (size_t)s.plan_first * 2, sizeof(double) * 2 * s.plan_count);
+    h_cnt[li] = s.plan_count;
+    // DWAPlanner::updatePlanAndLocalCosts (dwa_planner.cpp:254-285); pos is the float-narrowed pose
+    const double gx = plan_xy[((size_t)s.plan_first + s.plan_count - 1) * 2], gy = plan_xy[((size_t)s.plan_first + s.plan_count - 1) * 2 + 1];
+    const double sq_dist = (s.pos[0] - gx) * (s.pos[0] - gx) + (s.pos[1] - gy) * (s.pos[1] - gy);
+    const double angle_to_goal = atan2(gy - s.pos[1], gx - s.pos[0]);
+    h_front[2 * li] = gx + c.forward_point_distance * cos(angle_to_goal);
+    h_front[2 * li + 1] = gy + c.forward_point_distance * sin(angle_to_goal);
+    h_align[li] = sq_dist > c.forward_point_distance * c.forward_point_distance * c.cheat_factor ? 1 : 0;
+  }
+  HIP_TRY(hipMemcpyAsync(pl.state + first, states, sizeof(navgpu_robot_state) * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(pl.plan + (size_t)first * pl.max_plan * 2, h_plan.data(), sizeof(double) * h_plan.size(), hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(pl.plan_count + first, h_cnt.data(), sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(pl.front_last + (size_t)first * 2, h_front.data(), sizeof(double) * 2 * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(pl.align_on + first, h_align.data(), sizeof(int32_t) * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  f->planner_staged = true;
+  return NAVGPU_OK;
+}
+
+int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
+  if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  if (!f->planner_configured || !f->planner_staged) return NAVGPU_ERR_STATE;
+  PlannerDev& pl = f->pl;
+  launch_samples(pl, first, count, f->stream);
+  PROFILED(f, NAVGPU_K_BFS, launch_bfs(pl, first, count, f->stream));
+  PROFILED(f, NAVGPU_K_SCORE, launch_score(pl, first, count, nullptr, f->stream));
+  PROFILED(f, NAVGPU_K_SELECT, launch_select(pl, first, count, f->stream));
+  return checkLaunch();
+}
+
+int navgpu_planner_results(navgpu_fleet* f, uint32_t first, uint32_t count, navgpu_plan_result* results) {
+  if (!f || !results || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  HIP_TRY(hipMemcpyAsync(results, f->pl.result + first, sizeof(navgpu_plan_result) * count, hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  return NAVGPU_OK;
+}
+
+int navgpu_planner_trajectory(navgpu_fleet* f, uint32_t instance, double* xyth, uint32_t cap) {
+  if (!f || !xyth || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
+  navgpu_plan_result r;
+  HIP_TRY(hipMemcpyAsync(&r, f->pl.result + instance, sizeof(r), hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  uint32_t n = std::min<uint32_t>(r.n_points > 0 ? r.n_points : 0, cap);
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(xyth, f->pl.traj + (size_t)instance * f->pl.max_sim_steps * 3, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, f->stream));
+    HIP_TRY(hipStreamSynchronize(f->stream));
+  }
+  return r.n_points;
+}
+
+int navgpu_planner_samples(navgpu_fleet* f, uint32_t instance, double* costs, int32_t* status, float* vel, uint32_t cap) {
+  if (!f || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
+  PlannerDev& pl = f->pl;
+  if (!pl.sample_cost) return NAVGPU_ERR_STATE;
+  int32_t cnt[4];
+  HIP_TRY(hipMemcpyAsync(cnt, pl.axis_count + 4 * instance, sizeof(cnt), hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  const uint32_t n = std::min<uint32_t>(cnt[3], cap);
+  if (costs && n) HIP_TRY(hipMemcpyAsync(costs, pl.sample_cost + (size_t)instance * pl.max_samples, sizeof(double) * n, hipMemcpyDeviceToHost, f->stream));
+  if (status && n) HIP_TRY(hipMemcpyAsync(status, pl.sample_status + (size_t)instance * pl.max_samples, sizeof(int32_t) * n, hipMemcpyDeviceToHost, f->stream));
+  std::vector<float> ax((size_t)3 * pl.max_axis);
+  if (vel && n) HIP_TRY(hipMemcpyAsync(ax.data(), pl.axis_samples + (size_t)instance * 3 * pl.max_axis, sizeof(float) * ax.size(), hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  if (vel)
+    for (uint32_t s = 0; s < n; ++s) {
+      const int ix = s / (cnt[1] * cnt[2]), rem = s - ix * (cnt[1] * cnt[2]), iy = rem / cnt[2], it = rem - iy * cnt[2];
+      vel[3 * s] = ax[ix];
+      vel[3 * s + 1] = ax[pl.max_axis + iy];
+      vel[3 * s + 2] = ax[2 * pl.max_axis + it];
+    }
+  return cnt[3];
+}
+
+int navgpu_planner_check_trajectory(navgpu_fleet* f, uint32_t instance, const float vs[3], int32_t* ok) {
+  if (!f || !vs || !ok || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
+  if (!f->planner_configured || !f->planner_staged) return NAVGPU_ERR_STATE;
+  PlannerDev& pl = f->pl;
+  // checkTrajectory resets the oscillation flags first (dwa_planner.cpp:217)
+  HIP_TRY(hipMemsetAsync(pl.osc_flags + instance, 0, sizeof(uint32_t), f->stream));
+  HIP_TRY(hipMemcpyAsync(f->d_explicit, vs, sizeof(float) * 3, hipMemcpyHostToDevice, f->stream));
+  launch_score(pl, instance, 1, f->d_explicit, f->stream);
+  double cost;
+  int idx;
+  HIP_TRY(hipMemcpyAsync(&cost, pl.part_cost + (size_t)instance * pl.score_blocks, sizeof(double), hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipMemcpyAsync(&idx, pl.part_index + (size_t)instance * pl.score_blocks, sizeof(int), hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  *ok = (idx != 0x7FFFFFFF) ? 1 : 0;
+  return checkLaunch();
+}
+
+int navgpu_planner_get_oscillation(navgpu_fleet* f, uint32_t first, uint32_t count, uint32_t* flags, float* prev) {
+  if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  if (flags) HIP_TRY(hipMemcpyAsync(flags, f->pl.osc_flags + first, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, f->stream));
+  if (prev) HIP_TRY(hipMemcpyAsync(prev, f->pl.osc_prev + (size_t)first * 3, sizeof(float) * 3 * count, hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  return NAVGPU_OK;
+}
+int navgpu_planner_set_oscillation(navgpu_fleet* f, uint32_t first, uint32_t count, const uint32_t* flags, const float* prev) {
+  if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  if (flags) HIP_TRY(hipMemcpyAsync(f->pl.osc_flags + first, flags, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
+  if (prev) HIP_TRY(hipMemcpyAsync(f->pl.osc_prev + (size_t)first * 3, prev, sizeof(float) * 3 * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipStreamSynchronize(f->stream));
+  return NAVGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ measurement
+int navgpu_profile_enable(navgpu_fleet* f, int32_t enable) {
+  if (!f) return NAVGPU_ERR_INVALID;
+  if (!enable && f->profiling) {
+    int rc = f->foldEvents();
+    if (rc) return rc;
+  }
+  f->profiling = enable != 0;
+  return NAVGPU_OK;
+}
+int navgpu_profile_reset(navgpu_fleet* f) {
+  if (!f) return NAVGPU_ERR_INVALID;
+  int rc = f->foldEvents();
+  if (rc) return rc;
+  for (int k = 0; k < NAVGPU_K_COUNT; ++k) {
+    f->prof_ms[k] = 0;
+    f->prof_n[k] = 0;
+  }
+  return NAVGPU_OK;
+}
+int navgpu_profile_read(navgpu_fleet* f, int32_t k, double* total_ms, uint64_t* launches) {
+  if (!f || k < 0 || k >= NAVGPU_K_COUNT) return NAVGPU_ERR_INVALID;
+  int rc = f->foldEvents();
+  if (rc) return rc;
+  if (total_ms) *total_ms = f->prof_ms[k];
+  if (launches) *launches = f->prof_n[k];
+  return NAVGPU_OK;
+}
+
+}  // extern "C"

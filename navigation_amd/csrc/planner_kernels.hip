@@ -1,0 +1,928 @@
+// HIP kernels (gfx950) for the local-planner half of the hot path:
+//   k_samples : VelocityIterator + SimpleTrajectoryGenerator::initialise (per-axis sample lists)
+//   k_bfs     : MapGridCostFunction::prepare — MapGrid wavefronts as bit-parallel level-synchronous BFS
+//   k_score   : generateTrajectory + the six DWA critics, one lane per velocity sample
+//   k_select  : first-strict-minimum selection, winner trajectory, oscillation flag update
+// Compiled with -ffp-contract=off: the fp64 step arithmetic on fp32 state has to round exactly
+// like the reference (simple_trajectory_generator.cpp:253-260, SURVEY §7 hard part 2).
+#include "navgpu_device.h"
+
+namespace navgpu {
+
+constexpr int kMaxAxis = 128;  // per-axis sample capacity staged in LDS (vsamples + 1 <= 128)
+
+__device__ __forceinline__ Geom geomOf(const PlannerDev& pl, uint32_t inst) {
+  return Geom{pl.origin[2 * inst], pl.origin[2 * inst + 1], pl.res, pl.nx, pl.ny};
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_samples: base_local_planner/include/base_local_planner/velocity_iterator.h:49-74 and
+// SimpleTrajectoryGenerator::initialise (src/simple_trajectory_generator.cpp:60-135).
+// One lane per axis: `next += step_size` is a sequential fp64 accumulation and must stay one.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first) {
+  const uint32_t inst = first + blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const navgpu_dwa_config& c = pl.cfg;
+  const navgpu_robot_state st = pl.state[inst];
+  int32_t* cnt = pl.axis_count + 4 * inst;
+  if (tid < 3) {
+    const int a = tid;
+    const float vsamp = a == 0 ? (float)c.vx_samples : (a == 1 ? (float)c.vy_samples : (float)c.vth_samples);
+    const double max_vel_th = c.max_rot_vel, min_vel_th = -1.0 * max_vel_th;
+    double lim_min = a == 0 ? c.min_vel_x : (a == 1 ? c.min_vel_y : min_vel_th);
+    double lim_max = a == 0 ? c.max_vel_x : (a == 1 ? c.max_vel_y : max_vel_th);
+    const float acc = a == 0 ? (float)c.acc_lim_x : (a == 1 ? (float)c.acc_lim_y : (float)c.acc_lim_theta);
+    const float v = st.vel[a];
+    float maxv, minv;
+    if (!c.use_dwa) {
+      // goal = last pose of the plan narrowed to float (dwa_planner.cpp:305-306)
+      const double* P = pl.plan + (size_t)inst * pl.max_plan * 2;
+      const uint32_t np = pl.plan_count[inst];
+      const float gx = (float)P[2 * (np - 1)], gy = (float)P[2 * (np - 1) + 1];
+      double dist = hyp2((double)(gx - st.pos[0]), (double)(gy - st.pos[1]));
+      if (a < 2) lim_max = fmax(fmin(lim_max, dist / c.sim_time), lim_min);
+      maxv = (float)fmin(lim_max, v + acc * c.sim_time);
+      minv = (float)fmax(lim_min, v - acc * c.sim_time);
+    } else {
+      maxv = (float)fmin(lim_max, v + acc * c.sim_period);
+      minv = (float)fmax(lim_min, v - acc * c.sim_period);
+    }
+    float* out = pl.axis_samples + ((size_t)inst * 3 + a) * pl.max_axis;
+    const double mn = minv, mx = maxv;
+    int n = 0;
+    if (mn == mx) {
+      out[n++] = (float)mn;
+    } else {
+      int num_samples = (int)vsamp;
+      num_samples = num_samples > 2 ? num_samples : 2;
+      double step_size = (mx - mn) / double(num_samples - 1 > 1 ? num_samples - 1 : 1);
+      double current, next = mn;
+      for (int j = 0; j < num_samples - 1; ++j) {
+        current = next;
+        next += step_size;
+        if (n < (int)pl.max_axis) out[n] = (float)current;
+        ++n;
+        if ((current < 0) && (next > 0)) {
+          if (n < (int)pl.max_axis) out[n] = 0.0f;
+          ++n;
+        }
+      }
+      if (n < (int)pl.max_axis) out[n] = (float)mx;
+      ++n;
+    }
+    cnt[a] = n < (int)pl.max_axis ? n : (int)pl.max_axis;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float prod = (float)c.vx_samples * (float)c.vy_samples * (float)c.vth_samples;
+    cnt[3] = prod > 0 ? cnt[0] * cnt[1] * cnt[2] : 0;
+    pl.counters[2 * inst] = 0;
+    pl.counters[2 * inst + 1] = 0;
+  }
+}
+void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
+  hipLaunchKernelGGL(k_samples, dim3(count), dim3(64), 0, s, pl, first);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_bfs: MapGridCostFunction::prepare (map_grid_cost_function.cpp:59-68) =
+//   MapGrid::resetPathDist + adjustPlanResolution (:135-171) + setTargetCells (:174-213) |
+//   setLocalGoal (:216-258) + computeTargetDistance (:262-310) with updatePathCell (:103-122).
+// The FIFO wavefront over a 4-connected unit-cost grid has a unique answer, so it is computed
+// level-synchronously: the grid is a bitmap (32 cells per word), one 1024-thread workgroup owns
+// one grid, every thread keeps the `free` and `visited` words it owns in registers and only the
+// two frontier bitmaps live in LDS.  One barrier per level.
+// Kept from the reference: seeds are distance 0 whatever their cost (only != 255 is checked) and
+// do propagate; an obstacle cell gets obstacleCosts() = N only when a visited free neighbour
+// touches it, else it stays unreachableCellCosts() = N+1; obstacle cells never propagate.
+// blockIdx.x: 0 = path_costs_ (and alignment_costs_), 1 = goal_costs_, 2 = goal_front_costs_.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t blockExclusiveScan1024(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t t = __shfl_up(incl, off);
+    if ((int)lane >= off) incl += t;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  const uint32_t nw = blockDim.x >> 6;
+  for (uint32_t w = 0; w < nw; ++w) {
+    uint32_t t = s_wave[w];
+    if (w < wave) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+__device__ __forceinline__ uint32_t blockMin1024(uint32_t v, uint32_t* s_wave) {
+  for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_down(v, off));
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_wave[wave] = v;
+  __syncthreads();
+  uint32_t r = 0xFFFFFFFFu;
+  const uint32_t nw = blockDim.x >> 6;
+  for (uint32_t w = 0; w < nw; ++w) r = min(r, s_wave[w]);
+  __syncthreads();
+  return r;
+}
+
+// enumerate the adjusted plan points of original pose i (the inserted ones first, then the pose
+// itself), calling f(local_index, x, y); returns how many there are.  adjustPlanResolution :135-171
+template <class F>
+__device__ __forceinline__ uint32_t adjustedPoints(const double* P, uint32_t i, double x_last_override, double y_last_override,
+                                                   bool override_last, uint32_t n, double resolution, bool count_only, F&& f) {
+  auto px = [&](uint32_t k) { return (override_last && k == n - 1) ? x_last_override : P[2 * k]; };
+  auto py = [&](uint32_t k) { return (override_last && k == n - 1) ? y_last_override : P[2 * k + 1]; };
+  const double loop_x = px(i), loop_y = py(i);
+  uint32_t cnt = 0;
+  if (i > 0) {
+    const double last_x = px(i - 1), last_y = py(i - 1);
+    const double min_sq_resolution = resolution * resolution * 4;
+    double sqdist = (loop_x - last_x) * (loop_x - last_x) + (loop_y - last_y) * (loop_y - last_y);
+    if (sqdist > min_sq_resolution) {
+      int steps = (int)(((sqrt(sqdist) - sqrt(min_sq_resolution)) / resolution) - 1);
+      if (steps > 1) {
+        if (!count_only) {
+          double deltax = (loop_x - last_x) / steps;
+          double deltay = (loop_y - last_y) / steps;
+          for (int j = 1; j < steps; ++j) f(cnt + j - 1, last_x + j * deltax, last_y + j * deltay);
+        }
+        cnt += steps - 1;
+      }
+    }
+  }
+  if (!count_only) f(cnt, loop_x, loop_y);
+  return cnt + 1;
+}
+
+template <int WPT>
+__global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
+  extern __shared__ __align__(16) uint32_t sm[];
+  __shared__ uint32_t s_wave[16];
+  const int which = blockIdx.x;
+  const uint32_t inst = first + blockIdx.y;
+  const uint32_t tid = threadIdx.x;
+  const Geom g = geomOf(pl, inst);
+  const uint32_t nx = pl.nx, ny = pl.ny, W = (nx + 31) >> 5, words = ny * W;
+  uint32_t* cur = sm;
+  uint32_t* nxt = sm + words;
+  const uint8_t* master = pl.master + (size_t)inst * pl.cells_padded;
+  uint32_t* dist = (which == 0 ? pl.path : (which == 1 ? pl.goal : pl.goal_front)) + (size_t)inst * pl.cells;
+  const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
+  const bool allow_unknown = pl.cfg.allow_unknown != 0;
+
+  // --- owned words: `free` bitmap from the costmap, frontiers cleared
+  uint32_t freeb[WPT], visited[WPT];
+#pragma unroll
+  for (int s = 0; s < WPT; ++s) {
+    const uint32_t w = tid + s * 1024;
+    freeb[s] = 0;
+    visited[s] = 0;
+    if (w < words) {
+      const uint32_t row = w / W, wi = w - row * W;
+      const uint8_t* p = master + row * nx + wi * 32;
+      const uint32_t nb = min(32u, nx - wi * 32);
+      uint32_t bits = 0;
+      for (uint32_t b = 0; b < nb; ++b) {
+        uint8_t cst = p[b];
+        bool obstacle = cst == kLethal || cst == kInscribed || (cst == kNoInfo && !allow_unknown);
+        bits |= (obstacle ? 0u : 1u) << b;
+      }
+      freeb[s] = bits;
+      cur[w] = 0;
+      nxt[w] = 0;
+    }
+  }
+  __syncthreads();
+
+  // --- seeds from the plan
+  {
+    const uint32_t n = pl.plan_count[inst];
+    const double* P = pl.plan + (size_t)inst * pl.max_plan * 2;
+    const bool ovr = which == 2;
+    const double lx = pl.front_last[2 * inst], ly = pl.front_last[2 * inst + 1];
+    const uint32_t chunk = (n + blockDim.x - 1) / blockDim.x;
+    const uint32_t i0 = min(n, tid * chunk), i1 = min(n, i0 + chunk);
+    uint32_t mine = 0;
+    for (uint32_t i = i0; i < i1; ++i) mine += adjustedPoints(P, i, lx, ly, ovr, n, g.res, true, [](uint32_t, double, double) {});
+    uint32_t total;
+    const uint32_t base = blockExclusiveScan1024(mine, s_wave, &total);
+    auto valid = [&](double x, double y, uint32_t& cell) {
+      uint32_t mx, my;
+      if (!worldToMap(g, x, y, mx, my)) return false;
+      cell = my * nx + mx;
+      return master[cell] != kNoInfo;
+    };
+    // f = first valid adjusted index
+    uint32_t fmin_ = 0xFFFFFFFFu, b = base;
+    for (uint32_t i = i0; i < i1; ++i)
+      b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+        uint32_t cell;
+        if (valid(x, y, cell)) fmin_ = min(fmin_, b + k);
+      });
+    const uint32_t f = blockMin1024(fmin_, s_wave);
+    if (f != 0xFFFFFFFFu) {  // else: no point of the plan is in the map -> every cell stays unreachable
+      // e = first invalid adjusted index after f
+      uint32_t emin = total;
+      b = base;
+      for (uint32_t i = i0; i < i1; ++i)
+        b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+          uint32_t cell;
+          if (b + k > f && !valid(x, y, cell)) emin = min(emin, b + k);
+        });
+      const uint32_t e = blockMin1024(emin, s_wave);
+      b = base;
+      for (uint32_t i = i0; i < i1; ++i)
+        b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+          const uint32_t idx = b + k;
+          const bool seed = (which == 0) ? (idx >= f && idx < e) : (idx == e - 1);
+          if (!seed) return;
+          uint32_t cell;
+          if (!valid(x, y, cell)) return;  // cannot happen inside [f, e)
+          const uint32_t my = cell / nx, mx = cell - my * nx;
+          atomicOr(&cur[my * W + (mx >> 5)], 1u << (mx & 31));
+          dist[cell] = 0;
+        });
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < WPT; ++s) {
+    const uint32_t w = tid + s * 1024;
+    if (w < words) visited[s] = cur[w];
+  }
+
+  // --- level-synchronous expansion
+  const uint32_t last_mask = (nx & 31) ? ((1u << (nx & 31)) - 1u) : 0xFFFFFFFFu;
+  uint32_t level = 0;
+  while (true) {
+    int any = 0;
+#pragma unroll
+    for (int s = 0; s < WPT; ++s) {
+      const uint32_t w = tid + s * 1024;
+      if (w < words) {
+        const uint32_t row = w / W, wi = w - row * W;
+        const uint32_t fc = cur[w];
+        const uint32_t l = wi > 0 ? cur[w - 1] : 0u;
+        const uint32_t r = wi + 1 < W ? cur[w + 1] : 0u;
+        const uint32_t u = row > 0 ? cur[w - W] : 0u;
+        const uint32_t d = row + 1 < ny ? cur[w + W] : 0u;
+        uint32_t cand = ((fc << 1) | (l >> 31) | (fc >> 1) | (r << 31) | u | d) & ~visited[s];
+        if (wi + 1 == W) cand &= last_mask;
+        const uint32_t nf = cand & freeb[s];
+        uint32_t no = cand & ~freeb[s];
+        visited[s] |= cand;
+        nxt[w] = nf;
+        any |= nf != 0;
+        uint32_t* drow = dist + row * nx + wi * 32;
+        uint32_t t = nf;
+        while (t) {
+          const int bpos = __ffs(t) - 1;
+          t &= t - 1;
+          drow[bpos] = level + 1;
+        }
+        while (no) {
+          const int bpos = __ffs(no) - 1;
+          no &= no - 1;
+          drow[bpos] = N_obst;
+        }
+      }
+    }
+    if (!__syncthreads_or(any)) break;
+    uint32_t* t = cur;
+    cur = nxt;
+    nxt = t;
+    ++level;
+  }
+  // --- never visited: unreachableCellCosts()
+#pragma unroll
+  for (int s = 0; s < WPT; ++s) {
+    const uint32_t w = tid + s * 1024;
+    if (w < words) {
+      const uint32_t row = w / W, wi = w - row * W;
+      uint32_t t = ~visited[s];
+      if (wi + 1 == W) t &= last_mask;
+      uint32_t* drow = dist + row * nx + wi * 32;
+      while (t) {
+        const int bpos = __ffs(t) - 1;
+        t &= t - 1;
+        drow[bpos] = N_unreach;
+      }
+    }
+  }
+}
+
+size_t bfs_lds_bytes(uint32_t nx, uint32_t ny) { return (size_t)2 * ny * ((nx + 31) / 32) * 4; }
+
+void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
+  const uint32_t words = pl.ny * ((pl.nx + 31) / 32);
+  const size_t lds = bfs_lds_bytes(pl.nx, pl.ny);
+  dim3 grid(3, count);
+  if (words <= 6 * 1024)
+    hipLaunchKernelGGL(k_bfs<6>, grid, dim3(1024), lds, s, pl, first);
+  else if (words <= 12 * 1024)
+    hipLaunchKernelGGL(k_bfs<12>, grid, dim3(1024), lds, s, pl, first);
+  else
+    hipLaunchKernelGGL(k_bfs<20>, grid, dim3(1024), lds, s, pl, first);  // <= 20480 words (host checks)
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_score: one lane per velocity sample.
+//   SimpleTrajectoryGenerator::generateTrajectory / computeNewPositions / computeNewVelocities
+//     (simple_trajectory_generator.cpp:180-276)
+//   SimpleScoredSamplingPlanner::scoreTrajectory (simple_scored_sampling_planner.cpp:50-79) with the
+//     critic order of dwa_planner.cpp:167-173: oscillation, obstacle, goal_front, alignment, path, goal
+//   ObstacleCostFunction::scoreTrajectory/footprintCost (obstacle_cost_function.cpp:74-142),
+//   WorldModel::footprintCost (world_model.h:65-86), CostmapModel::footprintCost/lineCost/pointCost
+//     (costmap_model.cpp:50-142), LineIterator (line_iterator.h:38-139)
+//   MapGridCostFunction::scoreTrajectory (map_grid_cost_function.cpp:75-129, aggregation Last)
+//   OscillationCostFunction::scoreTrajectory (oscillation_cost_function.cpp:166-176)
+// Every sample is scored in full (no early-out against the incumbent): critic terms are
+// non-negative, so the first strict minimum is the same sample the reference keeps.
+// The costmap window the trajectories can reach is staged in LDS; cells outside it (never needed
+// with a correctly sized window) fall back to a global load, so results never depend on it.
+// ------------------------------------------------------------------------------------------------
+struct ScoreOut {
+  double total;
+  int status;
+  int n_points;
+};
+
+template <bool EXPLICIT>
+__global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, const float* explicit_sample) {
+  extern __shared__ __align__(16) uint8_t s_win[];
+  __shared__ double s_fp[2 * kMaxFootprint];
+  __shared__ float s_axis[3][kMaxAxis];
+  __shared__ double s_rc[4];
+  __shared__ int s_ri[4];
+  __shared__ int s_cnt[2];
+
+  const uint32_t inst = first + blockIdx.y;
+  const uint32_t tid = threadIdx.x;
+  const navgpu_dwa_config& c = pl.cfg;
+  const Geom g = geomOf(pl, inst);
+  const navgpu_robot_state st = pl.state[inst];
+  const uint8_t* master = pl.master + (size_t)inst * pl.cells_padded;
+  const uint32_t* dpath = pl.path + (size_t)inst * pl.cells;
+  const uint32_t* dgoal = pl.goal + (size_t)inst * pl.cells;
+  const uint32_t* dfront = pl.goal_front + (size_t)inst * pl.cells;
+  const int32_t* cnt = pl.axis_count + 4 * inst;
+  const int n_samples = EXPLICIT ? 1 : cnt[3];
+  const uint32_t nfp = pl.fp_n[inst];
+  const int win = (int)pl.win;
+
+  // ---- stage: footprint, per-axis samples, costmap window around the robot
+  if (tid < 2 * nfp) s_fp[tid] = pl.fp_spec[(size_t)inst * kMaxFootprint * 2 + tid];
+  if (!EXPLICIT) {
+    for (uint32_t i = tid; i < 3 * kMaxAxis; i += blockDim.x) {
+      uint32_t a = i / kMaxAxis, k = i - a * kMaxAxis;
+      s_axis[a][k] = k < pl.max_axis ? pl.axis_samples[((size_t)inst * 3 + a) * pl.max_axis + k] : 0.f;
+    }
+  }
+  if (tid == 0) s_cnt[0] = s_cnt[1] = 0;
+  int wx0 = 0, wy0 = 0;
+  {
+    // window origin: robot cell (floor of the map coordinate, also valid when the robot is off the map)
+    double fx = floor(((double)st.pos[0] - g.ox) / g.res), fy = floor(((double)st.pos[1] - g.oy) / g.res);
+    fx = fmin(fmax(fx, -1.0e6), 1.0e6);
+    fy = fmin(fmax(fy, -1.0e6), 1.0e6);
+    wx0 = (int)fx - win / 2;
+    wy0 = (int)fy - win / 2;
+    for (int i = tid; i < win * win; i += blockDim.x) {
+      int ly = i / win, lx = i - ly * win;
+      int gx = wx0 + lx, gy = wy0 + ly;
+      uint8_t v = 0;
+      if (gx >= 0 && gy >= 0 && gx < (int)g.nx && gy < (int)g.ny) v = master[gy * g.nx + gx];
+      s_win[i] = v;
+    }
+  }
+  __syncthreads();
+
+  auto cellCost = [&](int x, int y) -> uint8_t {
+    const int lx = x - wx0, ly = y - wy0;
+    if ((unsigned)lx < (unsigned)win && (unsigned)ly < (unsigned)win) return s_win[ly * win + lx];
+    return master[y * g.nx + x];
+  };
+
+  const int sidx = blockIdx.x * blockDim.x + tid;
+  double total = -1.0;
+  int status = NAVGPU_SAMPLE_REJECTED;
+  bool in_range = sidx < n_samples;
+
+  if (in_range) {
+    float vs[3];
+    if (EXPLICIT) {
+      vs[0] = explicit_sample[0];
+      vs[1] = explicit_sample[1];
+      vs[2] = explicit_sample[2];
+    } else {
+      const int nth = cnt[2], nyv = cnt[1];
+      const int ix = sidx / (nyv * nth), rem = sidx - ix * (nyv * nth);
+      const int iy = rem / nth, ith = rem - iy * nth;
+      vs[0] = s_axis[0][ix];
+      vs[1] = s_axis[1][iy];
+      vs[2] = s_axis[2][ith];
+    }
+    // ---- generateTrajectory: reject tests and step count (:193-216)
+    const double vmag = hyp2((double)vs[0], (double)vs[1]);
+    const double eps = 1e-4;
+    bool reject = false;
+    if ((c.min_trans_vel >= 0 && vmag + eps < c.min_trans_vel) && (c.min_rot_vel >= 0 && fabs((double)vs[2]) + eps < c.min_rot_vel)) reject = true;
+    if (c.max_trans_vel >= 0 && vmag - eps > c.max_trans_vel) reject = true;
+    int num_steps = 0;
+    if (!reject) {
+      double ns;
+      if (c.discretize_by_time) {
+        ns = ceil(c.sim_time / c.sim_granularity);
+      } else {
+        double sim_time_distance = vmag * c.sim_time;
+        double sim_time_angle = fabs((double)vs[2]) * c.sim_time;
+        ns = ceil(fmax(sim_time_distance / c.sim_granularity, sim_time_angle / c.angular_sim_granularity));
+      }
+      num_steps = (int)ns;
+      if (num_steps <= 0) reject = true;  // `return num_steps > 0` (:250)
+      if (num_steps > (int)pl.max_sim_steps) num_steps = (int)pl.max_sim_steps;  // host validates the capacity
+    }
+    if (!reject) {
+      status = NAVGPU_SAMPLE_SCORED;
+      const double dt = c.sim_time / num_steps;
+      const bool continued = !c.use_dwa;
+      float px = st.pos[0], py = st.pos[1], pth = st.pos[2];
+      float lv[3] = {vs[0], vs[1], vs[2]};
+      const float acc[3] = {(float)c.acc_lim_x, (float)c.acc_lim_y, (float)c.acc_lim_theta};
+      auto newVel = [&](const float* vel_in, float* out) {  // computeNewVelocities (:265-276)
+        for (int i = 0; i < 3; ++i) {
+          if (vel_in[i] < vs[i])
+            out[i] = (float)fmin((double)vs[i], vel_in[i] + acc[i] * dt);
+          else
+            out[i] = (float)fmax((double)vs[i], vel_in[i] - acc[i] * dt);
+        }
+      };
+      if (continued) {
+        float t0[3];
+        newVel(st.vel, t0);
+        lv[0] = t0[0];
+        lv[1] = t0[1];
+        lv[2] = t0[2];
+      }
+      const double xv = lv[0], yv = lv[1], thv = lv[2];  // traj.xv_, yv_, thetav_
+
+      // ---- critics
+      const uint32_t osc = EXPLICIT ? 0u : pl.osc_flags[inst];
+      const bool osc_fail = ((osc & NAVGPU_OSC_FORWARD_POS_ONLY) && xv < 0.0) || ((osc & NAVGPU_OSC_FORWARD_NEG_ONLY) && xv > 0.0) ||
+                            ((osc & NAVGPU_OSC_STRAFE_POS_ONLY) && yv < 0.0) || ((osc & NAVGPU_OSC_STRAFE_NEG_ONLY) && yv > 0.0) ||
+                            ((osc & NAVGPU_OSC_ROT_POS_ONLY) && thv < 0.0) || ((osc & NAVGPU_OSC_ROT_NEG_ONLY) && thv > 0.0);
+      const double sc_obs = pl.scale_obstacle, sc_gf = pl.scale_goal, sc_al = pl.align_on[inst] ? pl.scale_path : 0.0,
+                   sc_path = pl.scale_path, sc_goal = pl.scale_goal;
+      const bool en_obs = sc_obs != 0, en_gf = sc_gf != 0, en_al = sc_al != 0, en_path = sc_path != 0, en_goal = sc_goal != 0;
+      double code_obs = 0, code_gf = 0, code_al = 0, code_path = 0, code_goal = 0;
+      double v_obs = 0, v_gf = 0, v_al = 0, v_path = 0, v_goal = 0;
+      int first_fail = 6;  // order index of the earliest critic that failed (1..5), 6 = none
+      const bool allow_unknown = c.allow_unknown != 0;
+      const double fpd = c.forward_point_distance;
+      const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
+
+      if (en_obs && nfp == 0) {  // "Footprint spec is empty" (obstacle_cost_function.cpp:78-82)
+        code_obs = -9.0;
+        first_fail = 1;
+      }
+      if (osc_fail) {
+        total = -5.0;
+      } else {
+        for (int step = 0; step < num_steps; ++step) {
+          const bool live_obs = en_obs && 1 < first_fail, live_gf = en_gf && 2 < first_fail, live_al = en_al && 3 < first_fail,
+                     live_path = en_path && 4 < first_fail, live_goal = en_goal && 5 < first_fail;
+          if (!(live_obs || live_gf || live_al || live_path || live_goal)) break;
+          const double x = px, y = py, th = pth;
+          double sn, cs;
+          sincos(th, &sn, &cs);
+          uint32_t cx = 0, cy = 0;
+          const bool ok_c = worldToMap(g, x, y, cx, cy);
+          if (live_obs) {
+            double f_cost = 0.0;
+            bool bad = !ok_c;  // CostmapModel::footprintCost: centre off the map -> -1
+            if (!bad) {
+              if (nfp < 3) {
+                uint8_t cc = cellCost(cx, cy);
+                if (cc == kLethal || cc == kInscribed || (cc == kNoInfo && !allow_unknown))
+                  bad = true;
+                else
+                  f_cost = cc;
+              } else {
+                int fx0 = 0, fy0 = 0, pxc = 0, pyc = 0;
+                uint8_t mx_cost = 0;
+                for (uint32_t v = 0; v <= nfp && !bad; ++v) {
+                  int vx, vy;
+                  if (v < nfp) {
+                    const double sx = s_fp[2 * v], sy = s_fp[2 * v + 1];
+                    const double wx = x + (sx * cs - sy * sn);
+                    const double wy = y + (sx * sn + sy * cs);
+                    uint32_t ux, uy;
+                    if (!worldToMap(g, wx, wy, ux, uy)) {
+                      bad = true;
+                      break;
+                    }
+                    vx = (int)ux;
+                    vy = (int)uy;
+                    if (v == 0) {
+                      fx0 = vx;
+                      fy0 = vy;
+                      pxc = vx;
+                      pyc = vy;
+                      continue;
+                    }
+                  } else {  // closing edge: last -> first
+                    vx = fx0;
+                    vy = fy0;
+                  }
+                  // lineCost over LineIterator(pxc, pyc, vx, vy)
+                  int deltax = vx - pxc, deltay = vy - pyc;
+                  deltax = deltax < 0 ? -deltax : deltax;
+                  deltay = deltay < 0 ? -deltay : deltay;
+                  int lx = pxc, ly = pyc;
+                  int xinc1, xinc2, yinc1, yinc2, den, num, numadd, numpixels;
+                  xinc1 = xinc2 = (vx >= pxc) ? 1 : -1;
+                  yinc1 = yinc2 = (vy >= pyc) ? 1 : -1;
+                  if (deltax >= deltay) {
+                    xinc1 = 0;
+                    yinc2 = 0;
+                    den = deltax;
+                    num = deltax / 2;
+                    numadd = deltay;
+                    numpixels = deltax;
+                  } else {
+                    xinc2 = 0;
+                    yinc1 = 0;
+                    den = deltay;
+                    num = deltay / 2;
+                    numadd = deltax;
+                    numpixels = deltay;
+                  }
+                  for (int cp = 0; cp <= numpixels; ++cp) {
+                    uint8_t cc = cellCost(lx, ly);
+                    if (cc == kLethal || (cc == kNoInfo && !allow_unknown)) {
+                      bad = true;
+                      break;
+                    }
+                    mx_cost = cc > mx_cost ? cc : mx_cost;
+                    num += numadd;
+                    if (num >= den) {
+                      num -= den;
+                      lx += xinc1;
+                      ly += yinc1;
+                    }
+                    lx += xinc2;
+                    ly += yinc2;
+                  }
+                  pxc = vx;
+                  pyc = vy;
+                }
+                f_cost = mx_cost;
+              }
+            }
+            if (bad) {
+              code_obs = -6.0;
+              first_fail = 1;
+            } else {
+              // ok_c holds here, so the -7 branch (obstacle_cost_function.cpp:135-137) cannot fire
+              const double occ = fmax(fmax(0.0, f_cost), (double)cellCost(cx, cy));
+              v_obs = c.sum_scores ? v_obs + occ : occ;
+            }
+          }
+          if ((en_path && 4 < first_fail) || (en_goal && 5 < first_fail)) {
+            if (!ok_c) {
+              if (en_path && 4 < first_fail) {
+                code_path = -4.0;
+                first_fail = 4;
+              } else {
+                code_goal = -4.0;
+                first_fail = 5;
+              }
+            } else {
+              const uint32_t cell = cy * g.nx + cx;
+              if (en_path && 4 < first_fail) {
+                const uint32_t d = dpath[cell];
+                if (d == N_obst) {
+                  code_path = -3.0;
+                  first_fail = 4;
+                } else if (d == N_unreach) {
+                  code_path = -2.0;
+                  first_fail = 4;
+                } else
+                  v_path = d;
+              }
+              if (en_goal && 5 < first_fail) {
+                const uint32_t d = dgoal[cell];
+                if (d == N_obst) {
+                  code_goal = -3.0;
+                  first_fail = 5;
+                } else if (d == N_unreach) {
+                  code_goal = -2.0;
+                  first_fail = 5;
+                } else
+                  v_goal = d;
+              }
+            }
+          }
+          if ((en_gf && 2 < first_fail) || (en_al && 3 < first_fail)) {
+            double sx = x, sy = y;
+            if (fpd != 0.0) {
+              sx = x + fpd * cs;
+              sy = y + fpd * sn;
+            }
+            uint32_t ux, uy;
+            if (!worldToMap(g, sx, sy, ux, uy)) {
+              if (en_gf && 2 < first_fail) {
+                code_gf = -4.0;
+                first_fail = 2;
+              } else {
+                code_al = -4.0;
+                first_fail = 3;
+              }
+            } else if (step == num_steps - 1) {  // aggregation Last: only the final point's value survives
+              const uint32_t cell = uy * g.nx + ux;
+              if (en_gf && 2 < first_fail) v_gf = dfront[cell];
+              if (en_al && 3 < first_fail) v_al = dpath[cell];
+            }
+          }
+          // ---- advance (computeNewPositions :253-260): fp64 on fp32 state, rounded back to fp32
+          if (continued) {
+            float t1[3];
+            newVel(lv, t1);
+            lv[0] = t1[0];
+            lv[1] = t1[1];
+            lv[2] = t1[2];
+          }
+          double sn2 = 0.0, cs2 = 0.0;
+          if (lv[1] != 0.0f) sincos(M_PI_2 + th, &sn2, &cs2);
+          const float nxp = (float)(px + (lv[0] * cs + lv[1] * cs2) * dt);
+          const float nyp = (float)(py + (lv[0] * sn + lv[1] * sn2) * dt);
+          const float ntp = (float)(pth + lv[2] * dt);
+          px = nxp;
+          py = nyp;
+          pth = ntp;
+        }
+        // ---- scoreTrajectory sum in critic order
+        total = 0.0;
+        bool done = false;
+        auto add = [&](bool en, double code, double value, double scale) {
+          if (done || !en) return;
+          if (code < 0) {
+            total = code;
+            done = true;
+            return;
+          }
+          double cost = value;
+          if (cost != 0) cost *= scale;
+          total += cost;
+        };
+        add(en_obs, code_obs, v_obs, sc_obs);
+        add(en_gf, code_gf, v_gf, sc_gf);
+        add(en_al, code_al, v_al, sc_al);
+        add(en_path, code_path, v_path, sc_path);
+        add(en_goal, code_goal, v_goal, sc_goal);
+      }
+    }
+    if (!EXPLICIT && pl.sample_cost) {
+      pl.sample_cost[(size_t)inst * pl.max_samples + sidx] = total;
+      pl.sample_status[(size_t)inst * pl.max_samples + sidx] = status;
+    }
+  }
+
+  // ---- workgroup argmin (lowest index wins ties == first strict minimum of the sequential loop)
+  const bool valid = in_range && status == NAVGPU_SAMPLE_SCORED && total >= 0.0;
+  double bc = valid ? total : 1.0e300;
+  int bi = valid ? sidx : 0x7FFFFFFF;
+  for (int off = 32; off > 0; off >>= 1) {
+    double oc = __shfl_down(bc, off);
+    int oi = __shfl_down(bi, off);
+    if (oc < bc || (oc == bc && oi < bi)) {
+      bc = oc;
+      bi = oi;
+    }
+  }
+  const unsigned long long m_scored = __ballot(in_range && status == NAVGPU_SAMPLE_SCORED);
+  const unsigned long long m_valid = __ballot(valid);
+  if ((tid & 63) == 0) {
+    s_rc[tid >> 6] = bc;
+    s_ri[tid >> 6] = bi;
+    atomicAdd(&s_cnt[0], __popcll(m_scored));
+    atomicAdd(&s_cnt[1], __popcll(m_valid));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (s_rc[w] < bc || (s_rc[w] == bc && s_ri[w] < bi)) {
+        bc = s_rc[w];
+        bi = s_ri[w];
+      }
+    pl.part_cost[(size_t)inst * pl.score_blocks + blockIdx.x] = bc;
+    pl.part_index[(size_t)inst * pl.score_blocks + blockIdx.x] = bi;
+    if (s_cnt[0]) atomicAdd(&pl.counters[2 * inst], s_cnt[0]);
+    if (s_cnt[1]) atomicAdd(&pl.counters[2 * inst + 1], s_cnt[1]);
+  }
+}
+
+void launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s) {
+  const size_t lds = (size_t)pl.win * pl.win;
+  if (explicit_sample)
+    hipLaunchKernelGGL(k_score<true>, dim3(1, count), dim3(256), lds, s, pl, first, explicit_sample);
+  else
+    hipLaunchKernelGGL(k_score<false>, dim3(pl.score_blocks, count), dim3(256), lds, s, pl, first, explicit_sample);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_select: the tail of SimpleScoredSamplingPlanner::findBestTrajectory (:111-135) and of
+// DWAPlanner::findBestPath (dwa_planner.cpp:316,357-368): pick the first strict minimum, rebuild
+// the winner's points, run OscillationCostFunction::updateOscillationFlags
+// (oscillation_cost_function.cpp:56-164), fill drive velocities.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_select(PlannerDev pl, uint32_t first, uint32_t n_blocks) {
+  const uint32_t inst = first + blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const navgpu_dwa_config& c = pl.cfg;
+  double bc = 1.0e300;
+  int bi = 0x7FFFFFFF;
+  for (uint32_t k = tid; k < n_blocks; k += 64) {
+    double oc = pl.part_cost[(size_t)inst * pl.score_blocks + k];
+    int oi = pl.part_index[(size_t)inst * pl.score_blocks + k];
+    if (oc < bc || (oc == bc && oi < bi)) {
+      bc = oc;
+      bi = oi;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    double oc = __shfl_down(bc, off);
+    int oi = __shfl_down(bi, off);
+    if (oc < bc || (oc == bc && oi < bi)) {
+      bc = oc;
+      bi = oi;
+    }
+  }
+  if (tid != 0) return;
+  const navgpu_robot_state st = pl.state[inst];
+  const int32_t* cnt = pl.axis_count + 4 * inst;
+  navgpu_plan_result r;
+  r.n_samples = cnt[3];
+  r.n_scored = pl.counters[2 * inst];
+  r.n_valid = pl.counters[2 * inst + 1];
+  r.reserved = 0;
+  double* tr = pl.traj + (size_t)inst * pl.max_sim_steps * 3;
+  uint32_t flags = pl.osc_flags[inst];
+  if (bi == 0x7FFFFFFF) {
+    r.best_index = -1;
+    r.n_points = 0;
+    r.xv = r.yv = r.thetav = 0.f;
+    r.cost = -7.0;  // result_traj_.cost_ pre-set (dwa_planner.cpp:316)
+    r.drive[0] = r.drive[1] = r.drive[2] = 0.0;
+  } else {
+    const int nth = cnt[2], nyv = cnt[1];
+    const int ix = bi / (nyv * nth), rem = bi - ix * (nyv * nth);
+    const int iy = rem / nth, ith = rem - iy * nth;
+    float vs[3];
+    vs[0] = pl.axis_samples[((size_t)inst * 3 + 0) * pl.max_axis + ix];
+    vs[1] = pl.axis_samples[((size_t)inst * 3 + 1) * pl.max_axis + iy];
+    vs[2] = pl.axis_samples[((size_t)inst * 3 + 2) * pl.max_axis + ith];
+    const double vmag = hyp2((double)vs[0], (double)vs[1]);
+    double ns;
+    if (c.discretize_by_time)
+      ns = ceil(c.sim_time / c.sim_granularity);
+    else
+      ns = ceil(fmax(vmag * c.sim_time / c.sim_granularity, fabs((double)vs[2]) * c.sim_time / c.angular_sim_granularity));
+    int num_steps = (int)ns;
+    if (num_steps > (int)pl.max_sim_steps) num_steps = (int)pl.max_sim_steps;
+    const double dt = c.sim_time / num_steps;
+    const bool continued = !c.use_dwa;
+    const float acc[3] = {(float)c.acc_lim_x, (float)c.acc_lim_y, (float)c.acc_lim_theta};
+    float lv[3] = {vs[0], vs[1], vs[2]};
+    auto newVel = [&](const float* vel_in, float* out) {
+      for (int i = 0; i < 3; ++i) {
+        if (vel_in[i] < vs[i])
+          out[i] = (float)fmin((double)vs[i], vel_in[i] + acc[i] * dt);
+        else
+          out[i] = (float)fmax((double)vs[i], vel_in[i] - acc[i] * dt);
+      }
+    };
+    if (continued) {
+      float t0[3];
+      newVel(st.vel, t0);
+      lv[0] = t0[0];
+      lv[1] = t0[1];
+      lv[2] = t0[2];
+    }
+    r.xv = lv[0];
+    r.yv = lv[1];
+    r.thetav = lv[2];
+    float px = st.pos[0], py = st.pos[1], pth = st.pos[2];
+    for (int step = 0; step < num_steps; ++step) {
+      tr[3 * step] = px;
+      tr[3 * step + 1] = py;
+      tr[3 * step + 2] = pth;
+      if (continued) {
+        float t1[3];
+        newVel(lv, t1);
+        lv[0] = t1[0];
+        lv[1] = t1[1];
+        lv[2] = t1[2];
+      }
+      const double th = pth;
+      double sn, cs, sn2 = 0.0, cs2 = 0.0;
+      sincos(th, &sn, &cs);
+      if (lv[1] != 0.0f) sincos(M_PI_2 + th, &sn2, &cs2);
+      const float nxp = (float)(px + (lv[0] * cs + lv[1] * cs2) * dt);
+      const float nyp = (float)(py + (lv[0] * sn + lv[1] * sn2) * dt);
+      const float ntp = (float)(pth + lv[2] * dt);
+      px = nxp;
+      py = nyp;
+      pth = ntp;
+    }
+    r.best_index = bi;
+    r.n_points = num_steps;
+    r.cost = bc;
+    r.drive[0] = r.xv;
+    r.drive[1] = r.yv;
+    r.drive[2] = r.thetav;
+    // ---- updateOscillationFlags(pos, &result_traj_, min_trans_vel)
+    const double xv = r.xv, yv = r.yv, thv = r.thetav;
+    bool flag_set = false;
+    auto has = [&](uint32_t b) { return (flags & b) != 0; };
+    auto set = [&](uint32_t b, bool v) { flags = v ? (flags | b) : (flags & ~b); };
+    if (xv < 0.0) {
+      if (has(NAVGPU_OSC_FORWARD_POS)) {
+        set(NAVGPU_OSC_FORWARD_NEG_ONLY, true);
+        flag_set = true;
+      }
+      set(NAVGPU_OSC_FORWARD_POS, false);
+      set(NAVGPU_OSC_FORWARD_NEG, true);
+    }
+    if (xv > 0.0) {
+      if (has(NAVGPU_OSC_FORWARD_NEG)) {
+        set(NAVGPU_OSC_FORWARD_POS_ONLY, true);
+        flag_set = true;
+      }
+      set(NAVGPU_OSC_FORWARD_NEG, false);
+      set(NAVGPU_OSC_FORWARD_POS, true);
+    }
+    if (fabs(xv) <= c.min_trans_vel) {
+      if (yv < 0) {
+        if (has(NAVGPU_OSC_STRAFING_POS)) {
+          set(NAVGPU_OSC_STRAFE_NEG_ONLY, true);
+          flag_set = true;
+        }
+        set(NAVGPU_OSC_STRAFING_POS, false);
+        set(NAVGPU_OSC_STRAFING_NEG, true);
+      }
+      if (yv > 0) {
+        if (has(NAVGPU_OSC_STRAFING_NEG)) {
+          set(NAVGPU_OSC_STRAFE_POS_ONLY, true);
+          flag_set = true;
+        }
+        set(NAVGPU_OSC_STRAFING_NEG, false);
+        set(NAVGPU_OSC_STRAFING_POS, true);
+      }
+      if (thv < 0) {
+        if (has(NAVGPU_OSC_ROTATING_POS)) {
+          set(NAVGPU_OSC_ROT_NEG_ONLY, true);
+          flag_set = true;
+        }
+        set(NAVGPU_OSC_ROTATING_POS, false);
+        set(NAVGPU_OSC_ROTATING_NEG, true);
+      }
+      if (thv > 0) {
+        if (has(NAVGPU_OSC_ROTATING_NEG)) {
+          set(NAVGPU_OSC_ROT_POS_ONLY, true);
+          flag_set = true;
+        }
+        set(NAVGPU_OSC_ROTATING_NEG, false);
+        set(NAVGPU_OSC_ROTATING_POS, true);
+      }
+    }
+    float* prev = pl.osc_prev + 3 * inst;
+    if (flag_set) {
+      prev[0] = st.pos[0];
+      prev[1] = st.pos[1];
+      prev[2] = st.pos[2];
+    }
+    const uint32_t only = NAVGPU_OSC_FORWARD_POS_ONLY | NAVGPU_OSC_FORWARD_NEG_ONLY | NAVGPU_OSC_STRAFE_POS_ONLY |
+                          NAVGPU_OSC_STRAFE_NEG_ONLY | NAVGPU_OSC_ROT_POS_ONLY | NAVGPU_OSC_ROT_NEG_ONLY;
+    if (flags & only) {  // resetOscillationFlagsIfPossible (:71-82): float differences widened to double
+      const double x_diff = st.pos[0] - prev[0];
+      const double y_diff = st.pos[1] - prev[1];
+      const double sq_dist = x_diff * x_diff + y_diff * y_diff;
+      const double th_diff = st.pos[2] - prev[2];
+      if (sq_dist > c.oscillation_reset_dist * c.oscillation_reset_dist || fabs(th_diff) > c.oscillation_reset_angle) flags = 0;
+    }
+  }
+  r.oscillation_flags = flags;
+  pl.osc_flags[inst] = flags;
+  pl.result[inst] = r;
+}
+void launch_select(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
+  hipLaunchKernelGGL(k_select, dim3(count), dim3(64), 0, s, pl, first, pl.score_blocks);
+}
+
+}  // namespace navgpu

@@ -1,0 +1,455 @@
+"""Parity tests proper: the HIP path (through the C-ABI, libnavgpu.so) against the CPU oracle on
+the same seeded inputs, and against the reference's own test expectations.  Need a real MI355X.
+
+Bar: bit-exact for bytes / cell indices / selected sample index / status codes; 1e-5 on trajectory
+cost floats (north_star); inflation bit-exact vs the order-independent exact-EDT specification and
+">= reference, differing fraction reported and <= 1e-4" vs the reference's priority-queue walk."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LETHAL, INSCRIBED, NOINFO, FREE = 254, 253, 255, 0
+MAX_Z = 1.0
+
+
+@pytest.fixture(scope="module")
+def nav():
+    import navigation_amd as nav
+    nav.lib()  # raises if libnavgpu.so is missing: no fallback
+    assert nav.lib().navgpu_device_count() > 0, "no HIP device visible"
+    return nav
+
+
+def L(nav):
+    from navigation_amd import _lib
+    return _lib
+
+
+# ----------------------------------------------------------------------------------------------
+# inflation
+# ----------------------------------------------------------------------------------------------
+def _random_map(rs, n, density, unknown_frac=0.0):
+    g = np.zeros((n, n), np.uint8)
+    g[rs.random_sample((n, n)) < density] = LETHAL
+    if unknown_frac:
+        g[(rs.random_sample((n, n)) < unknown_frac) & (g == 0)] = NOINFO
+    # some pre-existing non-zero costs so the max() rule matters
+    m = (rs.random_sample((n, n)) < 0.02) & (g == 0)
+    g[m] = rs.randint(1, 253, m.sum())
+    return g
+
+
+@pytest.mark.parametrize("n,density,unk", [(64, 0.01, 0.0), (64, 0.05, 0.1), (97, 0.02, 0.05), (400, 0.01, 0.0),
+                                            (400, 0.001, 0.02), (400, 0.2, 0.0)])
+def test_inflate_full_window(nav, orc, n, density, unk):
+    N = L(nav)
+    rs = np.random.RandomState(n * 7 + int(density * 1000))
+    maps = np.stack([_random_map(rs, n, density, unk) for _ in range(3)])
+    fl = nav.Fleet(3, n, n, 0.05, layers=N.LAYER_INFLATION)
+    insc = 0.2
+    fl.configure_inflation(0.55, 10.0, insc)
+    fl.upload(N.GRID_MASTER, maps)
+    fl.inflate(boxes=[[0, 0, n, n]] * 3)
+    got = fl.master()
+    n_diff = 0
+    for k in range(3):
+        exact = orc.inflate(maps[k], 0.05, 0.55, 10.0, insc, exact=True)
+        assert np.array_equal(got[k], exact), "GPU inflation != exact-EDT oracle"
+        ref = orc.inflate(maps[k], 0.05, 0.55, 10.0, insc, exact=False)
+        assert (got[k] >= ref).all() or unk > 0  # with unknowns max() vs the 255-rule can order differently
+        n_diff += int((got[k] != ref).sum())
+    frac = n_diff / (3.0 * n * n)
+    print(f"inflation n={n} density={density}: {n_diff} cells differ from the reference PQ walk ({frac:.2e})")
+    assert frac <= 2e-4
+    fl.close()
+
+
+def test_inflate_partial_boxes_and_radii(nav, orc):
+    N = L(nav)
+    rs = np.random.RandomState(5)
+    n = 150
+    for radius, scaling, insc in [(0.55, 10.0, 0.2), (1.0, 3.0, 0.35), (0.05, 10.0, 0.0), (2.0, 1.0, 0.5)]:
+        maps = np.stack([_random_map(rs, n, 0.01, 0.03) for _ in range(4)])
+        boxes = [[0, 0, n, n], [10, 20, 60, 90], [100, 100, 150, 150], [40, 0, 41, 150]]
+        fl = nav.Fleet(4, n, n, 0.05, layers=N.LAYER_INFLATION)
+        fl.configure_inflation(radius, scaling, insc)
+        fl.upload(N.GRID_MASTER, maps)
+        fl.inflate(boxes=boxes)
+        got = fl.master()
+        for k in range(4):
+            exact = orc.inflate(maps[k], 0.05, radius, scaling, insc, box=boxes[k], exact=True)
+            assert np.array_equal(got[k], exact), (radius, k)
+        fl.close()
+
+
+def test_inflate_lut_matches_reference_tables(nav, orc):
+    # the cost table the GPU uploads is computed by the same fp64 libm expressions as the oracle's
+    R, costs, dists = orc.cost_lut(0.05, 0.55, 10.0, 0.2)
+    assert R == 11 and costs[0, 0] == LETHAL and costs[1, 0] == INSCRIBED
+
+
+# ----------------------------------------------------------------------------------------------
+# layered costmap cycles: the reference's own scenarios through the GPU path
+# ----------------------------------------------------------------------------------------------
+def _radii(length, width):
+    return [[width, length], [width, -length], [-width, -length], [-width, length]]
+
+
+class GpuLayered:
+    """Drives a 1-instance fleet the way the reference tests drive LayeredCostmap (testing_helper.h):
+    static observations accumulate and are re-applied on every updateMap."""
+
+    def __init__(self, nav, orc, n, res=1.0, static=None, inflation=None, polygon=None, track_unknown=False):
+        N = L(nav)
+        layers = N.LAYER_OBSTACLE | (N.LAYER_STATIC if static is not None else 0) | (N.LAYER_INFLATION if inflation else 0)
+        self.fl = nav.Fleet(1, n, n, res, layers=layers, track_unknown=track_unknown, max_points=64, max_observations=16)
+        self.N = N
+        self.obs = []
+        self.o = orc.LayeredCostmap(track_unknown)
+        if static is None:
+            self.o.resize(n, n, res, 0, 0)
+        if polygon is not None:
+            self.o.set_footprint(polygon)
+        if static is not None:
+            self.o.add_static(static, res=res)
+            self.fl.add_static_map(static)
+        self.o.add_obstacle()
+        self.fl.configure_obstacle()
+        if inflation:
+            self.o.add_inflation(inflation[0], inflation[1], exact=True)
+        if polygon is not None:
+            self.o.set_footprint(polygon)
+            self.fl.set_footprint(polygon)
+        if inflation:
+            self.fl.configure_inflation(inflation[0], inflation[1], self.o.inscribed_radius)
+
+    def add_observation(self, pts, origin=(0.0, 0.0, MAX_Z)):
+        self.o.add_observation(pts, origin=origin)
+        self.obs.append(dict(instance=0, points=np.asarray(pts, np.float32), origin=origin, obstacle_range=100.0,
+                             raytrace_range=100.0))
+
+    def update(self, rx=0.0, ry=0.0, ryaw=0.0):
+        self.o.update_map(rx, ry, ryaw)
+        self.fl.stage_observations([[rx, ry, ryaw]], self.obs)
+        self.fl.update_map()
+        m = self.fl.master()[0]
+        assert np.array_equal(m, self.o.master()), "GPU master grid != oracle"
+        assert np.array_equal(self.fl.download(self.N.GRID_OBSTACLE)[0], self.o.layer(2)), "GPU obstacle layer != oracle"
+        assert np.array_equal(self.fl.bounds()[0], self.o.bounds()), "update box differs"
+        return m
+
+
+def count(m, v, equal=True):
+    return int((m == v).sum()) if equal else int((m != v).sum())
+
+
+def test_reference_obstacle_scenarios(nav, orc, ten_by_ten):  # costmap_2d/test/obstacle_tests.cpp
+    g = GpuLayered(nav, orc, 10, static=ten_by_ten)
+    g.add_observation([[0.0, 0.0, MAX_Z / 2]], origin=(0, 0, MAX_Z / 2))
+    assert count(g.update(), LETHAL) == 21
+    g = GpuLayered(nav, orc, 10, static=ten_by_ten)
+    assert count(g.update(), LETHAL) == 20
+    g.add_observation([[9.5, 9.5, MAX_Z / 2]], origin=(0.5, 0.5, MAX_Z / 2))
+    assert count(g.update(), LETHAL) == 21
+    layer = g.o.layer(2)
+    for i in range(10):
+        layer[i, i] = LETHAL
+    g.o.set_layer(layer, 2)
+    g.fl.upload(g.N.GRID_OBSTACLE, layer)
+    m = g.update()
+    assert count(m, LETHAL) == 21 and count(m, FREE) == 79
+    g = GpuLayered(nav, orc, 10, track_unknown=True)
+    for p in (3.0, 5.0, 7.0):
+        g.add_observation([[p, p, MAX_Z]])
+    m = g.update()
+    assert count(m, LETHAL) == 3 and count(m, NOINFO) == 92 and count(m, FREE) == 5
+    g = GpuLayered(nav, orc, 10, track_unknown=True)
+    g.add_observation([[0.0, 5.0, 0.4]])
+    g.add_observation([[1.0, 5.0, 2.2]])
+    assert count(g.update(), LETHAL) == 1
+
+
+def test_reference_inflation_scenarios(nav, orc, ten_by_ten):  # costmap_2d/test/inflation_tests.cpp
+    g = GpuLayered(nav, orc, 10, static=ten_by_ten, inflation=(1.0, 1.0), polygon=_radii(1, 1))
+    m = g.update()
+    assert count(m, LETHAL) == 20 and count(m, INSCRIBED) == 28
+    g.add_observation([[0, 0, 0.4]])
+    m = g.update()
+    assert count(m, LETHAL) + count(m, INSCRIBED) == 51
+    g.add_observation([[2, 0, 0.0]])
+    m = g.update()
+    assert count(m, LETHAL) + count(m, INSCRIBED) == 54
+    g.add_observation([[1, 9, 0.0]])
+    m = g.update()
+    assert m[9, 1] == LETHAL and m[9, 0] == INSCRIBED and m[9, 2] == INSCRIBED
+    g.add_observation([[0, 9, 0.0]])
+    assert g.update()[9, 0] == LETHAL
+    g = GpuLayered(nav, orc, 10, inflation=(3.0, 1.0), polygon=_radii(1, 1.75))
+    g.add_observation([[5, 5, MAX_Z]])
+    for _ in range(2):
+        m = g.update()
+        assert count(m, FREE, False) == 29 and count(m, LETHAL) == 1 and count(m, INSCRIBED) == 4
+    g = GpuLayered(nav, orc, 10, inflation=(4.1, 1.0), polygon=_radii(2.1, 2.3))
+    g.add_observation([[0, 0, MAX_Z]])
+    m = g.update()
+    assert m[0, 0] == LETHAL and m[0, 1] == INSCRIBED and m[0, 2] == INSCRIBED and m[0, 3] < INSCRIBED and m[1, 1] == INSCRIBED
+
+
+def test_costmap_cycles_synthetic_fleet(nav, orc):
+    """Several update cycles of a small fleet on 400x400 maps with LaserScan clouds: master grid,
+    obstacle layer and update box bit-exact vs the oracle every cycle."""
+    from navigation_amd import synth
+    N = L(nav)
+    n, nI = 400, 3
+    insts = [synth.make_instance(n, i) for i in range(nI)]
+    insc = synth.inscribed_radius(synth.FOOTPRINT)
+    fl = nav.Fleet(nI, n, n, synth.RES, layers=N.LAYER_STATIC | N.LAYER_OBSTACLE | N.LAYER_INFLATION, max_points=720,
+                   max_observations=2)
+    fl.configure_obstacle()
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, insc)
+    oracles = []
+    for i, ins in enumerate(insts):
+        occ = np.where(ins["cells"] == 254, 100, 0).astype(np.int8)
+        fl.add_static_map(occ, first=i, count=1)
+        o = orc.LayeredCostmap(False)
+        o.set_footprint(synth.FOOTPRINT)
+        o.add_static(occ, res=synth.RES)
+        o.add_obstacle()
+        o.add_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, exact=True)
+        o.set_footprint(synth.FOOTPRINT)
+        oracles.append(o)
+    for cyc in range(3):
+        obs, poses = [], []
+        for i, ins in enumerate(insts):
+            pts = synth.laser_scan(ins, cyc)
+            org = (float(ins["pos"][0]), float(ins["pos"][1]), 0.3)
+            obs.append(dict(instance=i, points=pts, origin=org, obstacle_range=2.5, raytrace_range=3.0))
+            poses.append([float(v) for v in ins["pos"]])
+            oracles[i].clear_observations()
+            oracles[i].add_observation(pts, origin=org, obstacle_range=2.5, raytrace_range=3.0)
+            oracles[i].update_map(*poses[-1])
+        fl.stage_observations(poses, obs)
+        fl.update_map()
+        m = fl.master()
+        ol = fl.download(N.GRID_OBSTACLE)
+        b = fl.bounds()
+        for i in range(nI):
+            assert np.array_equal(b[i], oracles[i].bounds()), (cyc, i, b[i], oracles[i].bounds())
+            assert np.array_equal(ol[i], oracles[i].layer(2)), (cyc, i)
+            assert np.array_equal(m[i], oracles[i].master()), (cyc, i)
+    fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# planner: MapGrid wavefronts, per-sample costs, selection, oscillation
+# ----------------------------------------------------------------------------------------------
+def _inflated_instance(orc, n, idx, synth):
+    ins = synth.make_instance(n, idx)
+    insc = synth.inscribed_radius(synth.FOOTPRINT)
+    ins["master"] = orc.inflate(ins["cells"], synth.RES, synth.INFLATION_RADIUS, synth.COST_SCALING, insc, exact=True)
+    return ins
+
+
+def _check_planner(nav, orc, n, cfg_kw, n_inst=2, footprint=None, allow_unknown=1, unknown_frac=0.0, cycles=1, seed0=0):
+    from navigation_amd import synth
+    N = L(nav)
+    fp = synth.FOOTPRINT if footprint is None else footprint
+    cfg = nav.DwaConfig(allow_unknown=allow_unknown, **cfg_kw)
+    ocfg = orc.DwaConfig(**cfg.as_dict())
+    fl = nav.Fleet(n_inst, n, n, synth.RES, layers=N.LAYER_OBSTACLE, keep_sample_costs=True, max_sim_steps=128, max_plan=256)
+    fl.configure_planner(cfg)
+    fl.set_footprint(fp)
+    insts = [_inflated_instance(orc, n, seed0 + i, synth) for i in range(n_inst)]
+    rs = np.random.RandomState(99)
+    for ins in insts:
+        if unknown_frac:
+            m = ins["master"]
+            m[(rs.random_sample(m.shape) < unknown_frac) & (m == 0)] = NOINFO
+    fl.upload(N.GRID_MASTER, np.stack([i["master"] for i in insts]))
+    planners = [orc.DwaPlanner(i["master"], synth.RES, 0.0, 0.0, ocfg) for i in insts]
+    fl.set_plan()
+    for p in planners:
+        p.set_plan()
+    for cyc in range(cycles):
+        pos = np.stack([i["pos"] for i in insts]).copy()
+        vel = np.stack([i["vel"] for i in insts]).copy()
+        if cyc:
+            pos[:, 0] += 0.03 * cyc
+            pos[:, 2] += 0.4 * cyc
+            vel[:, 2] = -vel[:, 2]
+        plans = np.stack([i["plan"] for i in insts])
+        res = fl.find_best_path(pos, vel, plans)
+        for k, ins in enumerate(insts):
+            ores, otraj, cref, cfull, ostatus = planners[k].cycle(pos[k], vel[k], ins["plan"], fp)
+            # MapGrid grids, bit-exact
+            for gid, which in ((N.GRID_PATH, 0), (N.GRID_GOAL, 1), (N.GRID_GOAL_FRONT, 2)):
+                g = fl.download(gid, k, 1)[0]
+                og = planners[k].grid(which)
+                assert np.array_equal(g.astype(np.float64), og), f"MapGrid {which} differs (inst {k}, cycle {cyc})"
+            cost, status, vels = fl.samples(k)
+            assert len(cost) == ores.n_samples == res[k].n_samples
+            assert np.array_equal(status, ostatus), "generator accept/reject mask differs"
+            scored = status == 1
+            # footprint-collision / failure-code mask bit-exact, costs within 1e-5
+            neg_o, neg_g = cfull[scored] < 0, cost[scored] < 0
+            assert np.array_equal(neg_o, neg_g), "valid/invalid mask differs"
+            assert np.array_equal(cfull[scored][neg_o], cost[scored][neg_g]), "failure codes differ"
+            assert np.allclose(cost[scored][~neg_g], cfull[scored][~neg_o], rtol=0, atol=1e-5)
+            r = res[k]
+            assert r.best_index == ores.best_index, (r.best_index, ores.best_index)
+            assert r.n_scored == ores.n_scored and r.n_valid == ores.n_valid
+            assert abs(r.cost - ores.cost) <= 1e-5
+            assert r.oscillation_flags == ores.oscillation_flags
+            if r.best_index >= 0:
+                assert (r.xv, r.yv, r.thetav) == (ores.xv, ores.yv, ores.thetav)
+                assert list(r.drive) == list(ores.drive)
+                t = fl.trajectory(k)
+                assert t.shape == otraj.shape and np.allclose(t, otraj, rtol=0, atol=1e-6)
+    fl.close()
+    return res
+
+
+def test_planner_config1_shape(nav, orc):
+    # BASELINE config 1 shape: 200x200, 10x10x5 samples, 10 steps
+    _check_planner(nav, orc, 200, dict(vx_samples=10, vy_samples=10, vth_samples=5, sim_time=1.0, sim_granularity=0.1,
+                                       discretize_by_time=1), n_inst=3, cycles=3)
+
+
+def test_planner_config2_shape(nav, orc):
+    # BASELINE config 2 shape: 400x400, 32x32x16 samples, 20 steps
+    res = _check_planner(nav, orc, 400, dict(vx_samples=32, vy_samples=32, vth_samples=16, sim_time=2.0, sim_granularity=0.1,
+                                             discretize_by_time=1), n_inst=2)
+    assert res[0].n_samples > 16384
+
+
+def test_planner_reference_defaults_variable_steps(nav, orc):
+    # the reference's own defaults: discretize_by_time = false -> per-sample step counts (up to 38)
+    _check_planner(nav, orc, 200, dict(), n_inst=2, cycles=2)
+
+
+def test_planner_unknown_cells_and_polygon5(nav, orc):
+    from navigation_amd import synth
+    for au in (0, 1):
+        _check_planner(nav, orc, 200, dict(vx_samples=8, vy_samples=6, vth_samples=9, sim_time=1.5, sim_granularity=0.1,
+                                           discretize_by_time=1), n_inst=2, footprint=synth.FOOTPRINT5, allow_unknown=au,
+                       unknown_frac=0.01, seed0=10)
+
+
+def test_planner_sum_scores_and_zero_scales(nav, orc):
+    _check_planner(nav, orc, 160, dict(vx_samples=6, vy_samples=5, vth_samples=7, sim_time=1.2, sim_granularity=0.1,
+                                       discretize_by_time=1, sum_scores=1, occdist_scale=0.02), n_inst=2, seed0=20)
+    _check_planner(nav, orc, 160, dict(vx_samples=6, vy_samples=5, vth_samples=7, sim_time=1.2, sim_granularity=0.1,
+                                       discretize_by_time=1, occdist_scale=0.0, forward_point_distance=0.0), n_inst=2, seed0=22)
+
+
+def test_planner_oscillation_flags_persist(nav, orc):
+    from navigation_amd import synth
+    N = L(nav)
+    n = 160
+    cfg = nav.DwaConfig(vx_samples=6, vy_samples=6, vth_samples=8, sim_time=1.0, sim_granularity=0.1, discretize_by_time=1,
+                        min_vel_x=-0.3)
+    ocfg = orc.DwaConfig(**cfg.as_dict())
+    ins = _inflated_instance(orc, n, 3, synth)
+    fl = nav.Fleet(1, n, n, synth.RES, layers=N.LAYER_OBSTACLE, keep_sample_costs=True)
+    fl.configure_planner(cfg)
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.upload(N.GRID_MASTER, ins["master"])
+    p = orc.DwaPlanner(ins["master"], synth.RES, 0.0, 0.0, ocfg)
+    # force every combination of sticky flags through both implementations
+    for flags in (0, 1 << 8, 1 << 9, (1 << 4) | (1 << 10), (1 << 5) | (1 << 0), (1 << 1) | (1 << 11), 0xFFF):
+        prev = np.array([ins["pos"][0] - 0.01, ins["pos"][1], ins["pos"][2]], np.float32)
+        fl.set_oscillation([flags], [prev])
+        p.set_oscillation(flags, prev)
+        r = fl.find_best_path([ins["pos"]], [ins["vel"]], [ins["plan"]])[0]
+        o, _, _, cfull, st = p.cycle(ins["pos"], ins["vel"], ins["plan"], synth.FOOTPRINT)
+        cost, status, _ = fl.samples(0)
+        assert np.array_equal(cost[status == 1] < 0, cfull[st == 1] < 0)
+        assert r.best_index == o.best_index and r.oscillation_flags == o.oscillation_flags
+        gf, gp = fl.oscillation()
+        of, op = p.oscillation()
+        assert gf[0] == of and np.array_equal(gp[0], op)
+    fl.close()
+
+
+def test_planner_check_trajectory(nav, orc):
+    from navigation_amd import synth
+    N = L(nav)
+    n = 160
+    cfg = nav.DwaConfig(vx_samples=6, vy_samples=6, vth_samples=8, sim_time=1.0, sim_granularity=0.1, discretize_by_time=1)
+    ocfg = orc.DwaConfig(**cfg.as_dict())
+    ins = _inflated_instance(orc, n, 4, synth)
+    # a wall right in front of the robot so some samples collide
+    m = ins["master"]
+    cx = int(ins["pos"][0] / synth.RES)
+    m[:, cx + 12] = LETHAL
+    fl = nav.Fleet(1, n, n, synth.RES, layers=N.LAYER_OBSTACLE)
+    fl.configure_planner(cfg)
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.upload(N.GRID_MASTER, m)
+    p = orc.DwaPlanner(m, synth.RES, 0.0, 0.0, ocfg)
+    pos = ins["pos"].copy()
+    pos[2] = 0.0
+    fl.find_best_path([pos], [ins["vel"]], [ins["plan"]])
+    p.cycle(pos, ins["vel"], ins["plan"], synth.FOOTPRINT)
+    for vs in ([0.5, 0.0, 0.0], [0.1, 0.0, 0.5], [0.0, 0.0, 0.0], [0.3, 0.1, -0.4], [0.55, 0.0, 0.0]):
+        assert fl.check_trajectory(0, vs) == p.check_trajectory(pos, ins["vel"], vs), vs
+    fl.close()
+
+
+def test_fleet_batch_equals_single(nav, orc):
+    """Instances are independent: a batched launch gives each robot what a fleet of one gives it."""
+    from navigation_amd import synth
+    N = L(nav)
+    n, nI = 200, 5
+    cfg = nav.DwaConfig(vx_samples=10, vy_samples=10, vth_samples=5, sim_time=1.0, sim_granularity=0.1, discretize_by_time=1)
+    insts = [_inflated_instance(orc, n, 30 + i, synth) for i in range(nI)]
+    big = nav.Fleet(nI, n, n, synth.RES, layers=N.LAYER_OBSTACLE)
+    big.configure_planner(cfg)
+    big.set_footprint(synth.FOOTPRINT)
+    big.upload(N.GRID_MASTER, np.stack([i["master"] for i in insts]))
+    rb = big.find_best_path(np.stack([i["pos"] for i in insts]), np.stack([i["vel"] for i in insts]),
+                            np.stack([i["plan"] for i in insts]))
+    for k, ins in enumerate(insts):
+        one = nav.Fleet(1, n, n, synth.RES, layers=N.LAYER_OBSTACLE)
+        one.configure_planner(cfg)
+        one.set_footprint(synth.FOOTPRINT)
+        one.upload(N.GRID_MASTER, ins["master"])
+        r1 = one.find_best_path([ins["pos"]], [ins["vel"]], [ins["plan"]])[0]
+        assert (r1.best_index, r1.cost, r1.n_valid) == (rb[k].best_index, rb[k].cost, rb[k].n_valid)
+        one.close()
+    big.close()
+
+
+def test_full_size_properties(nav):
+    """BASELINE config-3 scale (64 instances here to bound memory/time): size-independent
+    properties — inflation is idempotent, never lowers a cell, never creates unknowns; the planner
+    returns a valid winner whose cost is the minimum of all sample costs."""
+    from navigation_amd import synth
+    N = L(nav)
+    n, nI = 400, 64
+    fl = nav.Fleet(nI, n, n, synth.RES, layers=N.LAYER_OBSTACLE | N.LAYER_INFLATION, keep_sample_costs=True)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, synth.inscribed_radius(synth.FOOTPRINT))
+    fl.set_footprint(synth.FOOTPRINT)
+    cfg = synth.fleet_config()
+    fl.configure_planner(cfg)
+    insts = [synth.make_instance(n, i) for i in range(nI)]
+    maps = np.stack([i["cells"] for i in insts])
+    fl.upload(N.GRID_MASTER, maps)
+    fl.inflate(boxes=[[0, 0, n, n]] * nI)
+    a = fl.master()
+    assert (a >= maps).all() and (a != NOINFO).all() and ((a == LETHAL) == (maps == LETHAL)).all()
+    fl.inflate(boxes=[[0, 0, n, n]] * nI)
+    assert np.array_equal(fl.master(), a), "inflation is not idempotent"
+    res = fl.find_best_path(np.stack([i["pos"] for i in insts]), np.stack([i["vel"] for i in insts]),
+                            np.stack([i["plan"] for i in insts]))
+    for k in (0, 17, 63):
+        cost, status, _ = fl.samples(k)
+        ok = (status == 1) & (cost >= 0)
+        assert res[k].n_valid == ok.sum() and res[k].n_scored == (status == 1).sum()
+        assert res[k].best_index == int(np.flatnonzero(ok)[np.argmin(cost[ok])])
+        assert res[k].cost == cost[ok].min()
+    fl.close()
