@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py — fleet throughput of the MI355X-native costmap + DWA hot path.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 launched by torch.distributed.run,
+one rank per GPU).  One *step* = one pass of the hot path over one batch: for every robot
+instance of the rank's fleet a LayeredCostmap::updateMap (LaserScan clearing + marking + merge +
+inflation) followed by a DWAPlanner::findBestPath (3 MapGrid wavefronts + rollout + six critics +
+selection).  Inputs are staged in HBM before the timed region.
+
+Workload (config.workload): BASELINE.json's metric is a whole-node throughput, quoted on the
+fleet configurations; configs[3] (2048 instances over 8 GPUs) does not fit one GPU, so at N=1 the
+workload is the largest single-GPU configuration, configs[2]: 256 batched robot instances on one
+MI355X, 400x400 costmaps, 32x32x16 samples, 20 sim steps, LaserScan update each cycle.  At N GPUs
+every rank runs the same 256 instances (weak scaling; N=8 is configs[3]).  The single-robot
+configs[1] latency is reported beside it in "single_robot".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+T_STEPS, P_PERIM, G_GRIDS = 20, 32, 4
+BYTES_PER_TRAJ = 20 + T_STEPS * (P_PERIM + 1) + T_STEPS * G_GRIDS * 4  # = 1000 B
+BYTES_PER_BFS_CELL = 5       # 1 B costmap read + 4 B distance write, per grid
+BYTES_PER_INFL_CELL = 2
+BYTES_PER_MERGE_CELL = 3
+
+
+def build_fleet(nav, n_inst, n_cells, seed0, device=0, vs=(32, 32, 16)):
+    from navigation_amd import _lib as N, synth
+    fl = nav.Fleet(n_inst, n_cells, n_cells, synth.RES, layers=N.LAYER_STATIC | N.LAYER_OBSTACLE | N.LAYER_INFLATION,
+                   max_points=720, max_observations=1, max_plan=200, max_footprint=8, max_sim_steps=24, device=device)
+    fl.configure_obstacle()
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, synth.inscribed_radius(synth.FOOTPRINT))
+    cfg = synth.fleet_config(*vs)
+    fl.configure_planner(cfg)
+    insts = [synth.make_instance(n_cells, seed0 + i) for i in range(n_inst)]
+    for i, ins in enumerate(insts):
+        fl.add_static_map(np.where(ins["cells"] == 254, 100, 0).astype(np.int8), first=i, count=1)
+    poses = np.array([[float(v) for v in ins["pos"]] for ins in insts])
+    obs = []
+    for i, ins in enumerate(insts):
+        pts = synth.laser_scan(ins, 0)
+        obs.append(dict(instance=i, points=pts, origin=(float(ins["pos"][0]), float(ins["pos"][1]), 0.3),
+                        obstacle_range=2.5, raytrace_range=3.0))
+    fl.stage_observations(poses, obs)
+    fl.stage_planner(np.stack([i["pos"] for i in insts]), np.stack([i["vel"] for i in insts]),
+                     np.stack([i["plan"] for i in insts]))
+    fl.set_plan()
+    return fl, insts, cfg
+
+
+def step(fl):
+    fl.update_map()
+    fl.planner_cycle()
+
+
+def cpu_baseline(insts_sample, cfg, n_cells, masters):
+    """Oracle ("port") timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import pyoracle as orc
+    from navigation_amd import synth
+    L = orc.lib()
+    cores = min(os.cpu_count() or 1, 16)
+    n_inst = len(insts_sample)
+    ocfg = orc.DwaConfig(**cfg.as_dict())
+    pos = np.ascontiguousarray(np.stack([i["pos"] for i in insts_sample]), np.float32)
+    vel = np.ascontiguousarray(np.stack([i["vel"] for i in insts_sample]), np.float32)
+    plans = np.ascontiguousarray(np.stack([i["plan"] for i in insts_sample]), np.float64)
+    origins = np.zeros((n_inst, 2))
+    cells = np.ascontiguousarray(masters, np.uint8)
+    fp = np.ascontiguousarray(synth.FOOTPRINT, np.float64)
+    cycles = 2
+    scored = C.c_uint64()
+    dt = L.orc_bench_dwa(n_cells, n_cells, synth.RES, cells, n_inst, C.byref(ocfg), pos, vel, plans, plans.shape[1], origins, fp,
+                         len(fp), cycles, cores, C.byref(scored))
+    raw = np.ascontiguousarray(np.stack([i["cells"] for i in insts_sample]), np.uint8)
+    reps = 2
+    dti = L.orc_bench_inflate(raw, n_inst, n_cells, n_cells, synth.RES, synth.INFLATION_RADIUS, synth.COST_SCALING,
+                              synth.inscribed_radius(synth.FOOTPRINT), reps, cores)
+    return dict(value=scored.value / dt, unit="trajectories/s", cores=cores, kind="port",
+                sample=f"{n_inst} instances x {cycles} planner cycles (4 MapGrid BFS + rollout + 6 critics, reference early-out), "
+                       f"one instance per thread",
+                inflation_cells_per_s=n_inst * reps * n_cells * n_cells / dti,
+                inflation_sample=f"{n_inst} full-window 400x400 InflationLayer::updateCosts (reference PQ walk) x {reps}",
+                seconds=round(dt + dti, 2))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--instances", type=int, default=256, help="robot instances per GPU")
+    ap.add_argument("--size", type=int, default=400, help="costmap cells per side")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    import navigation_amd as nav
+    from navigation_amd import _lib as N, synth
+
+    nav.lib()  # fails loudly if the HIP extension is missing
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    n_inst, n_cells = args.instances, args.size
+    fl, insts, cfg = build_fleet(nav, n_inst, n_cells, seed0=rank * n_inst, device=local_rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(fl)
+    fl.sync()
+    fl.profile(True)
+    fl.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(fl)
+    fl.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = fl.profile_read()
+    fl.profile(False)
+
+    res = fl.results()
+    scored = sum(r.n_scored for r in res)
+    boxes = fl.bounds()
+    win_cells = int(((boxes[:, 1] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 2])).sum())
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    cnt = torch.tensor([float(scored), float(win_cells)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)  # the only collective: throughput counters over RCCL
+    elapsed_max = float(el.item())
+    total_scored, total_win = float(cnt[0].item()), float(cnt[1].item())
+
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed_max / args.steps * 1e3
+        traj_per_s = total_scored * args.steps / elapsed_max
+        # dominant kernel by HIP-event time over the timed region
+        dom = max(prof, key=lambda k: prof[k][0])
+        avg_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}
+        alg_bytes = {
+            "k_score": BYTES_PER_TRAJ * scored,
+            "k_bfs": BYTES_PER_BFS_CELL * 3 * n_cells * n_cells * n_inst,
+            "k_inflate": BYTES_PER_INFL_CELL * win_cells / world,
+            "k_merge": BYTES_PER_MERGE_CELL * win_cells / world,
+            "k_obstacle": 0.0, "k_select": 0.0,
+        }
+        achieved = alg_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
+        out = {
+            "metric": "scored trajectories/sec (whole node) + costmap inflation cells/sec, 400x400 map",
+            "value": traj_per_s, "unit": "trajectories/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"configs[2]: {n_inst} batched robot instances per MI355X, {n_cells}x{n_cells} costmaps "
+                                   f"+ inflation, 32x32x16 velocity samples, 20 sim steps, LaserScan (720 beams) update "
+                                   f"each cycle; N GPUs = N x {n_inst} instances (N=8 is configs[3])",
+                       "instances_per_gpu": n_inst, "costmap": f"{n_cells}x{n_cells}@0.05", "vsamples": "32x32x16",
+                       "sim_steps": T_STEPS, "critics": "oscillation+obstacle+goal_front+alignment+path+goal",
+                       "parallelism": f"fleet-shard x{world}"},
+            "per_instance_trajectories_per_s": traj_per_s / (n_inst * world),
+            "inflation_cells_per_s": total_win * args.steps / elapsed_max,
+            "inflation_window_cells_per_step": total_win,
+            "trajectories_per_step": total_scored,
+            "kernel_ms": {k: round(avg_ms[k], 4) for k in avg_ms},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": avg_ms[dom],
+                         "frac_vs_measured_copy_peak_6290": achieved / 6290.0},
+        }
+    # ---- extra legs on rank 0 at N=1 only
+    if rank == 0 and world == 1:
+        # full-window inflation throughput (the BASELINE.md probe shape)
+        raw = np.stack([i["cells"] for i in insts])
+        fl.upload(N.GRID_MASTER, raw)
+        full = [[0, 0, n_cells, n_cells]] * n_inst
+        fl.inflate(boxes=full)
+        fl.sync()
+        fl.profile(True)
+        fl.profile_reset()
+        reps = 10
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            fl.inflate(boxes=full)
+        fl.sync()
+        dt = time.perf_counter() - t1
+        pk = fl.profile_read()["k_inflate"]
+        fl.profile(False)
+        out["inflation_full_window"] = {"cells_per_s": reps * n_inst * n_cells * n_cells / dt,
+                                        "kernel_ms": pk[0] / max(pk[1], 1),
+                                        "achieved_GBps": BYTES_PER_INFL_CELL * n_inst * n_cells * n_cells / (pk[0] / max(pk[1], 1) * 1e-3) / 1e9}
+        masters = fl.master(0, min(n_inst, 32))
+        if not args.no_single:
+            f1, i1, c1 = build_fleet(nav, 1, n_cells, seed0=0, device=local_rank)
+            for _ in range(3):
+                step(f1)
+            f1.sync()
+            t1 = time.perf_counter()
+            k1 = 50
+            for _ in range(k1):
+                step(f1)
+            f1.sync()
+            d1 = time.perf_counter() - t1
+            r1 = f1.results()[0]
+            out["single_robot"] = {"workload": "configs[1]: one robot, 400x400 + inflation, 32x32x16, 20 steps",
+                                   "ms_per_cycle": d1 / k1 * 1e3, "trajectories_per_s": r1.n_scored * k1 / d1,
+                                   "n_scored": r1.n_scored}
+            f1.close()
+        if not args.no_cpu_baseline:
+            ns = min(n_inst, 32)
+            out["cpu_baseline"] = cpu_baseline(insts[:ns], cfg, n_cells, masters[:ns])
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    fl.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

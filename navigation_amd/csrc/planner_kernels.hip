@@ -447,6 +447,12 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
       if (num_steps <= 0) reject = true;  // `return num_steps > 0` (:250)
       if (num_steps > (int)pl.max_sim_steps) num_steps = (int)pl.max_sim_steps;  // host validates the capacity
     }
+    // DWAPlanner::checkTrajectory ignores generateTrajectory's return value and scores whatever
+    // points exist (dwa_planner.cpp:229-230): a rejected sample is an empty trajectory, cost 0.
+    if (EXPLICIT && reject) {
+      reject = false;
+      num_steps = 0;
+    }
     if (!reject) {
       status = NAVGPU_SAMPLE_SCORED;
       const double dt = c.sim_time / num_steps;
