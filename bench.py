@@ -152,13 +152,9 @@ def main():
     boxes = fl.bounds()
     win_cells = int(((boxes[:, 1] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 2])).sum())
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    cnt = torch.tensor([float(scored), float(win_cells)], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)  # the only collective: throughput counters over RCCL
-    elapsed_max = float(el.item())
-    total_scored, total_win = float(cnt[0].item()), float(cnt[1].item())
+    # the only collective: throughput counters over RCCL (navigation_amd/sharding.py, gloo-tested on CPU)
+    from navigation_amd.sharding import reduce_counters
+    elapsed_max, (total_scored, total_win) = reduce_counters(dist, elapsed, [scored, win_cells], device="cuda")
 
     out = None
     if rank == 0:
