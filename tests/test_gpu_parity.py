@@ -454,3 +454,56 @@ def test_full_size_properties(nav):
         assert res[k].best_index == int(np.flatnonzero(ok)[np.argmin(cost[ok])])
         assert res[k].cost == cost[ok].min()
     fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# voxel layer: 3-D marking + 3-D raytrace clearing
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("track_unknown,z_voxels,unknown_thr", [(False, 10, 15), (True, 10, 15), (True, 16, 0), (True, 8, 5)])
+def test_voxel_layer_cycles(nav, orc, track_unknown, z_voxels, unknown_thr):
+    from navigation_amd import synth
+    N = L(nav)
+    n, nI = 200, 2
+    insts = [synth.make_instance(n, 50 + i) for i in range(nI)]
+    insc = synth.inscribed_radius(synth.FOOTPRINT5)
+    fl = nav.Fleet(nI, n, n, synth.RES, layers=N.LAYER_VOXEL | N.LAYER_INFLATION, track_unknown=track_unknown,
+                   max_points=1440, max_observations=2)
+    fl.configure_obstacle(z_voxels=z_voxels, origin_z=0.0, z_resolution=0.2, unknown_threshold=unknown_thr, mark_threshold=0,
+                          max_obstacle_height=2.0)
+    fl.set_footprint(synth.FOOTPRINT5)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, insc)
+    oracles = []
+    for ins in insts:
+        o = orc.LayeredCostmap(track_unknown)
+        o.resize(n, n, synth.RES, 0, 0)
+        o.set_footprint(synth.FOOTPRINT5)
+        o.add_voxel(z_voxels=z_voxels, origin_z=0.0, z_resolution=0.2, unknown_threshold=unknown_thr, mark_threshold=0,
+                    max_obstacle_height=2.0)
+        o.add_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, exact=True)
+        o.set_footprint(synth.FOOTPRINT5)
+        oracles.append(o)
+    for cyc in range(4):
+        obs, poses = [], []
+        for i, ins in enumerate(insts):
+            pts = synth.laser_scan(ins, cyc, z=0.3, z_jitter=1.5)
+            if cyc == 2:  # some points above max_obstacle_height / below the floor
+                pts[::7, 2] = 2.4
+                pts[3::11, 2] = -0.2
+            org = (float(ins["pos"][0]), float(ins["pos"][1]), 0.3 + 0.25 * cyc)
+            obs.append(dict(instance=i, points=pts, origin=org, obstacle_range=2.5, raytrace_range=3.0))
+            poses.append([float(v) for v in ins["pos"]])
+            oracles[i].clear_observations()
+            oracles[i].add_observation(pts, origin=org, obstacle_range=2.5, raytrace_range=3.0)
+            oracles[i].update_map(*poses[-1])
+        fl.stage_observations(poses, obs)
+        fl.update_map()
+        vox = fl.download(N.GRID_VOXEL)
+        ol = fl.download(N.GRID_OBSTACLE)
+        m = fl.master()
+        b = fl.bounds()
+        for i in range(nI):
+            assert np.array_equal(vox[i], oracles[i].voxels()), ("voxel columns", cyc, i)
+            assert np.array_equal(ol[i], oracles[i].layer(2)), ("voxel layer 2-D grid", cyc, i)
+            assert np.array_equal(b[i], oracles[i].bounds()), ("box", cyc, i)
+            assert np.array_equal(m[i], oracles[i].master()), ("master", cyc, i)
+    fl.close()
