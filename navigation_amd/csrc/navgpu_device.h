@@ -66,7 +66,7 @@ struct CostmapDev {
 
 struct PlannerDev {
   uint32_t nx, ny, cells;
-  double res;
+  double res, inv_res;
   double* origin;  // [n][2] (shared with the costmap)
   const uint8_t* master;
   uint32_t cells_padded;
@@ -114,6 +114,7 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
 void launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s);
 void launch_select(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
 size_t bfs_lds_bytes(uint32_t nx, uint32_t ny);
+bool bfs_supported(uint32_t nx, uint32_t ny);
 
 // ---- device helpers ---------------------------------------------------------------------------
 struct Geom {

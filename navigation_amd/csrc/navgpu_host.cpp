@@ -168,9 +168,8 @@ const char* navgpu_kernel_name(int32_t k) {
 int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   if (!d || !out || d->n_instances == 0 || d->size_x == 0 || d->size_y == 0 || !(d->resolution > 0)) return NAVGPU_ERR_INVALID;
   if (d->max_footprint > (uint32_t)kMaxFootprint) return NAVGPU_ERR_CAPACITY;
-  if ((uint64_t)d->size_x * d->size_y > (1ull << 30)) return NAVGPU_ERR_CAPACITY;
-  const uint32_t words = d->size_y * ((d->size_x + 31) / 32);
-  if (words > 20u * 1024u || bfs_lds_bytes(d->size_x, d->size_y) > 160u * 1024u - 4096u) {
+  if ((uint64_t)d->size_x * d->size_y > (1ull << 30) || d->size_x > 65535 || d->size_y > 65535) return NAVGPU_ERR_CAPACITY;
+  if (!bfs_supported(d->size_x, d->size_y)) {
     g_last_error = "grid too large for the LDS-resident wavefront kernel";
     return NAVGPU_ERR_CAPACITY;
   }
@@ -241,6 +240,7 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   pl.cells = cm.cells;
   pl.cells_padded = cm.cells_padded;
   pl.res = cm.res;
+  pl.inv_res = 1.0 / cm.res;
   pl.origin = cm.origin;
   pl.master = cm.master;
   pl.max_plan = f->desc.max_plan;

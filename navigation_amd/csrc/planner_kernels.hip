@@ -159,44 +159,98 @@ __device__ __forceinline__ uint32_t adjustedPoints(const double* P, uint32_t i, 
   return cnt + 1;
 }
 
-template <int WPT>
+// Thread -> bitmap mapping: the grid has W = ceil(nx/32) word columns; thread t owns the vertical
+// strip of RPT rows [r0, r0+RPT) in word column wi (t = strip*W + wi).  Its `free`, `visited` and
+// current-frontier words stay in registers; only the left/right words and the rows just above and
+// below the strip are read from the LDS copy of the frontier (2*RPT+2 reads instead of 5*RPT).
+// Distances are not scattered cell by cell inside the level loop (divergent bit loops and one store
+// instruction per new cell were the bulk of a level's cost): each owned word carries kPlanes
+// bit-sliced level planes in registers, `plane[b] |= newly_visited` when bit b of the level is set,
+// and the 32 distances of a word are decoded and stored once, 16 bytes at a time, after the loop.
+// Levels >= 2^kPlanes (corridor mazes) fall back to direct stores and a `late` bitmap in LDS.
+// Measured on MI355X (tools/microbench/lds_latency.hip): barrier 64 clk, dependent LDS read ~90 clk,
+// returning LDS atomics ~1 lane/clk/CU — hence no atomics anywhere in the level loop.
+constexpr int kPlanes = 10;
+template <int RPT>
 __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
   extern __shared__ __align__(16) uint32_t sm[];
   __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_flag[3];
   const int which = blockIdx.x;
   const uint32_t inst = first + blockIdx.y;
   const uint32_t tid = threadIdx.x;
   const Geom g = geomOf(pl, inst);
   const uint32_t nx = pl.nx, ny = pl.ny, W = (nx + 31) >> 5, words = ny * W;
+  // frontier bitmaps are padded with a zero border (one word left/right, one row above/below, rows
+  // rounded up to whole strips) so that every neighbour read and every store is unconditional
+  const uint32_t strips = (ny + RPT - 1) / RPT;
+  const uint32_t Wp = W + 2, padded = (strips * RPT + 2) * Wp;
   uint32_t* cur = sm;
-  uint32_t* nxt = sm + words;
+  uint32_t* nxt = sm + padded;
+  uint32_t* late = sm + 2 * padded;  // [words] cells reached at level >= 2^kPlanes (stored directly)
   const uint8_t* master = pl.master + (size_t)inst * pl.cells_padded;
   uint32_t* dist = (which == 0 ? pl.path : (which == 1 ? pl.goal : pl.goal_front)) + (size_t)inst * pl.cells;
   const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
-  const bool allow_unknown = pl.cfg.allow_unknown != 0;
+  const uint32_t unknown_is_obstacle = pl.cfg.allow_unknown != 0 ? 0u : 1u;
+  const bool owner = tid < strips * W;
+  const uint32_t wi = owner ? tid % W : 0, r0 = owner ? (tid / W) * RPT : 0;
+  const uint32_t last_mask = (nx & 31) ? ((1u << (nx & 31)) - 1u) : 0xFFFFFFFFu;
+  const uint32_t col_mask = (wi + 1 == W) ? last_mask : 0xFFFFFFFFu;
+  const bool aligned4 = (nx & 3) == 0;
 
-  // --- owned words: `free` bitmap from the costmap, frontiers cleared
-  uint32_t freeb[WPT], visited[WPT];
+  // --- owned words: `free` bitmap from the costmap (updatePathCell's obstacle test), frontiers cleared
+  uint32_t freeb[RPT], visited[RPT], fr[RPT];
 #pragma unroll
-  for (int s = 0; s < WPT; ++s) {
-    const uint32_t w = tid + s * 1024;
-    freeb[s] = 0;
-    visited[s] = 0;
-    if (w < words) {
-      const uint32_t row = w / W, wi = w - row * W;
-      const uint8_t* p = master + row * nx + wi * 32;
+  for (int k = 0; k < RPT; ++k) {
+    freeb[k] = 0;
+    visited[k] = 0xFFFFFFFFu;  // rows beyond the grid never take part
+    fr[k] = 0;
+    const uint32_t row = r0 + k;
+    if (owner) {
+      cur[(row + 1) * Wp + wi + 1] = 0;
+      nxt[(row + 1) * Wp + wi + 1] = 0;
+    }
+    if (owner && row < ny) {
       const uint32_t nb = min(32u, nx - wi * 32);
       uint32_t bits = 0;
-      for (uint32_t b = 0; b < nb; ++b) {
-        uint8_t cst = p[b];
-        bool obstacle = cst == kLethal || cst == kInscribed || (cst == kNoInfo && !allow_unknown);
-        bits |= (obstacle ? 0u : 1u) << b;
+      if (aligned4) {
+        const uint32_t* p4 = reinterpret_cast<const uint32_t*>(master + row * nx + wi * 32);
+        for (uint32_t q = 0; q < nb / 4; ++q) {
+          const uint32_t v = p4[q];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t cst = (v >> (8 * j)) & 0xFFu;
+            const bool obstacle = cst == kLethal || cst == kInscribed || (cst == kNoInfo && unknown_is_obstacle);
+            bits |= (obstacle ? 0u : 1u) << (4 * q + j);
+          }
+        }
+      } else {
+        const uint8_t* p = master + row * nx + wi * 32;
+        for (uint32_t b = 0; b < nb; ++b) {
+          const uint32_t cst = p[b];
+          const bool obstacle = cst == kLethal || cst == kInscribed || (cst == kNoInfo && unknown_is_obstacle);
+          bits |= (obstacle ? 0u : 1u) << b;
+        }
       }
-      freeb[s] = bits;
-      cur[w] = 0;
-      nxt[w] = 0;
+      freeb[k] = bits;
+      visited[k] = ~col_mask;  // bits past the last column count as visited
+      late[row * W + wi] = 0;
     }
   }
+  // zero border
+  for (uint32_t i = tid; i < Wp; i += blockDim.x) {
+    cur[i] = 0;
+    nxt[i] = 0;
+    cur[(strips * RPT + 1) * Wp + i] = 0;
+    nxt[(strips * RPT + 1) * Wp + i] = 0;
+  }
+  for (uint32_t i = tid; i < strips * RPT + 2; i += blockDim.x) {
+    cur[i * Wp] = 0;
+    nxt[i * Wp] = 0;
+    cur[i * Wp + Wp - 1] = 0;
+    nxt[i * Wp + Wp - 1] = 0;
+  }
+  if (tid < 3) s_flag[tid] = 0;
   __syncthreads();
 
   // --- seeds from the plan
@@ -244,68 +298,350 @@ __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
           uint32_t cell;
           if (!valid(x, y, cell)) return;  // cannot happen inside [f, e)
           const uint32_t my = cell / nx, mx = cell - my * nx;
+          atomicOr(&cur[(my + 1) * Wp + (mx >> 5) + 1], 1u << (mx & 31));  // a few hundred seeds, once
+        });
+    }
+  }
+  __syncthreads();
+  uint32_t plane[kPlanes][RPT];
+#pragma unroll
+  for (int b = 0; b < kPlanes; ++b)
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) plane[b][k] = 0;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const uint32_t row = r0 + k;
+    if (owner && row < ny) {
+      fr[k] = cur[(row + 1) * Wp + wi + 1];
+      visited[k] |= fr[k];  // seeds: level 0 == all planes clear
+    }
+  }
+
+  // --- level-synchronous expansion, ONE barrier per level (three rotating "anything new" flags)
+  const uint32_t base_w = r0 * W + wi;               // unpadded (late bitmap, dist rows)
+  const uint32_t base_p = (r0 + 1) * Wp + wi + 1;    // padded (frontier bitmaps)
+  uint32_t level = 0;
+  while (true) {
+    const uint32_t lvl1 = level + 1;  // distance of the cells reached in this round
+    uint32_t any = 0;
+    if (owner) {
+      const uint32_t top = cur[base_p - Wp];
+      const uint32_t bot = cur[base_p + RPT * Wp];
+      uint32_t lw[RPT], rw[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        lw[k] = cur[base_p + k * Wp - 1];
+        rw[k] = cur[base_p + k * Wp + 1];
+      }
+      uint32_t cand[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const uint32_t fc = fr[k];
+        const uint32_t u = k > 0 ? fr[k > 0 ? k - 1 : 0] : top;
+        const uint32_t d = k + 1 < RPT ? fr[k + 1 < RPT ? k + 1 : 0] : bot;
+        cand[k] = ((fc << 1) | (lw[k] >> 31) | (fc >> 1) | (rw[k] << 31) | u | d) & ~visited[k];
+      }
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const uint32_t nf = cand[k] & freeb[k];
+        visited[k] |= cand[k];
+        fr[k] = nf;
+        any |= nf;
+        nxt[base_p + k * Wp] = nf;
+      }
+      if (lvl1 < (1u << kPlanes)) {
+#pragma unroll
+        for (int b = 0; b < kPlanes; ++b) {
+          if (lvl1 & (1u << b)) {  // wave-uniform
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) plane[b][k] |= cand[k];
+          }
+        }
+      } else {  // rare: direct stores + remember which cells already hold their value
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          uint32_t q = cand[k];
+          if (q) {
+            late[base_w + k * W] |= q;
+            uint32_t* drow = dist + (r0 + k) * nx + wi * 32;
+            while (q) {
+              const int bpos = __ffs(q) - 1;
+              q &= q - 1;
+              drow[bpos] = ((freeb[k] >> bpos) & 1u) ? lvl1 : N_obst;
+            }
+          }
+        }
+      }
+    }
+    if (any) s_flag[level % 3] = 1;
+    if (tid == 0) s_flag[(level + 1) % 3] = 0;
+    __syncthreads();
+    if (!s_flag[level % 3]) break;
+    uint32_t* t = cur;
+    cur = nxt;
+    nxt = t;
+    ++level;
+  }
+
+  // --- decode: unvisited -> unreachableCellCosts(); touched obstacle -> obstacleCosts(); else level
+  if (owner) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      if (r0 + k >= ny) continue;
+      const uint32_t vis = visited[k], fb = freeb[k], lt = late[base_w + k * W];
+      uint32_t* drow = dist + (r0 + k) * nx + wi * 32;
+      const uint32_t nb = min(32u, nx - wi * 32);
+      auto value = [&](uint32_t bpos) -> uint32_t {
+        uint32_t lvl = 0;
+#pragma unroll
+        for (int b = 0; b < kPlanes; ++b) lvl |= ((plane[b][k] >> bpos) & 1u) << b;
+        if (!((vis >> bpos) & 1u)) return N_unreach;
+        if (!((fb >> bpos) & 1u) && lvl != 0) return N_obst;  // level 0 on an obstacle cell == a seed
+        return lvl;
+      };
+      if (aligned4 && lt == 0) {
+        for (uint32_t q = 0; q < nb / 4; ++q) {
+          uint4 v;
+          v.x = value(4 * q);
+          v.y = value(4 * q + 1);
+          v.z = value(4 * q + 2);
+          v.w = value(4 * q + 3);
+          *reinterpret_cast<uint4*>(drow + 4 * q) = v;
+        }
+      } else {
+        for (uint32_t bpos = 0; bpos < nb; ++bpos)
+          if (!((lt >> bpos) & 1u)) drow[bpos] = value(bpos);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_bfs_list: same wavefront, work proportional to the frontier.  The frontier stays a bitmap, but
+// each level only visits the words that hold frontier bits (a compact list in LDS, ~1000 of 5200
+// words at 400x400) and *pushes* their bits to the five neighbouring words with LDS atomics:
+//   old = atomicOr(visited[t], m)  -> newly reached bits  -> distance stores, next-frontier bits,
+//   the first thread to put a bit into next[t] appends t to the next level's list.
+// One barrier per level; three rotating counters / two lists make that single barrier sufficient.
+// LDS: visited, free, cur, next bitmaps + two u16 lists = 20 B per word (104 KB at 400x400).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_bfs_list(PlannerDev pl, uint32_t first) {
+  extern __shared__ __align__(16) uint32_t sm[];
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_cnt[3];
+  const int which = blockIdx.x;
+  const uint32_t inst = first + blockIdx.y;
+  const uint32_t tid = threadIdx.x;
+  const Geom g = geomOf(pl, inst);
+  const uint32_t nx = pl.nx, ny = pl.ny, W = (nx + 31) >> 5, words = ny * W;
+  uint32_t* vis = sm;
+  uint32_t* fre = sm + words;
+  uint32_t* cur = sm + 2 * words;
+  uint32_t* nxt = sm + 3 * words;
+  uint16_t* list0 = reinterpret_cast<uint16_t*>(sm + 4 * words);
+  uint16_t* list1 = list0 + words;
+  const uint8_t* master = pl.master + (size_t)inst * pl.cells_padded;
+  uint32_t* dist = (which == 0 ? pl.path : (which == 1 ? pl.goal : pl.goal_front)) + (size_t)inst * pl.cells;
+  const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
+  const bool allow_unknown = pl.cfg.allow_unknown != 0;
+  const uint32_t last_mask = (nx & 31) ? ((1u << (nx & 31)) - 1u) : 0xFFFFFFFFu;
+  const uint32_t unknown_is_obstacle = allow_unknown ? 0u : 1u;
+
+  // --- bitmaps: `free` from the costmap (updatePathCell's obstacle test :109-115), others cleared
+  const bool aligned4 = (nx & 3) == 0;
+  for (uint32_t w = tid; w < words; w += blockDim.x) {
+    const uint32_t row = w / W, wi = w - row * W;
+    const uint32_t nb = min(32u, nx - wi * 32);
+    uint32_t bits = 0;
+    if (aligned4) {
+      const uint32_t* p4 = reinterpret_cast<const uint32_t*>(master + row * nx + wi * 32);
+      for (uint32_t q = 0; q < nb / 4; ++q) {
+        const uint32_t v = p4[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t cst = (v >> (8 * j)) & 0xFFu;
+          const bool obstacle = cst == kLethal || cst == kInscribed || (cst == kNoInfo && unknown_is_obstacle);
+          bits |= (obstacle ? 0u : 1u) << (4 * q + j);
+        }
+      }
+    } else {
+      const uint8_t* p = master + row * nx + wi * 32;
+      for (uint32_t b = 0; b < nb; ++b) {
+        const uint32_t cst = p[b];
+        const bool obstacle = cst == kLethal || cst == kInscribed || (cst == kNoInfo && unknown_is_obstacle);
+        bits |= (obstacle ? 0u : 1u) << b;
+      }
+    }
+    fre[w] = bits;
+    vis[w] = (wi + 1 == W) ? ~last_mask : 0u;  // bits past the last column count as visited
+    cur[w] = 0;
+    nxt[w] = 0;
+  }
+  if (tid < 3) s_cnt[tid] = 0;
+  __syncthreads();
+
+  // --- seeds from the plan (setTargetCells :189-202 / setLocalGoal :225-251)
+  {
+    const uint32_t n = pl.plan_count[inst];
+    const double* P = pl.plan + (size_t)inst * pl.max_plan * 2;
+    const bool ovr = which == 2;
+    const double lx = pl.front_last[2 * inst], ly = pl.front_last[2 * inst + 1];
+    const uint32_t chunk = (n + blockDim.x - 1) / blockDim.x;
+    const uint32_t i0 = min(n, tid * chunk), i1 = min(n, i0 + chunk);
+    uint32_t mine = 0;
+    for (uint32_t i = i0; i < i1; ++i) mine += adjustedPoints(P, i, lx, ly, ovr, n, g.res, true, [](uint32_t, double, double) {});
+    uint32_t total;
+    const uint32_t base = blockExclusiveScan1024(mine, s_wave, &total);
+    auto valid = [&](double x, double y, uint32_t& cell) {
+      uint32_t mx, my;
+      if (!worldToMap(g, x, y, mx, my)) return false;
+      cell = my * nx + mx;
+      return master[cell] != kNoInfo;
+    };
+    uint32_t fmin_ = 0xFFFFFFFFu, b = base;
+    for (uint32_t i = i0; i < i1; ++i)
+      b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+        uint32_t cell;
+        if (valid(x, y, cell)) fmin_ = min(fmin_, b + k);
+      });
+    const uint32_t f = blockMin1024(fmin_, s_wave);
+    if (f != 0xFFFFFFFFu) {
+      uint32_t emin = total;
+      b = base;
+      for (uint32_t i = i0; i < i1; ++i)
+        b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+          uint32_t cell;
+          if (b + k > f && !valid(x, y, cell)) emin = min(emin, b + k);
+        });
+      const uint32_t e = blockMin1024(emin, s_wave);
+      b = base;
+      for (uint32_t i = i0; i < i1; ++i)
+        b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+          const uint32_t idx = b + k;
+          const bool seed = (which == 0) ? (idx >= f && idx < e) : (idx == e - 1);
+          if (!seed) return;
+          uint32_t cell;
+          if (!valid(x, y, cell)) return;
+          const uint32_t my = cell / nx, mx = cell - my * nx;
           atomicOr(&cur[my * W + (mx >> 5)], 1u << (mx & 31));
           dist[cell] = 0;
         });
     }
   }
   __syncthreads();
-#pragma unroll
-  for (int s = 0; s < WPT; ++s) {
-    const uint32_t w = tid + s * 1024;
-    if (w < words) visited[s] = cur[w];
+  // level-0 list: every word that holds a seed
+  for (uint32_t w = tid; w < words; w += blockDim.x) {
+    const uint32_t sbits = cur[w];
+    if (sbits) {
+      vis[w] |= sbits;
+      list0[atomicAdd(&s_cnt[0], 1u)] = (uint16_t)w;
+    }
   }
+  __syncthreads();
 
-  // --- level-synchronous expansion
-  const uint32_t last_mask = (nx & 31) ? ((1u << (nx & 31)) - 1u) : 0xFFFFFFFFu;
+  // --- level loop
   uint32_t level = 0;
+  uint32_t* cbuf = cur;
+  uint32_t* nbuf = nxt;
+  uint16_t* lcur = list0;
+  uint16_t* lnext = list1;
   while (true) {
-    int any = 0;
+    const uint32_t n = s_cnt[level % 3];
+    if (n == 0) break;
+    uint32_t* cnt_next = &s_cnt[(level + 1) % 3];
+    if (tid == 0) s_cnt[(level + 2) % 3] = 0;
+    // whole waves iterate together (ballots below); straight-line code so the five visited-atomics,
+    // the five `free` reads and then the five next-frontier atomics are each in flight together
+    const uint32_t n_round = (n + 63u) & ~63u;
+    const uint32_t lane = tid & 63u;
+    for (uint32_t i = tid; i < n_round; i += blockDim.x) {
+      const bool act = i < n;
+      const uint32_t w = act ? lcur[i] : 0u;
+      const uint32_t fc = act ? cbuf[w] : 0u;
+      if (act) cbuf[w] = 0;
+      const uint32_t row = w / W, wi = w - row * W;
+      const bool hl = wi > 0, hr = wi + 1 < W, hu = row > 0, hd = row + 1 < ny;
+      uint32_t t[5], m[5];
+      t[0] = w;
+      m[0] = (fc << 1) | (fc >> 1);
+      t[1] = hl ? w - 1 : w;
+      m[1] = hl ? (fc & 1u) << 31 : 0u;
+      t[2] = hr ? w + 1 : w;
+      m[2] = hr ? fc >> 31 : 0u;
+      t[3] = hu ? w - W : w;
+      m[3] = hu ? fc : 0u;
+      t[4] = hd ? w + W : w;
+      m[4] = hd ? fc : 0u;
+      if (wi + 1 == W) {
+        m[0] &= last_mask;
+        m[3] &= last_mask;
+        m[4] &= last_mask;
+      }
+      if (wi + 2 == W) m[2] &= last_mask;
+      uint32_t old[5], fb[5], nf[5];
 #pragma unroll
-    for (int s = 0; s < WPT; ++s) {
-      const uint32_t w = tid + s * 1024;
-      if (w < words) {
-        const uint32_t row = w / W, wi = w - row * W;
-        const uint32_t fc = cur[w];
-        const uint32_t l = wi > 0 ? cur[w - 1] : 0u;
-        const uint32_t r = wi + 1 < W ? cur[w + 1] : 0u;
-        const uint32_t u = row > 0 ? cur[w - W] : 0u;
-        const uint32_t d = row + 1 < ny ? cur[w + W] : 0u;
-        uint32_t cand = ((fc << 1) | (l >> 31) | (fc >> 1) | (r << 31) | u | d) & ~visited[s];
-        if (wi + 1 == W) cand &= last_mask;
-        const uint32_t nf = cand & freeb[s];
-        uint32_t no = cand & ~freeb[s];
-        visited[s] |= cand;
-        nxt[w] = nf;
-        any |= nf != 0;
-        uint32_t* drow = dist + row * nx + wi * 32;
-        uint32_t t = nf;
-        while (t) {
-          const int bpos = __ffs(t) - 1;
-          t &= t - 1;
-          drow[bpos] = level + 1;
-        }
-        while (no) {
-          const int bpos = __ffs(no) - 1;
-          no &= no - 1;
-          drow[bpos] = N_obst;
+      for (int j = 0; j < 5; ++j) old[j] = atomicOr(&vis[t[j]], m[j]);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) fb[j] = fre[t[j]];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const uint32_t nb = m[j] & ~old[j];
+        nf[j] = nb & fb[j];
+        uint32_t no = nb & ~fb[j];
+        if (nb) {
+          const uint32_t trow = j == 3 ? row - 1 : (j == 4 ? row + 1 : row);
+          const uint32_t twi = j == 1 ? wi - 1 : (j == 2 ? wi + 1 : wi);
+          uint32_t* drow = dist + trow * nx + twi * 32;
+          uint32_t q = nf[j];
+          while (q) {
+            const int bpos = __ffs(q) - 1;
+            q &= q - 1;
+            drow[bpos] = level + 1;
+          }
+          while (no) {
+            const int bpos = __ffs(no) - 1;
+            no &= no - 1;
+            drow[bpos] = N_obst;
+          }
         }
       }
+      uint32_t prev[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) prev[j] = nf[j] ? atomicOr(&nbuf[t[j]], nf[j]) : 1u;
+      // wave-aggregated append of the words that just received their first next-frontier bit
+      uint32_t my_count = 0;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) my_count += (nf[j] && prev[j] == 0) ? 1u : 0u;
+      uint32_t incl = my_count;
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if ((int)lane >= off) incl += v;
+      }
+      const uint32_t wave_total = __shfl(incl, 63);
+      uint32_t base_pos = 0;
+      if (wave_total) {
+        if (lane == 63) base_pos = atomicAdd(cnt_next, wave_total);
+        base_pos = __shfl(base_pos, 63);
+        uint32_t pos = base_pos + incl - my_count;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          if (nf[j] && prev[j] == 0) lnext[pos++] = (uint16_t)t[j];
+      }
     }
-    if (!__syncthreads_or(any)) break;
-    uint32_t* t = cur;
-    cur = nxt;
-    nxt = t;
+    __syncthreads();
+    uint32_t* tb = cbuf;
+    cbuf = nbuf;
+    nbuf = tb;
+    uint16_t* tl = lcur;
+    lcur = lnext;
+    lnext = tl;
     ++level;
   }
   // --- never visited: unreachableCellCosts()
-#pragma unroll
-  for (int s = 0; s < WPT; ++s) {
-    const uint32_t w = tid + s * 1024;
-    if (w < words) {
+  for (uint32_t w = tid; w < words; w += blockDim.x) {
+    uint32_t t = ~vis[w];
+    if (t) {
       const uint32_t row = w / W, wi = w - row * W;
-      uint32_t t = ~visited[s];
-      if (wi + 1 == W) t &= last_mask;
       uint32_t* drow = dist + row * nx + wi * 32;
       while (t) {
         const int bpos = __ffs(t) - 1;
@@ -316,18 +652,50 @@ __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
   }
 }
 
-size_t bfs_lds_bytes(uint32_t nx, uint32_t ny) { return (size_t)2 * ny * ((nx + 31) / 32) * 4; }
+size_t bfs_list_lds_bytes(uint32_t nx, uint32_t ny) { return (size_t)ny * ((nx + 31) / 32) * 20; }
+
+// rows per thread needed so that ceil(ny/RPT) * W strips fit one 1024-thread workgroup
+static int bfs_rows_per_thread(uint32_t nx, uint32_t ny) {
+  const uint32_t W = (nx + 31) / 32;
+  for (int rpt : {6, 12, 24}) {
+    if (((ny + rpt - 1) / rpt) * W <= 1024) return rpt;
+  }
+  return 0;
+}
+
+static int bfs_rows_per_thread(uint32_t nx, uint32_t ny);
+size_t bfs_lds_bytes(uint32_t nx, uint32_t ny) {
+  const uint32_t W = (nx + 31) / 32;
+  const int rpt = bfs_rows_per_thread(nx, ny);
+  if (!rpt) return ~(size_t)0;
+  const uint32_t strips = (ny + rpt - 1) / rpt;
+  return ((size_t)2 * (strips * rpt + 2) * (W + 2) + (size_t)ny * W) * 4;
+}
+
+bool bfs_supported(uint32_t nx, uint32_t ny) {
+  if (ny * ((nx + 31) / 32) <= 65535u && bfs_list_lds_bytes(nx, ny) <= 156u * 1024u) return true;
+  return bfs_rows_per_thread(nx, ny) != 0 && bfs_lds_bytes(nx, ny) <= 156u * 1024u;
+}
 
 void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
-  const uint32_t words = pl.ny * ((pl.nx + 31) / 32);
-  const size_t lds = bfs_lds_bytes(pl.nx, pl.ny);
   dim3 grid(3, count);
-  if (words <= 6 * 1024)
-    hipLaunchKernelGGL(k_bfs<6>, grid, dim3(1024), lds, s, pl, first);
-  else if (words <= 12 * 1024)
-    hipLaunchKernelGGL(k_bfs<12>, grid, dim3(1024), lds, s, pl, first);
-  else
-    hipLaunchKernelGGL(k_bfs<20>, grid, dim3(1024), lds, s, pl, first);  // <= 20480 words (host checks)
+  const size_t lds = bfs_lds_bytes(pl.nx, pl.ny);  // dense bit-parallel sweep (no LDS atomics in the loop)
+  const int rpt = bfs_rows_per_thread(pl.nx, pl.ny);
+  if (rpt != 0 && lds <= 156u * 1024u) {
+#define NAVGPU_BFS(R)                                                                                           \
+  {                                                                                                             \
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(k_bfs<R>, grid, dim3(1024), lds, s, pl, first);                                           \
+  }
+    if (rpt == 6) NAVGPU_BFS(6)
+    else if (rpt == 12) NAVGPU_BFS(12)
+    else NAVGPU_BFS(24)
+#undef NAVGPU_BFS
+    return;
+  }
+  const size_t lds_list = bfs_list_lds_bytes(pl.nx, pl.ny);  // frontier-list variant (atomics; kept for comparison)
+  if (lds_list > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_list, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_list);
+  hipLaunchKernelGGL(k_bfs_list, grid, dim3(1024), lds_list, s, pl, first);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -402,11 +770,35 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
   }
   __syncthreads();
 
+  // NOTE: the LDS read is unconditional (clamped index) and the global fallback sits in its own
+  // rarely-taken branch; a `cond ? lds[i] : global[j]` form makes hipcc merge both into one FLAT load.
+  auto inWin = [&](int x, int y) { return (unsigned)(x - wx0) < (unsigned)win && (unsigned)(y - wy0) < (unsigned)win; };
   auto cellCost = [&](int x, int y) -> uint8_t {
-    const int lx = x - wx0, ly = y - wy0;
-    if ((unsigned)lx < (unsigned)win && (unsigned)ly < (unsigned)win) return s_win[ly * win + lx];
-    return master[y * g.nx + x];
+    const bool in = inWin(x, y);
+    uint32_t v = s_win[in ? (y - wy0) * win + (x - wx0) : 0];
+    asm volatile("" : "+v"(v));  // pin the ds_read here so it cannot be re-merged with the global load below
+    if (__builtin_expect(!in, 0)) v = master[y * g.nx + x];
+    return (uint8_t)v;
   };
+  const double inv_res = pl.inv_res;
+  // Costmap2D::worldToMap with the two fp64 divisions replaced by a multiply; exact: whenever the
+  // product is not clear of an integer by 1e-7 (error bound 5e-10 below 1e6 cells) the division is redone.
+  auto w2m = [&](double wx, double wy, uint32_t& mx, uint32_t& my) -> bool {
+    if (wx < g.ox || wy < g.oy) return false;
+    const double dx = wx - g.ox, dy = wy - g.oy;
+    const double qx = dx * inv_res, qy = dy * inv_res;
+    if (!(qx < 1.0e6) || !(qy < 1.0e6)) return false;  // beyond any supported grid (also NaN)
+    double fx = floor(qx), fy = floor(qy);
+    const double rx = qx - fx, ry = qy - fy;
+    if (__builtin_expect(rx < 1.0e-7 || rx > 1.0 - 1.0e-7 || ry < 1.0e-7 || ry > 1.0 - 1.0e-7, 0)) {
+      fx = (double)(int)(dx / g.res);
+      fy = (double)(int)(dy / g.res);
+    }
+    mx = (uint32_t)(int)fx;
+    my = (uint32_t)(int)fy;
+    return mx < g.nx && my < g.ny;
+  };
+  const uint8_t fail_span = (pl.cfg.allow_unknown != 0) ? 0 : 1;  // pointCost: 254, and 255 unless allow_unknown
 
   const int sidx = blockIdx.x * blockDim.x + tid;
   double total = -1.0;
@@ -507,7 +899,7 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
           double sn, cs;
           sincos(th, &sn, &cs);
           uint32_t cx = 0, cy = 0;
-          const bool ok_c = worldToMap(g, x, y, cx, cy);
+          const bool ok_c = w2m(x, y, cx, cy);
           if (live_obs) {
             double f_cost = 0.0;
             bool bad = !ok_c;  // CostmapModel::footprintCost: centre off the map -> -1
@@ -528,7 +920,7 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
                     const double wx = x + (sx * cs - sy * sn);
                     const double wy = y + (sx * sn + sy * cs);
                     uint32_t ux, uy;
-                    if (!worldToMap(g, wx, wy, ux, uy)) {
+                    if (!w2m(wx, wy, ux, uy)) {
                       bad = true;
                       break;
                     }
@@ -568,21 +960,41 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
                     numadd = deltax;
                     numpixels = deltay;
                   }
-                  for (int cp = 0; cp <= numpixels; ++cp) {
-                    uint8_t cc = cellCost(lx, ly);
-                    if (cc == kLethal || (cc == kNoInfo && !allow_unknown)) {
-                      bad = true;
-                      break;
+                  if (__builtin_expect(inWin(pxc, pyc) && inWin(vx, vy), 1)) {
+                    // every cell of the line lies in the endpoints' bounding box, hence in the window
+                    int idx = (pyc - wy0) * win + (pxc - wx0);
+                    const int inc1 = yinc1 * win + xinc1, inc2 = yinc2 * win + xinc2;
+                    for (int cp = 0; cp <= numpixels; ++cp) {
+                      const uint8_t cc = s_win[idx];
+                      if ((uint8_t)(cc - kLethal) <= fail_span) {
+                        bad = true;
+                        break;
+                      }
+                      mx_cost = cc > mx_cost ? cc : mx_cost;
+                      num += numadd;
+                      if (num >= den) {
+                        num -= den;
+                        idx += inc1;
+                      }
+                      idx += inc2;
                     }
-                    mx_cost = cc > mx_cost ? cc : mx_cost;
-                    num += numadd;
-                    if (num >= den) {
-                      num -= den;
-                      lx += xinc1;
-                      ly += yinc1;
+                  } else {
+                    for (int cp = 0; cp <= numpixels; ++cp) {
+                      const uint8_t cc = master[ly * g.nx + lx];
+                      if ((uint8_t)(cc - kLethal) <= fail_span) {
+                        bad = true;
+                        break;
+                      }
+                      mx_cost = cc > mx_cost ? cc : mx_cost;
+                      num += numadd;
+                      if (num >= den) {
+                        num -= den;
+                        lx += xinc1;
+                        ly += yinc1;
+                      }
+                      lx += xinc2;
+                      ly += yinc2;
                     }
-                    lx += xinc2;
-                    ly += yinc2;
                   }
                   pxc = vx;
                   pyc = vy;
@@ -641,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
               sy = y + fpd * sn;
             }
             uint32_t ux, uy;
-            if (!worldToMap(g, sx, sy, ux, uy)) {
+            if (!w2m(sx, sy, ux, uy)) {
               if (en_gf && 2 < first_fail) {
                 code_gf = -4.0;
                 first_fail = 2;
