@@ -88,6 +88,8 @@ struct PlannerDev {
   int32_t* axis_count;        // [n][4]  (nx, ny, nth, total)
   uint32_t *path, *goal, *goal_front;  // [n][cells] each
   uint32_t win;               // edge (cells) of the costmap window staged in LDS by k_score
+  uint32_t use_tables, tab_steps, tab_nfp, tab_nth;
+  uint32_t debug;             // timing ablation bits (NAVGPU_DEBUG_SCORE), 0 in product use  // k_score<TABLES>: shared per-(v_theta, step) tables in LDS
   double* sample_cost;        // [n][max_samples] or null
   int32_t* sample_status;     // [n][max_samples] or null
   double* part_cost;          // [n][score_blocks]
@@ -114,6 +116,7 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
 void launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s);
 void launch_select(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
 size_t bfs_lds_bytes(uint32_t nx, uint32_t ny);
+size_t score_table_bytes(const PlannerDev& pl);
 bool bfs_supported(uint32_t nx, uint32_t ny);
 
 // ---- device helpers ---------------------------------------------------------------------------

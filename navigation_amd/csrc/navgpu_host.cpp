@@ -501,6 +501,17 @@ static void updateWindow(navgpu_fleet* f) {
   double cells = ceil(reach / f->pl.res) + 2;
   uint32_t win = (uint32_t)std::min(cells * 2 + 1, 240.0);
   f->pl.win = win;
+  // shared heading tables (k_score<TABLES>): constant velocity + fixed step count only
+  uint32_t max_nfp = 0;
+  for (uint32_t v : f->h_fp_n) max_nfp = std::max(max_nfp, v);
+  f->pl.use_tables = 0;
+  if (c.use_dwa && c.discretize_by_time && max_nfp <= 8) {
+    f->pl.tab_steps = (uint32_t)ceil(c.sim_time / c.sim_granularity);
+    f->pl.tab_nfp = max_nfp;
+    f->pl.tab_nth = (uint32_t)std::max(c.vth_samples, 2) + 1;
+    const size_t lds = (((size_t)win * win + 15) & ~(size_t)15) + score_table_bytes(f->pl);
+    if (f->pl.tab_steps >= 1 && f->pl.tab_steps <= f->pl.max_sim_steps && lds <= 60 * 1024) f->pl.use_tables = 1;
+  }
 }
 
 int navgpu_set_footprint(navgpu_fleet* f, uint32_t first, uint32_t count, const double* xy, uint32_t nv) {

@@ -5,6 +5,8 @@
 //   k_select  : first-strict-minimum selection, winner trajectory, oscillation flag update
 // Compiled with -ffp-contract=off: the fp64 step arithmetic on fp32 state has to round exactly
 // like the reference (simple_trajectory_generator.cpp:253-260, SURVEY §7 hard part 2).
+#include <cstdlib>
+
 #include "navgpu_device.h"
 
 namespace navgpu {
@@ -720,9 +722,16 @@ struct ScoreOut {
   int n_points;
 };
 
-template <bool EXPLICIT>
+// TABLES (use_dwa && discretize_by_time): the heading sequence theta_k of a sample depends only on its
+// v_theta and the step (theta += v_theta*dt, rounded to float each step), so sincos(theta_k),
+// sincos(pi/2+theta_k), the rotated footprint vertices and the forward-point offset are computed once
+// per (v_theta sample, step) by the workgroup into LDS and shared by all (vx, vy) samples, and lanes
+// are mapped so that a wave shares one v_theta: identical edge shapes => convergent Bresenham loops.
+// The arithmetic per value is unchanged (same operations, same rounding), only deduplicated.
+template <bool EXPLICIT, bool TABLES>
 __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, const float* explicit_sample) {
-  extern __shared__ __align__(16) uint8_t s_win[];
+  extern __shared__ __align__(16) uint8_t s_dyn[];
+  uint8_t* s_win = s_dyn;
   __shared__ double s_fp[2 * kMaxFootprint];
   __shared__ float s_axis[3][kMaxAxis];
   __shared__ double s_rc[4];
@@ -768,6 +777,41 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
       s_win[i] = v;
     }
   }
+  // ---- TABLES: per-(v_theta sample, step) heading, trig, rotated footprint, forward-point offset
+  const int K = TABLES ? (int)pl.tab_steps : 0;
+  const int tnfp = TABLES ? (int)pl.tab_nfp : 0;
+  const int nth_s = TABLES ? cnt[2] : 0;
+  double* s_trig = reinterpret_cast<double*>(s_dyn + ((win * win + 15) & ~15));  // [nth][K][4] cs, sn, cs2, sn2
+  double* s_rot = s_trig + (size_t)pl.tab_nth * K * 4;                            // [nth][K][tnfp][2]
+  float* s_th = reinterpret_cast<float*>(s_rot + (size_t)pl.tab_nth * K * tnfp * 2);  // [nth][K]
+  if (TABLES) {
+    __syncthreads();  // s_axis, s_fp staged
+    const double dt_t = c.sim_time / K;
+    if ((int)tid < nth_s) {
+      float pth = st.pos[2];
+      const float vth = s_axis[2][tid];
+      for (int k = 0; k < K; ++k) {
+        s_th[tid * K + k] = pth;
+        pth = (float)(pth + vth * dt_t);  // computeNewPositions :258
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < nth_s * K; e += blockDim.x) {
+      const double th = s_th[e];
+      double sn, cs, sn2, cs2;
+      sincos(th, &sn, &cs);
+      sincos(M_PI_2 + th, &sn2, &cs2);
+      s_trig[4 * e] = cs;
+      s_trig[4 * e + 1] = sn;
+      s_trig[4 * e + 2] = cs2;
+      s_trig[4 * e + 3] = sn2;
+      for (int v = 0; v < (int)nfp && v < tnfp; ++v) {
+        const double sx = s_fp[2 * v], sy = s_fp[2 * v + 1];
+        s_rot[(e * tnfp + v) * 2] = sx * cs - sy * sn;      // world_model.h:72-73
+        s_rot[(e * tnfp + v) * 2 + 1] = sx * sn + sy * cs;
+      }
+    }
+  }
   __syncthreads();
 
   // NOTE: the LDS read is unconditional (clamped index) and the global fallback sits in its own
@@ -800,10 +844,19 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
   };
   const uint8_t fail_span = (pl.cfg.allow_unknown != 0) ? 0 : 1;  // pointCost: 254, and 255 unless allow_unknown
 
-  const int sidx = blockIdx.x * blockDim.x + tid;
+  // lane -> sample slot.  TABLES: v_theta-major so that a wave shares one heading sequence; the slot
+  // index (x-outer, y, theta-inner, as the reference enumerates) is what results are keyed by.
+  const int lin = blockIdx.x * blockDim.x + tid;
+  bool in_range = lin < n_samples;
+  int sidx = lin, t_ith = 0;
+  if (TABLES && in_range) {
+    const int nxy = cnt[0] * cnt[1];
+    t_ith = lin / nxy;
+    const int r = lin - t_ith * nxy;
+    sidx = r * cnt[2] + t_ith;
+  }
   double total = -1.0;
   int status = NAVGPU_SAMPLE_REJECTED;
-  bool in_range = sidx < n_samples;
 
   if (in_range) {
     float vs[3];
@@ -895,12 +948,19 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
           const bool live_obs = en_obs && 1 < first_fail, live_gf = en_gf && 2 < first_fail, live_al = en_al && 3 < first_fail,
                      live_path = en_path && 4 < first_fail, live_goal = en_goal && 5 < first_fail;
           if (!(live_obs || live_gf || live_al || live_path || live_goal)) break;
+          const int te = TABLES ? t_ith * K + step : 0;
+          if (TABLES) pth = s_th[te];
           const double x = px, y = py, th = pth;
           double sn, cs;
-          sincos(th, &sn, &cs);
+          if (TABLES) {
+            cs = s_trig[4 * te];
+            sn = s_trig[4 * te + 1];
+          } else {
+            sincos(th, &sn, &cs);
+          }
           uint32_t cx = 0, cy = 0;
           const bool ok_c = w2m(x, y, cx, cy);
-          if (live_obs) {
+          if (live_obs && !(pl.debug & 2u)) {
             double f_cost = 0.0;
             bool bad = !ok_c;  // CostmapModel::footprintCost: centre off the map -> -1
             if (!bad) {
@@ -916,9 +976,15 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
                 for (uint32_t v = 0; v <= nfp && !bad; ++v) {
                   int vx, vy;
                   if (v < nfp) {
-                    const double sx = s_fp[2 * v], sy = s_fp[2 * v + 1];
-                    const double wx = x + (sx * cs - sy * sn);
-                    const double wy = y + (sx * sn + sy * cs);
+                    double wx, wy;
+                    if (TABLES) {
+                      wx = x + s_rot[(te * tnfp + v) * 2];
+                      wy = y + s_rot[(te * tnfp + v) * 2 + 1];
+                    } else {
+                      const double sx = s_fp[2 * v], sy = s_fp[2 * v + 1];
+                      wx = x + (sx * cs - sy * sn);
+                      wy = y + (sx * sn + sy * cs);
+                    }
                     uint32_t ux, uy;
                     if (!w2m(wx, wy, ux, uy)) {
                       bad = true;
@@ -961,22 +1027,33 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
                     numpixels = deltay;
                   }
                   if (__builtin_expect(inWin(pxc, pyc) && inWin(vx, vy), 1)) {
-                    // every cell of the line lies in the endpoints' bounding box, hence in the window
+                    // every cell of the line lies in the endpoints' bounding box, hence in the window.
+                    // The Bresenham addresses do not depend on the bytes read, so the cells are fetched
+                    // kChunk at a time with all ds_reads in flight together (one wait per chunk instead
+                    // of one dependent LDS round trip per cell); cells past the end re-read the first
+                    // cell, cells past a lethal cell cannot change the outcome (-1 either way).
+                    constexpr int kChunk = 12;
                     int idx = (pyc - wy0) * win + (pxc - wx0);
+                    const int idx_first = idx;
                     const int inc1 = yinc1 * win + xinc1, inc2 = yinc2 * win + xinc2;
-                    for (int cp = 0; cp <= numpixels; ++cp) {
-                      const uint8_t cc = s_win[idx];
-                      if ((uint8_t)(cc - kLethal) <= fail_span) {
-                        bad = true;
-                        break;
+                    for (int cp = 0; cp <= numpixels && !bad; cp += kChunk) {
+                      uint32_t cellv[kChunk];
+#pragma unroll
+                      for (int u = 0; u < kChunk; ++u) {
+                        cellv[u] = s_win[(cp + u <= numpixels) ? idx : idx_first];
+                        num += numadd;
+                        if (num >= den) {
+                          num -= den;
+                          idx += inc1;
+                        }
+                        idx += inc2;
                       }
-                      mx_cost = cc > mx_cost ? cc : mx_cost;
-                      num += numadd;
-                      if (num >= den) {
-                        num -= den;
-                        idx += inc1;
+#pragma unroll
+                      for (int u = 0; u < kChunk; ++u) {
+                        const uint8_t cc = (uint8_t)cellv[u];
+                        bad |= (uint8_t)(cc - kLethal) <= fail_span;
+                        mx_cost = cc > mx_cost ? cc : mx_cost;
                       }
-                      idx += inc2;
                     }
                   } else {
                     for (int cp = 0; cp <= numpixels; ++cp) {
@@ -1023,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
             } else {
               const uint32_t cell = cy * g.nx + cx;
               if (en_path && 4 < first_fail) {
-                const uint32_t d = dpath[cell];
+                const uint32_t d = (pl.debug & 1u) ? 7u : dpath[cell];
                 if (d == N_obst) {
                   code_path = -3.0;
                   first_fail = 4;
@@ -1034,7 +1111,7 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
                   v_path = d;
               }
               if (en_goal && 5 < first_fail) {
-                const uint32_t d = dgoal[cell];
+                const uint32_t d = (pl.debug & 1u) ? 9u : dgoal[cell];
                 if (d == N_obst) {
                   code_goal = -3.0;
                   first_fail = 5;
@@ -1076,7 +1153,12 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
             lv[2] = t1[2];
           }
           double sn2 = 0.0, cs2 = 0.0;
-          if (lv[1] != 0.0f) sincos(M_PI_2 + th, &sn2, &cs2);
+          if (TABLES) {
+            cs2 = s_trig[4 * te + 2];
+            sn2 = s_trig[4 * te + 3];
+          } else if (lv[1] != 0.0f) {
+            sincos(M_PI_2 + th, &sn2, &cs2);
+          }
           const float nxp = (float)(px + (lv[0] * cs + lv[1] * cs2) * dt);
           const float nyp = (float)(py + (lv[0] * sn + lv[1] * sn2) * dt);
           const float ntp = (float)(pth + lv[2] * dt);
@@ -1145,12 +1227,26 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
   }
 }
 
-void launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s) {
-  const size_t lds = (size_t)pl.win * pl.win;
-  if (explicit_sample)
-    hipLaunchKernelGGL(k_score<true>, dim3(1, count), dim3(256), lds, s, pl, first, explicit_sample);
-  else
-    hipLaunchKernelGGL(k_score<false>, dim3(pl.score_blocks, count), dim3(256), lds, s, pl, first, explicit_sample);
+size_t score_table_bytes(const PlannerDev& pl) {
+  return (size_t)pl.tab_nth * pl.tab_steps * ((4 + 2 * pl.tab_nfp) * sizeof(double) + sizeof(float));
+}
+void launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s) {
+  PlannerDev pl = pl_in;
+  size_t extra_lds = 0;
+  if (const char* e = getenv("NAVGPU_DEBUG_SCORE")) pl.debug = (uint32_t)atoi(e);          // timing ablations only
+  if (const char* e = getenv("NAVGPU_DEBUG_SCORE_LDS")) extra_lds = (size_t)atoi(e);       // occupancy experiments only
+  if (const char* e = getenv("NAVGPU_DEBUG_NO_TABLES")) pl.use_tables = atoi(e) ? 0 : pl.use_tables;
+  const size_t win_bytes = (((size_t)pl.win * pl.win + 15) & ~(size_t)15) + extra_lds;
+  if (explicit_sample) {
+    hipLaunchKernelGGL((k_score<true, false>), dim3(1, count), dim3(256), win_bytes, s, pl, first, explicit_sample);
+  } else if (pl.use_tables) {
+    const size_t lds = win_bytes + score_table_bytes(pl);
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_score<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_score<false, true>), dim3(pl.score_blocks, count), dim3(256), lds, s, pl, first, explicit_sample);
+  } else {
+    if (win_bytes > 48 * 1024) hipFuncSetAttribute((const void*)k_score<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes);
+    hipLaunchKernelGGL((k_score<false, false>), dim3(pl.score_blocks, count), dim3(256), win_bytes, s, pl, first, explicit_sample);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
