@@ -61,6 +61,20 @@ def build_fleet(nav, n_inst, n_cells, seed0, device=0, vs=(32, 32, 16)):
     return fl, insts, cfg
 
 
+def hbm_traffic_from_profiles(kernel):
+    """HBM bytes per launch of `kernel` as measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this
+    exact workload (bench.py cannot collect PMC counters itself); newest profiles/*_hbm_traffic.json."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return d["kernels"][kernel]["hbm_bytes_raw"], os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def step(fl):
     fl.update_map()
     fl.planner_cycle()
@@ -171,6 +185,7 @@ def main():
             "k_obstacle": 0.0, "k_select": 0.0,
         }
         achieved = alg_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
+        traffic, traffic_src = hbm_traffic_from_profiles(dom) if (n_inst, n_cells) == (256, 400) else (None, None)
         out = {
             "metric": "scored trajectories/sec (whole node) + costmap inflation cells/sec, 400x400 map",
             "value": traj_per_s, "unit": "trajectories/s",
@@ -189,7 +204,7 @@ def main():
             "trajectories_per_step": total_scored,
             "kernel_ms": {k: round(avg_ms[k], 4) for k in avg_ms},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": avg_ms[dom],
                          "frac_vs_measured_copy_peak_6290": achieved / 6290.0},
         }

@@ -15,7 +15,11 @@
 namespace navgpu {
 
 constexpr uint8_t kNoInfo = 255, kLethal = 254, kInscribed = 253, kFree = 0;
-constexpr int kMaxFootprint = 32;  // vertices kept in registers/LDS by the kernels
+constexpr int kMaxFootprint = 32;
+#ifndef NAVGPU_SCORE_THREADS
+#define NAVGPU_SCORE_THREADS 256
+#endif
+constexpr int kScoreThreads = NAVGPU_SCORE_THREADS;  // samples per k_score workgroup  // vertices kept in registers/LDS by the kernels
 
 struct InstCostmapState {  // per-instance state that persists across update cycles (device resident)
   double last_min_x, last_min_y, last_max_x, last_max_y;  // InflationLayer::last_* (inflation_layer.cpp:63-66)

@@ -663,7 +663,7 @@ int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
   const uint32_t ax = (uint32_t)(std::max(cfg.vx_samples, 2) + 1), ay = (uint32_t)(std::max(cfg.vy_samples, 2) + 1),
                  at = (uint32_t)(std::max(cfg.vth_samples, 2) + 1);
   const uint32_t max_samples = ax * ay * at;
-  const uint32_t score_blocks = (max_samples + 255) / 256;
+  const uint32_t score_blocks = (max_samples + kScoreThreads - 1) / kScoreThreads;
   if (max_axis != pl.max_axis || max_samples != pl.max_samples) {
     HIP_TRY(hipStreamSynchronize(f->stream));
     f->release(pl.axis_samples);

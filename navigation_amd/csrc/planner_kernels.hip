@@ -729,13 +729,13 @@ struct ScoreOut {
 // are mapped so that a wave shares one v_theta: identical edge shapes => convergent Bresenham loops.
 // The arithmetic per value is unchanged (same operations, same rounding), only deduplicated.
 template <bool EXPLICIT, bool TABLES>
-__global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, const float* explicit_sample) {
+__global__ __launch_bounds__(kScoreThreads) void k_score(PlannerDev pl, uint32_t first, const float* explicit_sample) {
   extern __shared__ __align__(16) uint8_t s_dyn[];
   uint8_t* s_win = s_dyn;
   __shared__ double s_fp[2 * kMaxFootprint];
   __shared__ float s_axis[3][kMaxAxis];
-  __shared__ double s_rc[4];
-  __shared__ int s_ri[4];
+  __shared__ double s_rc[kScoreThreads / 64];
+  __shared__ int s_ri[kScoreThreads / 64];
   __shared__ int s_cnt[2];
 
   const uint32_t inst = first + blockIdx.y;
@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(256) void k_score(PlannerDev pl, uint32_t first, co
   }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < kScoreThreads / 64; ++w)
       if (s_rc[w] < bc || (s_rc[w] == bc && s_ri[w] < bi)) {
         bc = s_rc[w];
         bi = s_ri[w];
@@ -1238,14 +1238,14 @@ void launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, const
   if (const char* e = getenv("NAVGPU_DEBUG_NO_TABLES")) pl.use_tables = atoi(e) ? 0 : pl.use_tables;
   const size_t win_bytes = (((size_t)pl.win * pl.win + 15) & ~(size_t)15) + extra_lds;
   if (explicit_sample) {
-    hipLaunchKernelGGL((k_score<true, false>), dim3(1, count), dim3(256), win_bytes, s, pl, first, explicit_sample);
+    hipLaunchKernelGGL((k_score<true, false>), dim3(1, count), dim3(kScoreThreads), win_bytes, s, pl, first, explicit_sample);
   } else if (pl.use_tables) {
     const size_t lds = win_bytes + score_table_bytes(pl);
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_score<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_score<false, true>), dim3(pl.score_blocks, count), dim3(256), lds, s, pl, first, explicit_sample);
+    hipLaunchKernelGGL((k_score<false, true>), dim3(pl.score_blocks, count), dim3(kScoreThreads), lds, s, pl, first, explicit_sample);
   } else {
     if (win_bytes > 48 * 1024) hipFuncSetAttribute((const void*)k_score<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes);
-    hipLaunchKernelGGL((k_score<false, false>), dim3(pl.score_blocks, count), dim3(256), win_bytes, s, pl, first, explicit_sample);
+    hipLaunchKernelGGL((k_score<false, false>), dim3(pl.score_blocks, count), dim3(kScoreThreads), win_bytes, s, pl, first, explicit_sample);
   }
 }
 
