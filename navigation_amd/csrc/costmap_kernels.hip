@@ -708,9 +708,151 @@ __global__ __launch_bounds__(256) void k_inflate(CostmapDev cm, uint32_t first, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_inflate_bits: the same windowed exact EDT, bit-parallel (inflation radius <= 14 cells).
+//   * seeds of a halo'd tile row are four 32-bit words built with wave ballots (no per-cell LDS
+//     traffic); the nearest seed column distance of a cell is two bit scans (ctz / clz) on a 2R+1
+//     bit window of that row;
+//   * per-row distances are 4-bit nibbles packed 8 rows per word, column-major, so one lane
+//     (= one column) reads 5 words and holds every row it needs in registers;
+//   * a cell's squared distance is min over dy of h(dy)^2 + dy^2 (3 VALU ops per dy, constants
+//     folded when R is the template value) and its cost one lookup in a table indexed by d^2
+//     (host-built from the reference's pairwise table; monotone in d^2, checked on the host).
+// Tile = 64 columns (one per lane) x 32 rows per 256-thread workgroup.
+// ------------------------------------------------------------------------------------------------
+constexpr int kBX = 64, kBY = 32;
+template <int RT>
+__global__ __launch_bounds__(256) void k_inflate_bits(CostmapDev cm, uint32_t first, const int32_t* boxes) {
+  const uint32_t inst = first + blockIdx.z;
+  const int R = RT > 0 ? RT : (int)cm.R;
+  int min_i, min_j, max_i, max_j;
+  if (boxes) {
+    min_i = boxes[4 * blockIdx.z + 0];
+    min_j = boxes[4 * blockIdx.z + 1];
+    max_i = boxes[4 * blockIdx.z + 2];
+    max_j = boxes[4 * blockIdx.z + 3];
+  } else {
+    const InstCostmapState* st = cm.state + inst;
+    if (!st->box_valid) return;
+    min_i = st->box[0];
+    max_i = st->box[1];
+    min_j = st->box[2];
+    max_j = st->box[3];
+  }
+  min_i = max(0, min_i - R);
+  min_j = max(0, min_j - R);
+  max_i = min((int)cm.nx, max_i + R);
+  max_j = min((int)cm.ny, max_j + R);
+  const int tx0 = blockIdx.x * kBX, ty0 = blockIdx.y * kBY;
+  if (tx0 - R >= max_i || tx0 + kBX + R <= min_i || ty0 - R >= max_j || ty0 + kBY + R <= min_j) return;
+
+  constexpr int kMaxHR = kBY + 2 * 14;      // halo'd rows
+  constexpr int kOct = (kMaxHR + 7) / 8;    // row octets
+  __shared__ uint32_t s_rows[kMaxHR][4];    // seed bits of columns [tx0-32, tx0+96)
+  __shared__ uint32_t s_hd[kOct + 1][kBX];  // nibble-packed nearest-seed |dx| per (row octet, column)
+  __shared__ uint8_t s_lut2[256];           // cost by squared distance
+  __shared__ int s_any;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HR = kBY + 2 * R;
+  uint8_t* master = cm.master + (size_t)inst * cm.cells_padded;
+  if (tid == 0) s_any = 0;
+  s_lut2[tid] = cm.lut2[tid];
+  __syncthreads();
+  // ---- seed bitmaps by ballot: wave w takes halo rows w, w+4, ...
+  int any = 0;
+  for (int r = wave; r < HR; r += 4) {
+    const int gy = ty0 - R + r;
+    const bool row_ok = gy >= min_j && gy < max_j;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int gx = tx0 - 32 + half * 64 + (int)lane;
+      bool sd = false;
+      if (row_ok && gx >= min_i && gx < max_i && gx >= tx0 - R && gx < tx0 + kBX + R) sd = master[gy * cm.nx + gx] == kLethal;
+      const unsigned long long m = __ballot(sd);
+      if (lane == 0) {
+        s_rows[r][2 * half] = (uint32_t)m;
+        s_rows[r][2 * half + 1] = (uint32_t)(m >> 32);
+      }
+      any |= m != 0ull;
+    }
+  }
+  if (any && lane == 0) s_any = 1;
+  __syncthreads();
+  if (!s_any) return;
+  // ---- pass A: nearest seed |dx| (nibble, 15 = none within R) for every (halo row, column)
+  const uint32_t lowmask = (1u << R) - 1u;
+  for (int o = wave; o * 8 < HR; o += 4) {
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = o * 8 + k;
+      uint32_t h = 15;
+      if (r < HR) {
+        // cell column c = lane sits at bit 32 + c of the 128-bit row; window = bits [32+c-R, 32+c+R]
+        const uint32_t sft = 32u + lane - (uint32_t)R;
+        const uint32_t wi = sft >> 5, bs = sft & 31u;
+        const unsigned long long two = ((unsigned long long)s_rows[r][wi + 1 < 4 ? wi + 1 : 3] << 32) | s_rows[r][wi];
+        const uint32_t q = (uint32_t)(two >> bs);
+        const uint32_t qr = q >> R;        // bit k: seed at dx = +k (k = 0..R after masking below)
+        const uint32_t ql = q & lowmask;   // bit j: seed at dx = j - R
+        uint32_t dr = 15, dl = 15;
+        if (qr & ((2u << R) - 1u)) dr = (uint32_t)__builtin_ctz(qr & ((2u << R) - 1u));
+        if (ql) dl = (uint32_t)R - (31u - (uint32_t)__builtin_clz(ql));
+        h = dr < dl ? dr : dl;
+      }
+      packed |= h << (4 * k);
+    }
+    s_hd[o][lane] = packed;
+  }
+  __syncthreads();
+  // ---- pass B: wave w owns output rows [8w, 8w+8) of the tile; halo rows [8w, 8w+8+2R) = 5 words
+  uint32_t hw[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) hw[k] = (wave + k) * 8 < (uint32_t)HR ? s_hd[wave + k][lane] : 0xFFFFFFFFu;
+  const int gx = tx0 + (int)lane;
+  const int R2 = R * R;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int gy = ty0 + (int)wave * 8 + j;
+    uint32_t best = 0xFFFFu;
+    if (RT > 0) {
+#pragma unroll
+      for (int dy = -RT; dy <= RT; ++dy) {
+        const int p = j + RT + dy;  // halo row relative to the first loaded word
+        const uint32_t h = (hw[p >> 3] >> (4 * (p & 7))) & 15u;
+        const uint32_t d2 = h * h + (uint32_t)(dy * dy);
+        best = d2 < best ? d2 : best;
+      }
+    } else {
+      for (int dy = -R; dy <= R; ++dy) {
+        const int p = j + R + dy;
+        const uint32_t wsel = p >> 3;
+        const uint32_t word = wsel == 0 ? hw[0] : (wsel == 1 ? hw[1] : (wsel == 2 ? hw[2] : (wsel == 3 ? hw[3] : hw[4])));
+        const uint32_t h = (word >> (4 * (p & 7))) & 15u;
+        const uint32_t d2 = h * h + (uint32_t)(dy * dy);
+        best = d2 < best ? d2 : best;
+      }
+    }
+    if (best > (uint32_t)R2 || gx >= (int)cm.nx || gy >= (int)cm.ny) continue;
+    const uint8_t cost = s_lut2[best];
+    if (cost == 0) continue;
+    const uint8_t old = master[gy * cm.nx + gx];
+    const uint8_t nv = (old == kNoInfo && cost >= kInscribed) ? cost : (old > cost ? old : cost);
+    if (nv != old) master[gy * cm.nx + gx] = nv;
+  }
+}
+
 void launch_inflate(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s) {
   if (!cm.infl_enabled) return;
   const int R = (int)cm.R;
+  if (cm.lut2_ok && R >= 1 && R <= 14) {
+    dim3 grid((cm.nx + kBX - 1) / kBX, (cm.ny + kBY - 1) / kBY, count);
+    if (R == 11)
+      hipLaunchKernelGGL(k_inflate_bits<11>, grid, dim3(256), 0, s, cm, first, boxes);
+    else
+      hipLaunchKernelGGL(k_inflate_bits<0>, grid, dim3(256), 0, s, cm, first, boxes);
+    return;
+  }
   const int W = kTile + 2 * R, WS = (W + 3) & ~3;
   size_t lds = (size_t)W * WS + (size_t)W * kTile + (size_t)(R + 2) * (R + 2);
   dim3 grid((cm.nx + kTile - 1) / kTile, (cm.ny + kTile - 1) / kTile, count);

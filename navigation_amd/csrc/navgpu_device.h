@@ -57,6 +57,8 @@ struct CostmapDev {
   uint8_t *master, *stat, *obst;
   uint32_t* voxel;
   uint8_t* lut;        // (R+2)^2 cost table with 0 where cached distance > R
+  uint8_t* lut2;       // [256] cost by squared cell distance (k_inflate_bits), valid when lut2_ok
+  int32_t lut2_ok;
   InstCostmapState* state;  // [n]
   // staged cycle inputs
   double* pose;        // [n][3]

@@ -224,6 +224,7 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   if (d->layers & (NAVGPU_LAYER_OBSTACLE | NAVGPU_LAYER_VOXEL)) A(cm.obst, (size_t)n * cm.cells_padded);
   if (d->layers & NAVGPU_LAYER_VOXEL) A(cm.voxel, (size_t)n * cm.cells_padded);
   A(cm.lut, 66 * 66);
+  A(cm.lut2, 256);
   A(cm.state, n);
   A(cm.pose, (size_t)n * 3);
   A(cm.fp_world, (size_t)n * kMaxFootprint * 2);
@@ -467,6 +468,30 @@ int navgpu_inflation_configure(navgpu_fleet* f, const navgpu_inflation_params* p
     return NAVGPU_ERR_INVALID;
   }
   HIP_TRY(hipMemcpyAsync(cm.lut, lut.data(), lut.size(), hipMemcpyHostToDevice, f->stream));
+  // cost by squared distance for the bit-parallel kernel: max over the (i, j) pairs that share d^2,
+  // usable only if it is non-increasing in d^2 (then max-over-seeds == cost of the nearest seed)
+  std::vector<uint8_t> lut2(256, 0);
+  bool lut2_ok = R <= 14;
+  if (lut2_ok) {
+    for (uint32_t i = 0; i <= R; ++i)
+      for (uint32_t j = 0; j <= R; ++j) {
+        const uint32_t d2 = i * i + j * j;
+        if (d2 < 256) lut2[d2] = std::max(lut2[d2], lut[(size_t)i * n + j]);
+      }
+    uint8_t prev = 255;
+    for (uint32_t d2 = 0; d2 <= R * R; ++d2) {
+      bool reachable = false;
+      for (uint32_t i = 0; i * i <= d2 && !reachable; ++i) {
+        const uint32_t rem = d2 - i * i, j = (uint32_t)llround(sqrt((double)rem));
+        reachable = j * j == rem;
+      }
+      if (!reachable) continue;
+      if (lut2[d2] > prev) lut2_ok = false;
+      prev = lut2[d2];
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(cm.lut2, lut2.data(), lut2.size(), hipMemcpyHostToDevice, f->stream));
+  cm.lut2_ok = lut2_ok ? 1 : 0;
   HIP_TRY(hipStreamSynchronize(f->stream));
   const bool changed = !f->inflation_configured || f->infl.inflation_radius != p->inflation_radius ||
                        f->infl.cost_scaling_factor != p->cost_scaling_factor || f->infl.inscribed_radius != p->inscribed_radius ||
