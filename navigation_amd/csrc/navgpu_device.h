@@ -93,6 +93,7 @@ struct PlannerDev {
   float* axis_samples;        // [n][3][max_axis]
   int32_t* axis_count;        // [n][4]  (nx, ny, nth, total)
   uint32_t *path, *goal, *goal_front;  // [n][cells] each
+  uint32_t* bfs_scratch;      // k_bfs_global bitmaps (only for grids too large for LDS)
   uint32_t win;               // edge (cells) of the costmap window staged in LDS by k_score
   uint32_t use_tables, tab_steps, tab_nfp, tab_nth;
   uint32_t debug;             // timing ablation bits (NAVGPU_DEBUG_SCORE), 0 in product use  // k_score<TABLES>: shared per-(v_theta, step) tables in LDS
@@ -123,7 +124,8 @@ void launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, const fl
 void launch_select(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
 size_t bfs_lds_bytes(uint32_t nx, uint32_t ny);
 size_t score_table_bytes(const PlannerDev& pl);
-bool bfs_supported(uint32_t nx, uint32_t ny);
+bool bfs_lds_resident(uint32_t nx, uint32_t ny);
+size_t bfs_scratch_words(uint32_t nx, uint32_t ny);
 
 // ---- device helpers ---------------------------------------------------------------------------
 struct Geom {

@@ -169,10 +169,6 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   if (!d || !out || d->n_instances == 0 || d->size_x == 0 || d->size_y == 0 || !(d->resolution > 0)) return NAVGPU_ERR_INVALID;
   if (d->max_footprint > (uint32_t)kMaxFootprint) return NAVGPU_ERR_CAPACITY;
   if ((uint64_t)d->size_x * d->size_y > (1ull << 30) || d->size_x > 65535 || d->size_y > 65535) return NAVGPU_ERR_CAPACITY;
-  if (!bfs_supported(d->size_x, d->size_y)) {
-    g_last_error = "grid too large for the LDS-resident wavefront kernel";
-    return NAVGPU_ERR_CAPACITY;
-  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || d->device < 0 || d->device >= ndev) {
     g_last_error = "no HIP device";
@@ -257,6 +253,7 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   A(pl.path, (size_t)n * pl.cells);
   A(pl.goal, (size_t)n * pl.cells);
   A(pl.goal_front, (size_t)n * pl.cells);
+  if (bfs_scratch_words(cm.nx, cm.ny)) A(pl.bfs_scratch, (size_t)n * bfs_scratch_words(cm.nx, cm.ny));
   A(pl.counters, (size_t)n * 2);
   A(pl.osc_flags, n);
   A(pl.osc_prev, (size_t)n * 3);

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
   const uint32_t inst = first + blockIdx.y;
   const uint32_t tid = threadIdx.x;
   const Geom g = geomOf(pl, inst);
-  const uint32_t nx = pl.nx, ny = pl.ny, W = (nx + 31) >> 5, words = ny * W;
+  const uint32_t nx = pl.nx, ny = pl.ny, W = (nx + 31) >> 5;
   // frontier bitmaps are padded with a zero border (one word left/right, one row above/below, rows
   // rounded up to whole strips) so that every neighbour read and every store is unconditional
   const uint32_t strips = (ny + RPT - 1) / RPT;
@@ -419,70 +419,44 @@ __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_bfs_list: same wavefront, work proportional to the frontier.  The frontier stays a bitmap, but
-// each level only visits the words that hold frontier bits (a compact list in LDS, ~1000 of 5200
-// words at 400x400) and *pushes* their bits to the five neighbouring words with LDS atomics:
-//   old = atomicOr(visited[t], m)  -> newly reached bits  -> distance stores, next-frontier bits,
-//   the first thread to put a bit into next[t] appends t to the next level's list.
-// One barrier per level; three rotating counters / two lists make that single barrier sufficient.
-// LDS: visited, free, cur, next bitmaps + two u16 lists = 20 B per word (104 KB at 400x400).
+// k_bfs_global: fallback for grids whose frontier bitmaps do not fit in LDS (e.g. 1000x1000): the
+// same level-synchronous bit-parallel sweep with the four bitmaps in a global scratch buffer
+// (L2-resident, 4 x words x 4 B per grid) and direct distance stores.  One workgroup per grid;
+// correctness first — this path is ~10x slower per level than the LDS kernels.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_bfs_list(PlannerDev pl, uint32_t first) {
-  extern __shared__ __align__(16) uint32_t sm[];
+__global__ __launch_bounds__(1024) void k_bfs_global(PlannerDev pl, uint32_t first, uint32_t* scratch) {
   __shared__ uint32_t s_wave[16];
-  __shared__ uint32_t s_cnt[3];
   const int which = blockIdx.x;
   const uint32_t inst = first + blockIdx.y;
   const uint32_t tid = threadIdx.x;
   const Geom g = geomOf(pl, inst);
   const uint32_t nx = pl.nx, ny = pl.ny, W = (nx + 31) >> 5, words = ny * W;
-  uint32_t* vis = sm;
-  uint32_t* fre = sm + words;
-  uint32_t* cur = sm + 2 * words;
-  uint32_t* nxt = sm + 3 * words;
-  uint16_t* list0 = reinterpret_cast<uint16_t*>(sm + 4 * words);
-  uint16_t* list1 = list0 + words;
+  uint32_t* base = scratch + ((size_t)(blockIdx.y * 3 + which)) * 4 * words;
+  uint32_t* vis = base;
+  uint32_t* fre = base + words;
+  uint32_t* cur = base + 2 * words;
+  uint32_t* nxt = base + 3 * words;
   const uint8_t* master = pl.master + (size_t)inst * pl.cells_padded;
   uint32_t* dist = (which == 0 ? pl.path : (which == 1 ? pl.goal : pl.goal_front)) + (size_t)inst * pl.cells;
   const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
-  const bool allow_unknown = pl.cfg.allow_unknown != 0;
+  const uint32_t unknown_is_obstacle = pl.cfg.allow_unknown != 0 ? 0u : 1u;
   const uint32_t last_mask = (nx & 31) ? ((1u << (nx & 31)) - 1u) : 0xFFFFFFFFu;
-  const uint32_t unknown_is_obstacle = allow_unknown ? 0u : 1u;
-
-  // --- bitmaps: `free` from the costmap (updatePathCell's obstacle test :109-115), others cleared
-  const bool aligned4 = (nx & 3) == 0;
   for (uint32_t w = tid; w < words; w += blockDim.x) {
     const uint32_t row = w / W, wi = w - row * W;
+    const uint8_t* p = master + row * nx + wi * 32;
     const uint32_t nb = min(32u, nx - wi * 32);
     uint32_t bits = 0;
-    if (aligned4) {
-      const uint32_t* p4 = reinterpret_cast<const uint32_t*>(master + row * nx + wi * 32);
-      for (uint32_t q = 0; q < nb / 4; ++q) {
-        const uint32_t v = p4[q];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t cst = (v >> (8 * j)) & 0xFFu;
-          const bool obstacle = cst == kLethal || cst == kInscribed || (cst == kNoInfo && unknown_is_obstacle);
-          bits |= (obstacle ? 0u : 1u) << (4 * q + j);
-        }
-      }
-    } else {
-      const uint8_t* p = master + row * nx + wi * 32;
-      for (uint32_t b = 0; b < nb; ++b) {
-        const uint32_t cst = p[b];
-        const bool obstacle = cst == kLethal || cst == kInscribed || (cst == kNoInfo && unknown_is_obstacle);
-        bits |= (obstacle ? 0u : 1u) << b;
-      }
+    for (uint32_t b = 0; b < nb; ++b) {
+      const uint32_t cst = p[b];
+      const bool obstacle = cst == kLethal || cst == kInscribed || (cst == kNoInfo && unknown_is_obstacle);
+      bits |= (obstacle ? 0u : 1u) << b;
     }
     fre[w] = bits;
-    vis[w] = (wi + 1 == W) ? ~last_mask : 0u;  // bits past the last column count as visited
+    vis[w] = (wi + 1 == W) ? ~last_mask : 0u;
     cur[w] = 0;
     nxt[w] = 0;
   }
-  if (tid < 3) s_cnt[tid] = 0;
   __syncthreads();
-
-  // --- seeds from the plan (setTargetCells :189-202 / setLocalGoal :225-251)
   {
     const uint32_t n = pl.plan_count[inst];
     const double* P = pl.plan + (size_t)inst * pl.max_plan * 2;
@@ -493,14 +467,14 @@ __global__ __launch_bounds__(1024) void k_bfs_list(PlannerDev pl, uint32_t first
     uint32_t mine = 0;
     for (uint32_t i = i0; i < i1; ++i) mine += adjustedPoints(P, i, lx, ly, ovr, n, g.res, true, [](uint32_t, double, double) {});
     uint32_t total;
-    const uint32_t base = blockExclusiveScan1024(mine, s_wave, &total);
+    const uint32_t bs = blockExclusiveScan1024(mine, s_wave, &total);
     auto valid = [&](double x, double y, uint32_t& cell) {
       uint32_t mx, my;
       if (!worldToMap(g, x, y, mx, my)) return false;
       cell = my * nx + mx;
       return master[cell] != kNoInfo;
     };
-    uint32_t fmin_ = 0xFFFFFFFFu, b = base;
+    uint32_t fmin_ = 0xFFFFFFFFu, b = bs;
     for (uint32_t i = i0; i < i1; ++i)
       b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
         uint32_t cell;
@@ -509,14 +483,14 @@ __global__ __launch_bounds__(1024) void k_bfs_list(PlannerDev pl, uint32_t first
     const uint32_t f = blockMin1024(fmin_, s_wave);
     if (f != 0xFFFFFFFFu) {
       uint32_t emin = total;
-      b = base;
+      b = bs;
       for (uint32_t i = i0; i < i1; ++i)
         b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
           uint32_t cell;
           if (b + k > f && !valid(x, y, cell)) emin = min(emin, b + k);
         });
       const uint32_t e = blockMin1024(emin, s_wave);
-      b = base;
+      b = bs;
       for (uint32_t i = i0; i < i1; ++i)
         b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
           const uint32_t idx = b + k;
@@ -531,115 +505,47 @@ __global__ __launch_bounds__(1024) void k_bfs_list(PlannerDev pl, uint32_t first
     }
   }
   __syncthreads();
-  // level-0 list: every word that holds a seed
-  for (uint32_t w = tid; w < words; w += blockDim.x) {
-    const uint32_t sbits = cur[w];
-    if (sbits) {
-      vis[w] |= sbits;
-      list0[atomicAdd(&s_cnt[0], 1u)] = (uint16_t)w;
-    }
-  }
+  for (uint32_t w = tid; w < words; w += blockDim.x) vis[w] |= cur[w];
   __syncthreads();
-
-  // --- level loop
   uint32_t level = 0;
-  uint32_t* cbuf = cur;
-  uint32_t* nbuf = nxt;
-  uint16_t* lcur = list0;
-  uint16_t* lnext = list1;
   while (true) {
-    const uint32_t n = s_cnt[level % 3];
-    if (n == 0) break;
-    uint32_t* cnt_next = &s_cnt[(level + 1) % 3];
-    if (tid == 0) s_cnt[(level + 2) % 3] = 0;
-    // whole waves iterate together (ballots below); straight-line code so the five visited-atomics,
-    // the five `free` reads and then the five next-frontier atomics are each in flight together
-    const uint32_t n_round = (n + 63u) & ~63u;
-    const uint32_t lane = tid & 63u;
-    for (uint32_t i = tid; i < n_round; i += blockDim.x) {
-      const bool act = i < n;
-      const uint32_t w = act ? lcur[i] : 0u;
-      const uint32_t fc = act ? cbuf[w] : 0u;
-      if (act) cbuf[w] = 0;
+    int any = 0;
+    for (uint32_t w = tid; w < words; w += blockDim.x) {
       const uint32_t row = w / W, wi = w - row * W;
-      const bool hl = wi > 0, hr = wi + 1 < W, hu = row > 0, hd = row + 1 < ny;
-      uint32_t t[5], m[5];
-      t[0] = w;
-      m[0] = (fc << 1) | (fc >> 1);
-      t[1] = hl ? w - 1 : w;
-      m[1] = hl ? (fc & 1u) << 31 : 0u;
-      t[2] = hr ? w + 1 : w;
-      m[2] = hr ? fc >> 31 : 0u;
-      t[3] = hu ? w - W : w;
-      m[3] = hu ? fc : 0u;
-      t[4] = hd ? w + W : w;
-      m[4] = hd ? fc : 0u;
-      if (wi + 1 == W) {
-        m[0] &= last_mask;
-        m[3] &= last_mask;
-        m[4] &= last_mask;
-      }
-      if (wi + 2 == W) m[2] &= last_mask;
-      uint32_t old[5], fb[5], nf[5];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) old[j] = atomicOr(&vis[t[j]], m[j]);
-#pragma unroll
-      for (int j = 0; j < 5; ++j) fb[j] = fre[t[j]];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const uint32_t nb = m[j] & ~old[j];
-        nf[j] = nb & fb[j];
-        uint32_t no = nb & ~fb[j];
-        if (nb) {
-          const uint32_t trow = j == 3 ? row - 1 : (j == 4 ? row + 1 : row);
-          const uint32_t twi = j == 1 ? wi - 1 : (j == 2 ? wi + 1 : wi);
-          uint32_t* drow = dist + trow * nx + twi * 32;
-          uint32_t q = nf[j];
-          while (q) {
-            const int bpos = __ffs(q) - 1;
-            q &= q - 1;
-            drow[bpos] = level + 1;
-          }
-          while (no) {
-            const int bpos = __ffs(no) - 1;
-            no &= no - 1;
-            drow[bpos] = N_obst;
-          }
+      const uint32_t fc = cur[w];
+      const uint32_t l = wi > 0 ? cur[w - 1] : 0u;
+      const uint32_t r = wi + 1 < W ? cur[w + 1] : 0u;
+      const uint32_t u = row > 0 ? cur[w - W] : 0u;
+      const uint32_t d = row + 1 < ny ? cur[w + W] : 0u;
+      const uint32_t v = vis[w];
+      const uint32_t cand = ((fc << 1) | (l >> 31) | (fc >> 1) | (r << 31) | u | d) & ~v;
+      const uint32_t fb = fre[w];
+      const uint32_t nf = cand & fb;
+      uint32_t no = cand & ~fb;
+      nxt[w] = nf;
+      if (cand) {
+        vis[w] = v | cand;
+        any |= nf != 0;
+        uint32_t* drow = dist + row * nx + wi * 32;
+        uint32_t t = nf;
+        while (t) {
+          const int bpos = __ffs(t) - 1;
+          t &= t - 1;
+          drow[bpos] = level + 1;
+        }
+        while (no) {
+          const int bpos = __ffs(no) - 1;
+          no &= no - 1;
+          drow[bpos] = N_obst;
         }
       }
-      uint32_t prev[5];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) prev[j] = nf[j] ? atomicOr(&nbuf[t[j]], nf[j]) : 1u;
-      // wave-aggregated append of the words that just received their first next-frontier bit
-      uint32_t my_count = 0;
-#pragma unroll
-      for (int j = 0; j < 5; ++j) my_count += (nf[j] && prev[j] == 0) ? 1u : 0u;
-      uint32_t incl = my_count;
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(incl, off);
-        if ((int)lane >= off) incl += v;
-      }
-      const uint32_t wave_total = __shfl(incl, 63);
-      uint32_t base_pos = 0;
-      if (wave_total) {
-        if (lane == 63) base_pos = atomicAdd(cnt_next, wave_total);
-        base_pos = __shfl(base_pos, 63);
-        uint32_t pos = base_pos + incl - my_count;
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-          if (nf[j] && prev[j] == 0) lnext[pos++] = (uint16_t)t[j];
-      }
     }
-    __syncthreads();
-    uint32_t* tb = cbuf;
-    cbuf = nbuf;
-    nbuf = tb;
-    uint16_t* tl = lcur;
-    lcur = lnext;
-    lnext = tl;
+    if (!__syncthreads_or(any)) break;
+    uint32_t* t = cur;
+    cur = nxt;
+    nxt = t;
     ++level;
   }
-  // --- never visited: unreachableCellCosts()
   for (uint32_t w = tid; w < words; w += blockDim.x) {
     uint32_t t = ~vis[w];
     if (t) {
@@ -653,8 +559,6 @@ __global__ __launch_bounds__(1024) void k_bfs_list(PlannerDev pl, uint32_t first
     }
   }
 }
-
-size_t bfs_list_lds_bytes(uint32_t nx, uint32_t ny) { return (size_t)ny * ((nx + 31) / 32) * 20; }
 
 // rows per thread needed so that ceil(ny/RPT) * W strips fit one 1024-thread workgroup
 static int bfs_rows_per_thread(uint32_t nx, uint32_t ny) {
@@ -674,9 +578,11 @@ size_t bfs_lds_bytes(uint32_t nx, uint32_t ny) {
   return ((size_t)2 * (strips * rpt + 2) * (W + 2) + (size_t)ny * W) * 4;
 }
 
-bool bfs_supported(uint32_t nx, uint32_t ny) {
-  if (ny * ((nx + 31) / 32) <= 65535u && bfs_list_lds_bytes(nx, ny) <= 156u * 1024u) return true;
+bool bfs_lds_resident(uint32_t nx, uint32_t ny) {
   return bfs_rows_per_thread(nx, ny) != 0 && bfs_lds_bytes(nx, ny) <= 156u * 1024u;
+}
+size_t bfs_scratch_words(uint32_t nx, uint32_t ny) {  // per instance, for k_bfs_global
+  return bfs_lds_resident(nx, ny) ? 0 : (size_t)3 * 4 * ny * ((nx + 31) / 32);
 }
 
 void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
@@ -695,9 +601,7 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
 #undef NAVGPU_BFS
     return;
   }
-  const size_t lds_list = bfs_list_lds_bytes(pl.nx, pl.ny);  // frontier-list variant (atomics; kept for comparison)
-  if (lds_list > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_list, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_list);
-  hipLaunchKernelGGL(k_bfs_list, grid, dim3(1024), lds_list, s, pl, first);
+  hipLaunchKernelGGL(k_bfs_global, grid, dim3(1024), 0, s, pl, first, pl.bfs_scratch);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -507,3 +507,21 @@ def test_voxel_layer_cycles(nav, orc, track_unknown, z_voxels, unknown_thr):
             assert np.array_equal(b[i], oracles[i].bounds()), ("box", cyc, i)
             assert np.array_equal(m[i], oracles[i].master()), ("master", cyc, i)
     fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# larger grids: the RPT=12 LDS wavefront (600x600) and the global-memory fallback (1000x1000)
+# ----------------------------------------------------------------------------------------------
+def test_planner_600x600(nav, orc):
+    _check_planner(nav, orc, 600, dict(vx_samples=8, vy_samples=6, vth_samples=9, sim_time=1.5, sim_granularity=0.1,
+                                       discretize_by_time=1), n_inst=1, seed0=40)
+
+
+def test_planner_config5_shape_1000x1000(nav, orc):
+    """BASELINE config 5 shape on one instance: 1000x1000 map, 5-vertex polygon footprint,
+    64x64x32 velocity samples, 20 steps (the voxel layer of config 5 is covered by
+    test_voxel_layer_cycles)."""
+    from navigation_amd import synth
+    res = _check_planner(nav, orc, 1000, dict(vx_samples=64, vy_samples=64, vth_samples=32, sim_time=2.0, sim_granularity=0.1,
+                                              discretize_by_time=1), n_inst=1, footprint=synth.FOOTPRINT5, seed0=60)
+    assert res[0].n_samples > 131072
