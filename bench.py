@@ -58,7 +58,35 @@ def build_fleet(nav, n_inst, n_cells, seed0, device=0, vs=(32, 32, 16)):
     fl.stage_planner(np.stack([i["pos"] for i in insts]), np.stack([i["vel"] for i in insts]),
                      np.stack([i["plan"] for i in insts]))
     fl.set_plan()
+    fl._bench_host_inputs = (poses, obs, np.stack([i["pos"] for i in insts]), np.stack([i["vel"] for i in insts]),
+                             np.stack([i["plan"] for i in insts]))
     return fl, insts, cfg
+
+
+def raw_inputs(fl):
+    """Pre-marshalled ctypes/numpy buffers of one cycle's inputs (so the PCIe-inclusive leg times the
+    C-ABI staging calls, not Python list handling)."""
+    from navigation_amd._lib import Observation, RobotState, OBS_MARKING, OBS_CLEARING
+    poses, obs, pos, vel, plans = fl._bench_host_inputs
+    arr = (Observation * len(obs))()
+    pts, off = [], 0
+    for k, o in enumerate(obs):
+        p = np.ascontiguousarray(o["points"], np.float32)
+        arr[k] = Observation(o["instance"], off, len(p), OBS_MARKING | OBS_CLEARING, o["origin"][0], o["origin"][1],
+                             o["origin"][2], o["obstacle_range"], o["raytrace_range"])
+        pts.append(p)
+        off += len(p)
+    allp = np.ascontiguousarray(np.concatenate(pts), np.float32)
+    n = len(pos)
+    states = (RobotState * n)()
+    k = plans.shape[1]
+    for i in range(n):
+        states[i].pos[:] = [float(v) for v in pos[i]]
+        states[i].vel[:] = [float(v) for v in vel[i]]
+        states[i].plan_first = i * k
+        states[i].plan_count = k
+    packed = np.ascontiguousarray(plans, np.float64).reshape(-1, 2)
+    return poses, arr, len(obs), allp, states, n, packed
 
 
 def hbm_traffic_from_profiles(kernel):
@@ -229,6 +257,27 @@ def main():
         out["inflation_full_window"] = {"cells_per_s": reps * n_inst * n_cells * n_cells / dt,
                                         "kernel_ms": pk[0] / max(pk[1], 1),
                                         "achieved_GBps": BYTES_PER_INFL_CELL * n_inst * n_cells * n_cells / (pk[0] / max(pk[1], 1) * 1e-3) / 1e9}
+        # PCIe-inclusive rate: every cycle re-stages its inputs from host memory (H2D) and fetches
+        # the results (D2H) through the C-ABI.  Reported beside `value`, never as `value`.
+        poses_h, obs_arr, n_obs, pts_h, states_h, n_st, plans_h = raw_inputs(fl)
+        fl.stage_observations_raw(poses_h, obs_arr, n_obs, pts_h)
+        fl.stage_planner_raw(states_h, n_st, plans_h)
+        step(fl)
+        fl.sync()
+        kp = 10
+        t1 = time.perf_counter()
+        for _ in range(kp):
+            fl.stage_observations_raw(poses_h, obs_arr, n_obs, pts_h)
+            fl.stage_planner_raw(states_h, n_st, plans_h)
+            step(fl)
+            rr = fl.results()
+        dp = time.perf_counter() - t1
+        h2d = poses_h.nbytes + pts_h.nbytes + plans_h.nbytes + n_obs * 56 + n_st * 32
+        out["pcie_inclusive"] = {"trajectories_per_s": sum(r.n_scored for r in rr) * kp / dp, "ms_per_step": dp / kp * 1e3,
+                                 "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": n_st * 72,
+                                 "note": "pageable host buffers, synchronous staging calls"}
+        fl.upload(N.GRID_MASTER, raw)
+        fl.inflate(boxes=full)
         masters = fl.master(0, min(n_inst, 32))
         if not args.no_single:
             f1, i1, c1 = build_fleet(nav, 1, n_cells, seed0=0, device=local_rank)

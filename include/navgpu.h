@@ -76,6 +76,9 @@ typedef struct {
   uint32_t max_sim_steps;   /* capacity: trajectory points (ceil(sim_time/sim_granularity) or the
                                per-sample bound when discretize_by_time = 0)                            */
   int32_t keep_sample_costs;/* 1: keep every sample's total cost + status for navgpu_planner_samples    */
+  int32_t rolling_window;   /* LayeredCostmap(rolling_window): every update re-centres the grids on the robot
+                               (Costmap2D::updateOrigin, costmap_2d.cpp:264-313; not with NAVGPU_LAYER_STATIC,
+                               whose rolling branch needs tf)                                            */
 } navgpu_fleet_desc;
 
 /* One sensor observation of one instance — costmap_2d::Observation (observation.h:46-103):
@@ -195,6 +198,8 @@ void* navgpu_stream(navgpu_fleet* fleet); /* the fleet's hipStream_t */
 /* Costmap2D origin per instance (costmap_2d.h origin_x_/origin_y_); origins_xy = count x {x,y}.
  * replaces: LayeredCostmap::resizeMap origin arguments (layered_costmap.cpp:67-77) */
 int navgpu_fleet_set_origin(navgpu_fleet* fleet, uint32_t first, uint32_t count, const double* origins_xy);
+/* Costmap2D::getOriginX/Y — with a rolling window the origins move every navgpu_costmap_stage */
+int navgpu_fleet_get_origin(navgpu_fleet* fleet, uint32_t first, uint32_t count, double* origins_xy);
 
 /* raw grid access.  host buffers are count x size_y x size_x elements of the grid's type.
  * replaces: Costmap2D::getCharMap() (costmap_2d.cpp:187-190), VoxelGrid::getData() */

@@ -24,7 +24,7 @@ class FleetDesc(C.Structure):
                 ("resolution", C.c_double), ("layers", C.c_int32), ("track_unknown", C.c_int32),
                 ("device", C.c_int32), ("max_points", C.c_uint32), ("max_observations", C.c_uint32),
                 ("max_plan", C.c_uint32), ("max_footprint", C.c_uint32), ("max_sim_steps", C.c_uint32),
-                ("keep_sample_costs", C.c_int32)]
+                ("keep_sample_costs", C.c_int32), ("rolling_window", C.c_int32)]
 
 
 class Observation(C.Structure):
@@ -109,6 +109,7 @@ SYMBOLS = [
     ("navgpu_sync", C.c_int, [vp]),
     ("navgpu_stream", vp, [vp]),
     ("navgpu_fleet_set_origin", C.c_int, [vp, u32, u32, vp]),
+    ("navgpu_fleet_get_origin", C.c_int, [vp, u32, u32, vp]),
     ("navgpu_grid_upload", C.c_int, [vp, C.c_int, u32, u32, vp]),
     ("navgpu_grid_download", C.c_int, [vp, C.c_int, u32, u32, vp]),
     ("navgpu_grid_device", C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]),

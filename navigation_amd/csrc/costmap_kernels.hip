@@ -71,6 +71,33 @@ void launch_static_interpret(uint8_t* dst, const int8_t* occ, uint32_t cells, ui
 }
 
 // ------------------------------------------------------------------------------------------------
+// Costmap2D::updateOrigin (costmap_2d.cpp:264-313) / VoxelLayer::updateOrigin (voxel_layer.cpp:385-440):
+// the overlap of the old and the new window keeps its contents, everything else becomes the default
+// value.  dst(x, y) = src(x + cell_ox, y + cell_oy) when that lies in the grid.  Ping-pong buffers,
+// the host swaps the pointers afterwards.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_shift(const T* src, T* dst, CostmapDev cm, uint32_t first, T fill) {
+  const uint32_t inst = first + blockIdx.y;
+  const int ox = cm.shift[2 * inst], oy = cm.shift[2 * inst + 1];
+  const T* s = src + (size_t)inst * cm.cells_padded;
+  T* d = dst + (size_t)inst * cm.cells_padded;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < cm.cells; i += gridDim.x * blockDim.x) {
+    const int y = i / cm.nx, x = i - y * cm.nx;
+    const int sx = x + ox, sy = y + oy;
+    d[i] = (sx >= 0 && sy >= 0 && sx < (int)cm.nx && sy < (int)cm.ny) ? s[sy * cm.nx + sx] : fill;
+  }
+}
+void launch_shift_u8(const uint8_t* src, uint8_t* dst, const CostmapDev& cm, uint32_t first, uint32_t count, uint8_t fill, hipStream_t s) {
+  dim3 grid(min((cm.cells + 255) / 256, 64u), count);
+  hipLaunchKernelGGL(k_shift<uint8_t>, grid, dim3(256), 0, s, src, dst, cm, first, fill);
+}
+void launch_shift_u32(const uint32_t* src, uint32_t* dst, const CostmapDev& cm, uint32_t first, uint32_t count, uint32_t fill, hipStream_t s) {
+  dim3 grid(min((cm.cells + 255) / 256, 64u), count);
+  hipLaunchKernelGGL(k_shift<uint32_t>, grid, dim3(256), 0, s, src, dst, cm, first, fill);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Bresenham walkers
 // ------------------------------------------------------------------------------------------------
 // Costmap2D::raytraceLine + bresenham2D (costmap_2d.h:359-417): `at(offset)` on every visited cell

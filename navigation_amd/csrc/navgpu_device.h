@@ -68,6 +68,9 @@ struct CostmapDev {
   uint32_t* obs_count; // [n]
   float* points;       // [n][max_points][3] xyz
   uint32_t max_obs, max_points;
+  int32_t* shift;      // [n][2] pending rolling-window shift in cells (cell_ox, cell_oy)
+  uint8_t *master_alt, *obst_alt;  // ping-pong targets of the shift
+  uint32_t* voxel_alt;
 };
 
 struct PlannerDev {
@@ -117,6 +120,8 @@ void launch_static_interpret(uint8_t* dst, const int8_t* occ, uint32_t cells, ui
                              int track_unknown_space, int trinary, int lethal_threshold, int unknown_cost_value, hipStream_t s);
 void launch_fill_u8(uint8_t* dst, uint8_t v, size_t n, hipStream_t s);
 void launch_fill_u32(uint32_t* dst, uint32_t v, size_t n, hipStream_t s);
+void launch_shift_u8(const uint8_t* src, uint8_t* dst, const CostmapDev& cm, uint32_t first, uint32_t count, uint8_t fill, hipStream_t s);
+void launch_shift_u32(const uint32_t* src, uint32_t* dst, const CostmapDev& cm, uint32_t first, uint32_t count, uint32_t fill, hipStream_t s);
 
 void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
 void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);

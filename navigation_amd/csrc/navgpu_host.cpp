@@ -39,6 +39,8 @@ struct navgpu_fleet {
   CostmapDev cm{};
   PlannerDev pl{};
   bool planner_configured = false, inflation_configured = false, planner_staged = false;
+  bool shift_pending = false;                   // rolling window: staged origins not yet applied to the grids
+  uint32_t shift_first = 0, shift_count = 0;
   std::vector<void*> allocs;
   // host mirrors
   std::vector<double> h_origin;                 // [n][2]
@@ -228,6 +230,17 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   A(cm.obs, (size_t)n * cm.max_obs);
   A(cm.obs_count, n);
   A(cm.points, (size_t)n * cm.max_points * 3);
+  A(cm.shift, (size_t)n * 2);
+  if (d->rolling_window) {
+    if (d->layers & NAVGPU_LAYER_STATIC) {
+      g_last_error = "rolling_window with a static layer needs tf (StaticLayer::updateCosts rolling branch) and is not supported";
+      navgpu_fleet_destroy(f);
+      return NAVGPU_ERR_INVALID;
+    }
+    A(cm.master_alt, (size_t)n * cm.cells_padded);
+    if (cm.obst) A(cm.obst_alt, (size_t)n * cm.cells_padded);
+    if (cm.voxel) A(cm.voxel_alt, (size_t)n * cm.cells_padded);
+  }
   A(f->d_bounds_tmp, (size_t)n * 4);
   A(f->d_boxes_tmp, (size_t)n * 4);
   A(f->d_explicit, 4);
@@ -315,6 +328,12 @@ int navgpu_fleet_set_origin(navgpu_fleet* f, uint32_t first, uint32_t count, con
   memcpy(&f->h_origin[(size_t)first * 2], xy, sizeof(double) * 2 * count);
   HIP_TRY(hipMemcpyAsync(f->cm.origin + (size_t)first * 2, xy, sizeof(double) * 2 * count, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(hipStreamSynchronize(f->stream));
+  return NAVGPU_OK;
+}
+
+int navgpu_fleet_get_origin(navgpu_fleet* f, uint32_t first, uint32_t count, double* xy) {
+  if (!f || !xy || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  memcpy(xy, &f->h_origin[(size_t)first * 2], sizeof(double) * 2 * count);
   return NAVGPU_OK;
 }
 
@@ -580,6 +599,29 @@ int navgpu_costmap_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
       memcpy(&h_pts[((size_t)li * cm.max_points + h_pts_used[li]) * 3], points + (size_t)o.first_point * 3, sizeof(float) * 3 * o.n_points);
     h_pts_used[li] += o.n_points;
   }
+  // rolling window: LayeredCostmap::updateMap :86-91 + Costmap2D::updateOrigin :264-276, evaluated here
+  // in fp64 exactly as the reference does; the grids are shifted on the device by navgpu_costmap_update
+  if (f->desc.rolling_window) {
+    if (f->shift_pending) return NAVGPU_ERR_STATE;  // previous stage not consumed by an update yet
+    std::vector<int32_t> h_shift((size_t)count * 2);
+    const double size_m_x = (cm.nx - 1 + 0.5) * cm.res, size_m_y = (cm.ny - 1 + 0.5) * cm.res;  // getSizeInMetersX/Y
+    for (uint32_t li = 0; li < count; ++li) {
+      double& ox = f->h_origin[(size_t)(first + li) * 2];
+      double& oy = f->h_origin[(size_t)(first + li) * 2 + 1];
+      const double new_origin_x = poses[3 * li] - size_m_x / 2, new_origin_y = poses[3 * li + 1] - size_m_y / 2;
+      const int cell_ox = int((new_origin_x - ox) / cm.res), cell_oy = int((new_origin_y - oy) / cm.res);
+      ox = ox + cell_ox * cm.res;
+      oy = oy + cell_oy * cm.res;
+      h_shift[2 * li] = cell_ox;
+      h_shift[2 * li + 1] = cell_oy;
+    }
+    HIP_TRY(hipMemcpyAsync(cm.shift + (size_t)first * 2, h_shift.data(), sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(cm.origin + (size_t)first * 2, &f->h_origin[(size_t)first * 2], sizeof(double) * 2 * count, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    f->shift_pending = true;
+    f->shift_first = first;
+    f->shift_count = count;
+  }
   // transformFootprint (footprint.cpp:103-118) per instance, fp64 libm
   std::vector<double> h_fpw((size_t)count * kMaxFootprint * 2, 0.0);
   for (uint32_t li = 0; li < count; ++li) {
@@ -606,6 +648,23 @@ int navgpu_costmap_update(navgpu_fleet* f, uint32_t first, uint32_t count) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
   CostmapDev& cm = f->cm;
   if ((cm.layers & NAVGPU_LAYER_INFLATION) && !f->inflation_configured) return NAVGPU_ERR_STATE;
+  if (f->desc.rolling_window && f->shift_pending) {
+    if (first != f->shift_first || count != f->shift_count) return NAVGPU_ERR_STATE;
+    // the ping-pong swap is fleet-wide, so a rolling fleet is staged and updated as a whole
+    if (first != 0 || count != f->desc.n_instances) return NAVGPU_ERR_INVALID;
+    launch_shift_u8(cm.master, cm.master_alt, cm, first, count, cm.master_default, f->stream);
+    std::swap(cm.master, cm.master_alt);
+    f->pl.master = cm.master;
+    if (cm.obst) {
+      launch_shift_u8(cm.obst, cm.obst_alt, cm, first, count, cm.obstacle_default, f->stream);
+      std::swap(cm.obst, cm.obst_alt);
+    }
+    if (cm.voxel) {
+      launch_shift_u32(cm.voxel, cm.voxel_alt, cm, first, count, 0x0000FFFFu, f->stream);
+      std::swap(cm.voxel, cm.voxel_alt);
+    }
+    f->shift_pending = false;
+  }
   PROFILED(f, NAVGPU_K_OBSTACLE, launch_obstacle(cm, first, count, nullptr, 0, f->stream));
   PROFILED(f, NAVGPU_K_MERGE, launch_merge(cm, first, count, nullptr, f->stream));
   if (cm.layers & NAVGPU_LAYER_INFLATION) PROFILED(f, NAVGPU_K_INFLATE, launch_inflate(cm, first, count, nullptr, f->stream));

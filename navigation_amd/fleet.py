@@ -29,10 +29,10 @@ def _ptr(a):
 class Fleet:
     def __init__(self, n_instances, size_x, size_y, resolution, layers=N.LAYER_OBSTACLE | N.LAYER_INFLATION,
                  track_unknown=False, device=0, max_points=1024, max_observations=4, max_plan=256,
-                 max_footprint=16, max_sim_steps=64, keep_sample_costs=False):
+                 max_footprint=16, max_sim_steps=64, keep_sample_costs=False, rolling_window=False):
         self.L = lib()
         d = FleetDesc(n_instances, size_x, size_y, resolution, layers, int(track_unknown), device, max_points,
-                      max_observations, max_plan, max_footprint, max_sim_steps, int(keep_sample_costs))
+                      max_observations, max_plan, max_footprint, max_sim_steps, int(keep_sample_costs), int(rolling_window))
         self.desc = d
         self.n, self.nx, self.ny, self.res = n_instances, size_x, size_y, resolution
         self.layers = layers
@@ -59,6 +59,12 @@ class Fleet:
     # ---------------------------------------------------------------- grids
     def sync(self):
         check(self.L.navgpu_sync(self.h), "navgpu_sync")
+
+    def origins(self):
+        """Current Costmap2D origins (they move with a rolling window)."""
+        o = np.zeros((self.n, 2), np.float64)
+        check(self.L.navgpu_fleet_get_origin(self.h, 0, self.n, _ptr(o)), "get_origin")
+        return o
 
     def set_origin(self, origins_xy, first=0):
         o = np.ascontiguousarray(origins_xy, np.float64).reshape(-1, 2)

@@ -147,6 +147,30 @@ struct Grid2D {
   double sizeInMetersX() const { return (size_x - 1 + 0.5) * resolution; }  // costmap_2d.cpp:440-443
   double sizeInMetersY() const { return (size_y - 1 + 0.5) * resolution; }  // costmap_2d.cpp:445-448
 
+  // costmap_2d.cpp:264-313: updateOrigin (rolling window): keep the overlap, default everywhere else.
+  // Returns the cell offsets so that sibling arrays (voxel columns) can be moved the same way.
+  void updateOrigin(double new_origin_x, double new_origin_y, int* out_cell_ox = nullptr, int* out_cell_oy = nullptr) {
+    int cell_ox = int((new_origin_x - origin_x) / resolution);
+    int cell_oy = int((new_origin_y - origin_y) / resolution);
+    double new_grid_ox = origin_x + cell_ox * resolution;
+    double new_grid_oy = origin_y + cell_oy * resolution;
+    int sx = size_x, sy = size_y;
+    int lower_left_x = std::min(std::max(cell_ox, 0), sx), lower_left_y = std::min(std::max(cell_oy, 0), sy);
+    int upper_right_x = std::min(std::max(cell_ox + sx, 0), sx), upper_right_y = std::min(std::max(cell_oy + sy, 0), sy);
+    uint32_t cell_size_x = upper_right_x - lower_left_x, cell_size_y = upper_right_y - lower_left_y;
+    std::vector<uint8_t> local((size_t)cell_size_x * cell_size_y);
+    for (uint32_t i = 0; i < cell_size_y; ++i)  // copyMapRegion, costmap_2d.h:315-331
+      memcpy(local.data() + (size_t)i * cell_size_x, cells.data() + (size_t)(lower_left_y + i) * size_x + lower_left_x, cell_size_x);
+    resetMaps();
+    origin_x = new_grid_ox;
+    origin_y = new_grid_oy;
+    int start_x = lower_left_x - cell_ox, start_y = lower_left_y - cell_oy;
+    for (uint32_t i = 0; i < cell_size_y; ++i)
+      memcpy(cells.data() + (size_t)(start_y + i) * size_x + start_x, local.data() + (size_t)i * cell_size_x, cell_size_x);
+    if (out_cell_ox) *out_cell_ox = cell_ox;
+    if (out_cell_oy) *out_cell_oy = cell_oy;
+  }
+
   // costmap_2d.h:359-417: raytraceLine + bresenham2D; `at(offset)` is applied to every visited cell.
   template <class F>
   void raytraceLine(F&& at, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t max_length = UINT_MAX) const {
@@ -642,6 +666,19 @@ struct VoxelLayerOracle : ObstacleLayerOracle {
       }
     }
   }
+  // voxel_layer.cpp:385-440: the 2-D grid and the voxel columns move together; both are reset first
+  void updateOriginVoxel(double new_origin_x, double new_origin_y) {
+    std::vector<uint32_t> oldv = vg.data;
+    int cell_ox, cell_oy;
+    grid.updateOrigin(new_origin_x, new_origin_y, &cell_ox, &cell_oy);
+    vg.reset();
+    const int sx = grid.size_x, sy = grid.size_y;
+    for (int y = 0; y < sy; ++y)
+      for (int x = 0; x < sx; ++x) {
+        const int ox = x + cell_ox, oy = y + cell_oy;
+        if (ox >= 0 && oy >= 0 && ox < sx && oy < sy) vg.data[(size_t)y * sx + x] = oldv[(size_t)oy * sx + ox];
+      }
+  }
   void updateBoundsVoxel(double rx, double ry, double ryaw, const std::vector<Observation>& marking,
                          const std::vector<Observation>& clearing, Bounds& b) {
     if (!enabled) return;
@@ -843,7 +880,7 @@ struct InflationOracle {
 // ---------------------------------------------------------------------------------------------
 struct LayeredCostmapOracle {
   Grid2D master;
-  bool track_unknown = false;
+  bool track_unknown = false, rolling_window = false;
   bool has_static = false, has_obstacle = false, has_voxel = false, has_inflation = false;
   bool inflation_exact = false;  // use updateCostsExact instead of the PQ walk
   StaticLayerOracle slayer;
@@ -880,9 +917,20 @@ struct LayeredCostmapOracle {
     }
   }
   void updateMap(double rx, double ry, double ryaw) {
+    if (rolling_window) {  // layered_costmap.cpp:86-91
+      double new_origin_x = rx - master.sizeInMetersX() / 2;
+      double new_origin_y = ry - master.sizeInMetersY() / 2;
+      master.updateOrigin(new_origin_x, new_origin_y);
+    }
     if (!(has_static || has_obstacle || has_inflation)) return;
     Bounds b{1e30, 1e30, -1e30, -1e30};
     if (has_static) slayer.updateBounds(b);
+    if (has_obstacle && rolling_window) {  // obstacle_layer.cpp:343-344 / voxel_layer.cpp:119-120
+      if (has_voxel)
+        olayer.updateOriginVoxel(rx - olayer.grid.sizeInMetersX() / 2, ry - olayer.grid.sizeInMetersY() / 2);
+      else
+        olayer.grid.updateOrigin(rx - olayer.grid.sizeInMetersX() / 2, ry - olayer.grid.sizeInMetersY() / 2);
+    }
     if (has_obstacle) {
       if (has_voxel)
         olayer.updateBoundsVoxel(rx, ry, ryaw, marking, clearing, b);

@@ -64,6 +64,12 @@ void* orc_lc_create(int track_unknown) {
   return lc;
 }
 void orc_lc_destroy(void* h) { delete static_cast<LayeredCostmapOracle*>(h); }
+void orc_lc_set_rolling(void* h, int rolling) { static_cast<LayeredCostmapOracle*>(h)->rolling_window = rolling != 0; }
+void orc_lc_get_origin(void* h, double* xy) {
+  auto* lc = static_cast<LayeredCostmapOracle*>(h);
+  xy[0] = lc->master.origin_x;
+  xy[1] = lc->master.origin_y;
+}
 void orc_lc_resize(void* h, uint32_t sx, uint32_t sy, double res, double ox, double oy) {
   static_cast<LayeredCostmapOracle*>(h)->resizeMap(sx, sy, res, ox, oy);
 }

@@ -85,6 +85,8 @@ def lib():
 
     sig("orc_lc_create", vp, i)
     sig("orc_lc_destroy", None, vp)
+    sig("orc_lc_set_rolling", None, vp, i)
+    sig("orc_lc_get_origin", None, vp, f64p)
     sig("orc_lc_resize", None, vp, u, u, d, d, d)
     sig("orc_lc_add_static", None, vp, i8p, u, u, d, d, d, i, i)
     sig("orc_lc_add_obstacle", None, vp, i, i, d)
@@ -190,6 +192,14 @@ class LayeredCostmap:
 
     def resize(self, sx, sy, res=1.0, ox=0.0, oy=0.0):
         self.L.orc_lc_resize(self.h, sx, sy, res, ox, oy)
+
+    def set_rolling(self, rolling=True):
+        self.L.orc_lc_set_rolling(self.h, int(rolling))
+
+    def origin(self):
+        o = np.zeros(2, np.float64)
+        self.L.orc_lc_get_origin(self.h, o)
+        return o
 
     def add_static(self, occ, res=1.0, ox=0.0, oy=0.0, track_unknown_space=True, use_maximum=False):
         occ = np.ascontiguousarray(occ, dtype=np.int8)

@@ -525,3 +525,66 @@ def test_planner_config5_shape_1000x1000(nav, orc):
     res = _check_planner(nav, orc, 1000, dict(vx_samples=64, vy_samples=64, vth_samples=32, sim_time=2.0, sim_granularity=0.1,
                                               discretize_by_time=1), n_inst=1, footprint=synth.FOOTPRINT5, seed0=60)
     assert res[0].n_samples > 131072
+
+
+# ----------------------------------------------------------------------------------------------
+# rolling window (SURVEY f-2): Costmap2D::updateOrigin / VoxelLayer::updateOrigin on the device
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("voxel", [False, True])
+def test_rolling_window_cycles(nav, orc, voxel):
+    from navigation_amd import synth
+    N = L(nav)
+    n, nI = 120, 3
+    insc = synth.inscribed_radius(synth.FOOTPRINT)
+    layers = (N.LAYER_VOXEL if voxel else N.LAYER_OBSTACLE) | N.LAYER_INFLATION
+    fl = nav.Fleet(nI, n, n, synth.RES, layers=layers, track_unknown=True, max_points=720, max_observations=1, rolling_window=True)
+    fl.configure_obstacle()
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, insc)
+    rs = np.random.RandomState(3)
+    starts = rs.uniform(2.0, 4.0, (nI, 2))
+    oracles = []
+    for i in range(nI):
+        o = orc.LayeredCostmap(True)
+        o.resize(n, n, synth.RES, 0, 0)
+        o.set_rolling(True)
+        o.set_footprint(synth.FOOTPRINT)
+        if voxel:
+            o.add_voxel()
+        else:
+            o.add_obstacle()
+        o.add_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, exact=True)
+        o.set_footprint(synth.FOOTPRINT)
+        oracles.append(o)
+    world = synth.make_instance(400, 77)  # a fixed 20 m world the robots drive through
+    for cyc in range(6):
+        poses, obs = [], []
+        for i in range(nI):
+            # motion incl. backwards and a jump larger than the window (everything scrolls out)
+            x = starts[i, 0] + 0.37 * cyc * (1 if i != 1 else -0.5) + (9.0 if (cyc == 4 and i == 2) else 0.0)
+            y = starts[i, 1] + 0.21 * cyc
+            yaw = 0.3 * cyc - 0.5 * i
+            inst = dict(world)
+            inst["pos"] = np.array([x, y, yaw], np.float32)
+            pts = synth.laser_scan(inst, cyc, max_range=4.0, z=0.3, z_jitter=1.0 if voxel else None)
+            org = (float(x), float(y), 0.3)
+            poses.append([float(x), float(y), float(yaw)])
+            obs.append(dict(instance=i, points=pts, origin=org, obstacle_range=2.5, raytrace_range=3.0))
+            oracles[i].clear_observations()
+            oracles[i].add_observation(pts, origin=org, obstacle_range=2.5, raytrace_range=3.0)
+            oracles[i].update_map(*poses[-1])
+        fl.stage_observations(poses, obs)
+        fl.update_map()
+        m = fl.master()
+        ol = fl.download(N.GRID_OBSTACLE)
+        org_g = fl.origins()
+        b = fl.bounds()
+        vx = fl.download(N.GRID_VOXEL) if voxel else None
+        for i in range(nI):
+            assert np.array_equal(org_g[i], oracles[i].origin()), ("origin", cyc, i)
+            assert np.array_equal(b[i], oracles[i].bounds()), ("box", cyc, i)
+            assert np.array_equal(ol[i], oracles[i].layer(2)), ("layer", cyc, i)
+            if voxel:
+                assert np.array_equal(vx[i], oracles[i].voxels()), ("voxels", cyc, i)
+            assert np.array_equal(m[i], oracles[i].master()), ("master", cyc, i)
+    fl.close()
