@@ -122,12 +122,12 @@ def cpu_baseline(insts_sample, cfg, n_cells, masters):
     origins = np.zeros((n_inst, 2))
     cells = np.ascontiguousarray(masters, np.uint8)
     fp = np.ascontiguousarray(synth.FOOTPRINT, np.float64)
-    cycles = 2
+    cycles = 6  # 32 robots x 6 cycles ~ 20 s of CPU work spread over the host cores
     scored = C.c_uint64()
     dt = L.orc_bench_dwa(n_cells, n_cells, synth.RES, cells, n_inst, C.byref(ocfg), pos, vel, plans, plans.shape[1], origins, fp,
                          len(fp), cycles, cores, C.byref(scored))
     raw = np.ascontiguousarray(np.stack([i["cells"] for i in insts_sample]), np.uint8)
-    reps = 2
+    reps = 8
     dti = L.orc_bench_inflate(raw, n_inst, n_cells, n_cells, synth.RES, synth.INFLATION_RADIUS, synth.COST_SCALING,
                               synth.inscribed_radius(synth.FOOTPRINT), reps, cores)
     return dict(value=scored.value / dt, unit="trajectories/s", cores=cores, kind="port",

@@ -125,8 +125,8 @@ void launch_shift_u32(const uint32_t* src, uint32_t* dst, const CostmapDev& cm, 
 
 void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
 void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
-void launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s);
-void launch_select(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
+uint32_t launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s);  // returns blocks per instance
+void launch_select(const PlannerDev& pl, uint32_t first, uint32_t count, uint32_t n_blocks, hipStream_t s);
 size_t bfs_lds_bytes(uint32_t nx, uint32_t ny);
 size_t score_table_bytes(const PlannerDev& pl);
 bool bfs_lds_resident(uint32_t nx, uint32_t ny);

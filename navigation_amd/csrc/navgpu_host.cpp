@@ -826,8 +826,9 @@ int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
   PlannerDev& pl = f->pl;
   launch_samples(pl, first, count, f->stream);
   PROFILED(f, NAVGPU_K_BFS, launch_bfs(pl, first, count, f->stream));
-  PROFILED(f, NAVGPU_K_SCORE, launch_score(pl, first, count, nullptr, f->stream));
-  PROFILED(f, NAVGPU_K_SELECT, launch_select(pl, first, count, f->stream));
+  uint32_t n_blocks = 0;
+  PROFILED(f, NAVGPU_K_SCORE, n_blocks = launch_score(pl, first, count, nullptr, f->stream));
+  PROFILED(f, NAVGPU_K_SELECT, launch_select(pl, first, count, n_blocks, f->stream));
   return checkLaunch();
 }
 
