@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -26,6 +27,10 @@ thread_local std::string g_last_error;
       return NAVGPU_ERR_HIP;                                                                       \
     }                                                                                              \
   } while (0)
+
+// hipStreamSynchronize also flushes the runtime's batched launches; a hipStreamQuery polling loop does
+// not (measured: the queue then only drains when the poll gives up), so no polling here.
+static hipError_t waitStream(hipStream_t s) { return hipStreamSynchronize(s); }
 
 struct EventPair {
   int kernel;
@@ -49,6 +54,16 @@ struct navgpu_fleet {
   navgpu_inflation_params infl{};
   navgpu_obstacle_params obsp{};
   double fp_radius = 0.0;                       // largest vertex distance over all instances
+  // pinned host mirrors of the per-cycle staging arrays (full fleet size): H2D copies are truly
+  // asynchronous and no per-call allocation happens on the staging path
+  std::vector<void*> pinned;
+  ObsCsr* hp_obs = nullptr;
+  uint32_t *hp_cnt = nullptr, *hp_used = nullptr, *hp_plan_cnt = nullptr;
+  float* hp_pts = nullptr;
+  double *hp_fpw = nullptr, *hp_pose = nullptr, *hp_plan = nullptr, *hp_front = nullptr;
+  int32_t *hp_shift = nullptr, *hp_align = nullptr;
+  navgpu_robot_state* hp_state = nullptr;
+  navgpu_plan_result* hp_result = nullptr;
   // scratch device buffers
   double* d_bounds_tmp = nullptr;               // [n][4]
   int32_t* d_boxes_tmp = nullptr;               // [n][4]
@@ -76,6 +91,19 @@ struct navgpu_fleet {
       return NAVGPU_ERR_HIP;
     }
     allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return NAVGPU_OK;
+  }
+  template <class T>
+  int allocPinned(T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t e = hipHostMalloc(&q, std::max<size_t>(count * sizeof(T), 16), hipHostMallocDefault);
+    if (e != hipSuccess) {
+      g_last_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+      return NAVGPU_ERR_HIP;
+    }
+    memset(q, 0, std::max<size_t>(count * sizeof(T), 16));
+    pinned.push_back(q);
     *p = static_cast<T*>(q);
     return NAVGPU_OK;
   }
@@ -110,7 +138,7 @@ struct navgpu_fleet {
   }
   int foldEvents() {
     if (events.empty()) return NAVGPU_OK;
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(waitStream(stream));
     for (auto& e : events) {
       float ms = 0;
       HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
@@ -241,6 +269,26 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
     if (cm.obst) A(cm.obst_alt, (size_t)n * cm.cells_padded);
     if (cm.voxel) A(cm.voxel_alt, (size_t)n * cm.cells_padded);
   }
+#define AP(ptr, cnt)                              \
+  if ((rc = f->allocPinned(&(ptr), (cnt))) != 0) { \
+    navgpu_fleet_destroy(f);                       \
+    return rc;                                     \
+  }
+  AP(f->hp_obs, (size_t)n * cm.max_obs);
+  AP(f->hp_cnt, n);
+  AP(f->hp_used, n);
+  AP(f->hp_pts, (size_t)n * cm.max_points * 3);
+  AP(f->hp_fpw, (size_t)n * kMaxFootprint * 2);
+  AP(f->hp_pose, (size_t)n * 3);
+  AP(f->hp_shift, (size_t)n * 2);
+  AP(f->hp_state, n);
+  AP(f->hp_plan, (size_t)n * f->desc.max_plan * 2);
+  AP(f->hp_plan_cnt, n);
+  AP(f->hp_front, (size_t)n * 2);
+  AP(f->hp_align, n);
+  AP(f->hp_result, n);
+  f->pl.result = f->hp_result;  // k_select writes results straight into pinned host memory (72 B per robot)
+#undef AP
   A(f->d_bounds_tmp, (size_t)n * 4);
   A(f->d_boxes_tmp, (size_t)n * 4);
   A(f->d_explicit, 4);
@@ -270,7 +318,6 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   A(pl.counters, (size_t)n * 2);
   A(pl.osc_flags, n);
   A(pl.osc_prev, (size_t)n * 3);
-  A(pl.result, n);
   A(pl.traj, (size_t)n * pl.max_sim_steps * 3);
 #undef A
   f->h_origin.assign((size_t)n * 2, 0.0);
@@ -290,7 +337,7 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
     s.last_max_y = FLT_MAX;
   }
   hipError_t e = hipMemcpyAsync(cm.state, st.data(), sizeof(InstCostmapState) * n, hipMemcpyHostToDevice, f->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(f->stream);
+  if (e == hipSuccess) e = waitStream(f->stream);
   if (e != hipSuccess || checkLaunch() != NAVGPU_OK) {
     if (e != hipSuccess) g_last_error = std::string("fleet init: ") + hipGetErrorString(e);
     navgpu_fleet_destroy(f);
@@ -302,7 +349,7 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
 
 int navgpu_fleet_destroy(navgpu_fleet* f) {
   if (!f) return NAVGPU_ERR_INVALID;
-  if (f->stream) hipStreamSynchronize(f->stream);
+  if (f->stream) waitStream(f->stream);
   for (auto& e : f->events) {
     hipEventDestroy(e.a);
     hipEventDestroy(e.b);
@@ -312,13 +359,14 @@ int navgpu_fleet_destroy(navgpu_fleet* f) {
     hipEventDestroy(e.b);
   }
   for (void* p : f->allocs) hipFree(p);
+  for (void* p : f->pinned) hipHostFree(p);
   if (f->stream) hipStreamDestroy(f->stream);
   delete f;
   return NAVGPU_OK;
 }
 int navgpu_sync(navgpu_fleet* f) {
   if (!f) return NAVGPU_ERR_INVALID;
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   return NAVGPU_OK;
 }
 void* navgpu_stream(navgpu_fleet* f) { return f ? (void*)f->stream : nullptr; }
@@ -327,7 +375,7 @@ int navgpu_fleet_set_origin(navgpu_fleet* f, uint32_t first, uint32_t count, con
   if (!f || !xy || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
   memcpy(&f->h_origin[(size_t)first * 2], xy, sizeof(double) * 2 * count);
   HIP_TRY(hipMemcpyAsync(f->cm.origin + (size_t)first * 2, xy, sizeof(double) * 2 * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   return NAVGPU_OK;
 }
 
@@ -362,7 +410,7 @@ int navgpu_grid_upload(navgpu_fleet* f, int grid, uint32_t first, uint32_t count
   if (rc) return rc;
   HIP_TRY(hipMemcpy2DAsync((char*)base + (size_t)first * stride * elem, stride * elem, host, used * elem, used * elem, count,
                            hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   return NAVGPU_OK;
 }
 int navgpu_grid_download(navgpu_fleet* f, int grid, uint32_t first, uint32_t count, void* host) {
@@ -373,7 +421,7 @@ int navgpu_grid_download(navgpu_fleet* f, int grid, uint32_t first, uint32_t cou
   if (rc) return rc;
   HIP_TRY(hipMemcpy2DAsync(host, used * elem, (char*)base + (size_t)first * stride * elem, stride * elem, used * elem, count,
                            hipMemcpyDeviceToHost, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   return NAVGPU_OK;
 }
 int navgpu_grid_device(navgpu_fleet* f, int grid, void** ptr, size_t* stride_bytes) {
@@ -424,10 +472,10 @@ int navgpu_static_set_map(navgpu_fleet* f, uint32_t first, uint32_t count, const
   // has_updated_data_ = true for these instances
   std::vector<InstCostmapState> st(count);
   HIP_TRY(hipMemcpyAsync(st.data(), cm.state + first, sizeof(InstCostmapState) * count, hipMemcpyDeviceToHost, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   for (auto& s : st) s.static_has_updated_data = 1;
   HIP_TRY(hipMemcpyAsync(cm.state + first, st.data(), sizeof(InstCostmapState) * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   return checkLaunch();
 }
 
@@ -508,7 +556,7 @@ int navgpu_inflation_configure(navgpu_fleet* f, const navgpu_inflation_params* p
   }
   HIP_TRY(hipMemcpyAsync(cm.lut2, lut2.data(), lut2.size(), hipMemcpyHostToDevice, f->stream));
   cm.lut2_ok = lut2_ok ? 1 : 0;
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   const bool changed = !f->inflation_configured || f->infl.inflation_radius != p->inflation_radius ||
                        f->infl.cost_scaling_factor != p->cost_scaling_factor || f->infl.inscribed_radius != p->inscribed_radius ||
                        f->infl.enabled != p->enabled;
@@ -521,10 +569,10 @@ int navgpu_inflation_configure(navgpu_fleet* f, const navgpu_inflation_params* p
     const uint32_t nI = f->desc.n_instances;
     std::vector<InstCostmapState> st(nI);
     HIP_TRY(hipMemcpyAsync(st.data(), cm.state, sizeof(InstCostmapState) * nI, hipMemcpyDeviceToHost, f->stream));
-    HIP_TRY(hipStreamSynchronize(f->stream));
+    HIP_TRY(waitStream(f->stream));
     for (auto& s : st) s.need_reinflation = 1;
     HIP_TRY(hipMemcpyAsync(cm.state, st.data(), sizeof(InstCostmapState) * nI, hipMemcpyHostToDevice, f->stream));
-    HIP_TRY(hipStreamSynchronize(f->stream));
+    HIP_TRY(waitStream(f->stream));
   }
   return NAVGPU_OK;
 }
@@ -567,7 +615,7 @@ int navgpu_set_footprint(navgpu_fleet* f, uint32_t first, uint32_t count, const 
   HIP_TRY(hipMemcpyAsync(f->pl.fp_spec + (size_t)first * kMaxFootprint * 2, &f->h_fp_spec[(size_t)first * kMaxFootprint * 2],
                          sizeof(double) * kMaxFootprint * 2 * count, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(hipMemcpyAsync(f->pl.fp_n + first, &f->h_fp_n[first], sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   if (f->planner_configured) updateWindow(f);
   return NAVGPU_OK;
 }
@@ -576,17 +624,17 @@ int navgpu_costmap_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
                          uint32_t n_obs, const float* points, uint32_t n_points_total) {
   if (!f || !poses || !f->rangeOk(first, count) || (n_obs && (!obs || (!points && n_points_total)))) return NAVGPU_ERR_INVALID;
   CostmapDev& cm = f->cm;
-  std::vector<ObsCsr> h_obs((size_t)count * cm.max_obs);
-  std::vector<uint32_t> h_cnt(count, 0), h_pts_used(count, 0);
-  std::vector<float> h_pts((size_t)count * cm.max_points * 3, 0.f);
+  if (f->desc.rolling_window && f->shift_pending) return NAVGPU_ERR_STATE;  // previous stage not consumed by an update yet
+  HIP_TRY(waitStream(f->stream));  // the pinned mirrors may still feed an earlier copy
+  for (uint32_t li = 0; li < count; ++li) f->hp_cnt[first + li] = f->hp_used[first + li] = 0;
   for (uint32_t k = 0; k < n_obs; ++k) {
     const navgpu_observation& o = obs[k];
     if (o.instance < first || o.instance >= first + count) return NAVGPU_ERR_INVALID;
-    const uint32_t li = o.instance - first;
-    if (h_cnt[li] >= cm.max_obs || h_pts_used[li] + o.n_points > cm.max_points) return NAVGPU_ERR_CAPACITY;
+    const uint32_t i = o.instance;
+    if (f->hp_cnt[i] >= cm.max_obs || f->hp_used[i] + o.n_points > cm.max_points) return NAVGPU_ERR_CAPACITY;
     if ((uint64_t)o.first_point + o.n_points > n_points_total) return NAVGPU_ERR_INVALID;
-    ObsCsr& d = h_obs[(size_t)li * cm.max_obs + h_cnt[li]++];
-    d.first_point = h_pts_used[li];
+    ObsCsr& d = f->hp_obs[(size_t)i * cm.max_obs + f->hp_cnt[i]++];
+    d.first_point = f->hp_used[i];
     d.n_points = o.n_points;
     d.flags = o.flags;
     d.pad = 0;
@@ -596,14 +644,12 @@ int navgpu_costmap_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
     d.obstacle_range = o.obstacle_range;
     d.raytrace_range = o.raytrace_range;
     if (o.n_points)
-      memcpy(&h_pts[((size_t)li * cm.max_points + h_pts_used[li]) * 3], points + (size_t)o.first_point * 3, sizeof(float) * 3 * o.n_points);
-    h_pts_used[li] += o.n_points;
+      memcpy(&f->hp_pts[((size_t)i * cm.max_points + f->hp_used[i]) * 3], points + (size_t)o.first_point * 3, sizeof(float) * 3 * o.n_points);
+    f->hp_used[i] += o.n_points;
   }
   // rolling window: LayeredCostmap::updateMap :86-91 + Costmap2D::updateOrigin :264-276, evaluated here
   // in fp64 exactly as the reference does; the grids are shifted on the device by navgpu_costmap_update
   if (f->desc.rolling_window) {
-    if (f->shift_pending) return NAVGPU_ERR_STATE;  // previous stage not consumed by an update yet
-    std::vector<int32_t> h_shift((size_t)count * 2);
     const double size_m_x = (cm.nx - 1 + 0.5) * cm.res, size_m_y = (cm.ny - 1 + 0.5) * cm.res;  // getSizeInMetersX/Y
     for (uint32_t li = 0; li < count; ++li) {
       double& ox = f->h_origin[(size_t)(first + li) * 2];
@@ -612,36 +658,36 @@ int navgpu_costmap_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
       const int cell_ox = int((new_origin_x - ox) / cm.res), cell_oy = int((new_origin_y - oy) / cm.res);
       ox = ox + cell_ox * cm.res;
       oy = oy + cell_oy * cm.res;
-      h_shift[2 * li] = cell_ox;
-      h_shift[2 * li + 1] = cell_oy;
+      f->hp_shift[2 * (first + li)] = cell_ox;
+      f->hp_shift[2 * (first + li) + 1] = cell_oy;
     }
-    HIP_TRY(hipMemcpyAsync(cm.shift + (size_t)first * 2, h_shift.data(), sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(cm.shift + (size_t)first * 2, f->hp_shift + (size_t)first * 2, sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, f->stream));
     HIP_TRY(hipMemcpyAsync(cm.origin + (size_t)first * 2, &f->h_origin[(size_t)first * 2], sizeof(double) * 2 * count, hipMemcpyHostToDevice, f->stream));
-    HIP_TRY(hipStreamSynchronize(f->stream));
     f->shift_pending = true;
     f->shift_first = first;
     f->shift_count = count;
   }
   // transformFootprint (footprint.cpp:103-118) per instance, fp64 libm
-  std::vector<double> h_fpw((size_t)count * kMaxFootprint * 2, 0.0);
   for (uint32_t li = 0; li < count; ++li) {
     const uint32_t i = first + li;
     const double x = poses[3 * li], y = poses[3 * li + 1], th = poses[3 * li + 2];
+    f->hp_pose[3 * i] = x;
+    f->hp_pose[3 * i + 1] = y;
+    f->hp_pose[3 * i + 2] = th;
     const double cos_th = cos(th), sin_th = sin(th);
     for (uint32_t v = 0; v < f->h_fp_n[i]; ++v) {
       const double sx = f->h_fp_spec[((size_t)i * kMaxFootprint + v) * 2], sy = f->h_fp_spec[((size_t)i * kMaxFootprint + v) * 2 + 1];
-      h_fpw[((size_t)li * kMaxFootprint + v) * 2] = x + (sx * cos_th - sy * sin_th);
-      h_fpw[((size_t)li * kMaxFootprint + v) * 2 + 1] = y + (sx * sin_th + sy * cos_th);
+      f->hp_fpw[((size_t)i * kMaxFootprint + v) * 2] = x + (sx * cos_th - sy * sin_th);
+      f->hp_fpw[((size_t)i * kMaxFootprint + v) * 2 + 1] = y + (sx * sin_th + sy * cos_th);
     }
   }
-  HIP_TRY(hipMemcpyAsync(cm.pose + (size_t)first * 3, poses, sizeof(double) * 3 * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(cm.obs + (size_t)first * cm.max_obs, h_obs.data(), sizeof(ObsCsr) * h_obs.size(), hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(cm.obs_count + first, h_cnt.data(), sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(cm.points + (size_t)first * cm.max_points * 3, h_pts.data(), sizeof(float) * h_pts.size(), hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(cm.fp_world + (size_t)first * kMaxFootprint * 2, h_fpw.data(), sizeof(double) * h_fpw.size(), hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(cm.pose + (size_t)first * 3, f->hp_pose + (size_t)first * 3, sizeof(double) * 3 * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(cm.obs + (size_t)first * cm.max_obs, f->hp_obs + (size_t)first * cm.max_obs, sizeof(ObsCsr) * (size_t)count * cm.max_obs, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(cm.obs_count + first, f->hp_cnt + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(cm.points + (size_t)first * cm.max_points * 3, f->hp_pts + (size_t)first * cm.max_points * 3, sizeof(float) * 3 * (size_t)count * cm.max_points, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(cm.fp_world + (size_t)first * kMaxFootprint * 2, f->hp_fpw + (size_t)first * kMaxFootprint * 2, sizeof(double) * 2 * kMaxFootprint * (size_t)count, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(hipMemcpyAsync(cm.fp_n + first, &f->h_fp_n[first], sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));  // host vectors go out of scope
-  return NAVGPU_OK;
+  return NAVGPU_OK;  // copies stay in flight on the fleet's stream; the kernels are ordered behind them
 }
 
 int navgpu_costmap_update(navgpu_fleet* f, uint32_t first, uint32_t count) {
@@ -675,7 +721,7 @@ int navgpu_costmap_bounds(navgpu_fleet* f, uint32_t first, uint32_t count, int32
   if (!f || !boxes || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
   std::vector<InstCostmapState> st(count);
   HIP_TRY(hipMemcpyAsync(st.data(), f->cm.state + first, sizeof(InstCostmapState) * count, hipMemcpyDeviceToHost, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   for (uint32_t i = 0; i < count; ++i)
     for (int k = 0; k < 4; ++k) boxes[4 * i + k] = st[i].box[k];
   return NAVGPU_OK;
@@ -690,7 +736,7 @@ int navgpu_inflate(navgpu_fleet* f, uint32_t first, uint32_t count, const int32_
     d_boxes = f->d_boxes_tmp;
   }
   PROFILED(f, NAVGPU_K_INFLATE, launch_inflate(f->cm, first, count, d_boxes, f->stream));
-  if (boxes) HIP_TRY(hipStreamSynchronize(f->stream));  // d_boxes_tmp is reused by the next call
+  if (boxes) HIP_TRY(waitStream(f->stream));  // d_boxes_tmp is reused by the next call
   return checkLaunch();
 }
 
@@ -700,7 +746,7 @@ int navgpu_obstacle_update_bounds(navgpu_fleet* f, uint32_t first, uint32_t coun
   HIP_TRY(hipMemcpyAsync(f->d_bounds_tmp, bounds, sizeof(double) * 4 * count, hipMemcpyHostToDevice, f->stream));
   PROFILED(f, NAVGPU_K_OBSTACLE, launch_obstacle(f->cm, first, count, f->d_bounds_tmp, 1, f->stream));
   HIP_TRY(hipMemcpyAsync(bounds, f->d_bounds_tmp, sizeof(double) * 4 * count, hipMemcpyDeviceToHost, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   return checkLaunch();
 }
 
@@ -712,7 +758,7 @@ int navgpu_obstacle_update_costs(navgpu_fleet* f, uint32_t first, uint32_t count
     d_boxes = f->d_boxes_tmp;
   }
   PROFILED(f, NAVGPU_K_MERGE, launch_merge(f->cm, first, count, d_boxes, f->stream));
-  if (boxes) HIP_TRY(hipStreamSynchronize(f->stream));
+  if (boxes) HIP_TRY(waitStream(f->stream));
   return checkLaunch();
 }
 
@@ -746,7 +792,7 @@ int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
   const uint32_t max_samples = ax * ay * at;
   const uint32_t score_blocks = (max_samples + kScoreThreads - 1) / kScoreThreads;
   if (max_axis != pl.max_axis || max_samples != pl.max_samples) {
-    HIP_TRY(hipStreamSynchronize(f->stream));
+    HIP_TRY(waitStream(f->stream));
     f->release(pl.axis_samples);
     f->release(pl.part_cost);
     f->release(pl.part_index);
@@ -776,7 +822,7 @@ int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
   pl.scale_obstacle = pl.res * cfg.occdist_scale;
   f->planner_configured = true;
   updateWindow(f);
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   return NAVGPU_OK;
 }
 
@@ -792,30 +838,32 @@ int navgpu_planner_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
   if (!f->planner_configured) return NAVGPU_ERR_STATE;
   PlannerDev& pl = f->pl;
   const navgpu_dwa_config& c = pl.cfg;
-  std::vector<double> h_plan((size_t)count * pl.max_plan * 2, 0.0), h_front((size_t)count * 2);
-  std::vector<uint32_t> h_cnt(count);
-  std::vector<int32_t> h_align(count);
   for (uint32_t li = 0; li < count; ++li) {
     const navgpu_robot_state& s = states[li];
     if (s.plan_count == 0) return NAVGPU_ERR_INVALID;  // the ROS wrapper rejects empty plans before this point
     if (s.plan_count > pl.max_plan) return NAVGPU_ERR_CAPACITY;
     if ((uint64_t)s.plan_first + s.plan_count > n_plan_total) return NAVGPU_ERR_INVALID;
-    memcpy(&h_plan[(size_t)li * pl.max_plan * 2], plan_xy + (size_t)s.plan_first * 2, sizeof(double) * 2 * s.plan_count);
-    h_cnt[li] = s.plan_count;
+  }
+  HIP_TRY(waitStream(f->stream));  // the pinned mirrors may still feed an earlier copy
+  for (uint32_t li = 0; li < count; ++li) {
+    const uint32_t i = first + li;
+    const navgpu_robot_state& s = states[li];
+    f->hp_state[i] = s;
+    memcpy(&f->hp_plan[(size_t)i * pl.max_plan * 2], plan_xy + (size_t)s.plan_first * 2, sizeof(double) * 2 * s.plan_count);
+    f->hp_plan_cnt[i] = s.plan_count;
     // DWAPlanner::updatePlanAndLocalCosts (dwa_planner.cpp:254-285); pos is the float-narrowed pose
     const double gx = plan_xy[((size_t)s.plan_first + s.plan_count - 1) * 2], gy = plan_xy[((size_t)s.plan_first + s.plan_count - 1) * 2 + 1];
     const double sq_dist = (s.pos[0] - gx) * (s.pos[0] - gx) + (s.pos[1] - gy) * (s.pos[1] - gy);
     const double angle_to_goal = atan2(gy - s.pos[1], gx - s.pos[0]);
-    h_front[2 * li] = gx + c.forward_point_distance * cos(angle_to_goal);
-    h_front[2 * li + 1] = gy + c.forward_point_distance * sin(angle_to_goal);
-    h_align[li] = sq_dist > c.forward_point_distance * c.forward_point_distance * c.cheat_factor ? 1 : 0;
+    f->hp_front[2 * i] = gx + c.forward_point_distance * cos(angle_to_goal);
+    f->hp_front[2 * i + 1] = gy + c.forward_point_distance * sin(angle_to_goal);
+    f->hp_align[i] = sq_dist > c.forward_point_distance * c.forward_point_distance * c.cheat_factor ? 1 : 0;
   }
-  HIP_TRY(hipMemcpyAsync(pl.state + first, states, sizeof(navgpu_robot_state) * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(pl.plan + (size_t)first * pl.max_plan * 2, h_plan.data(), sizeof(double) * h_plan.size(), hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(pl.plan_count + first, h_cnt.data(), sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(pl.front_last + (size_t)first * 2, h_front.data(), sizeof(double) * 2 * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(pl.align_on + first, h_align.data(), sizeof(int32_t) * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(hipMemcpyAsync(pl.state + first, f->hp_state + first, sizeof(navgpu_robot_state) * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(pl.plan + (size_t)first * pl.max_plan * 2, f->hp_plan + (size_t)first * pl.max_plan * 2, sizeof(double) * 2 * (size_t)count * pl.max_plan, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(pl.plan_count + first, f->hp_plan_cnt + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(pl.front_last + (size_t)first * 2, f->hp_front + (size_t)first * 2, sizeof(double) * 2 * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(pl.align_on + first, f->hp_align + first, sizeof(int32_t) * count, hipMemcpyHostToDevice, f->stream));
   f->planner_staged = true;
   return NAVGPU_OK;
 }
@@ -834,20 +882,30 @@ int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
 
 int navgpu_planner_results(navgpu_fleet* f, uint32_t first, uint32_t count, navgpu_plan_result* results) {
   if (!f || !results || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
-  HIP_TRY(hipMemcpyAsync(results, f->pl.result + first, sizeof(navgpu_plan_result) * count, hipMemcpyDeviceToHost, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  // zero-copy: the results already sit in pinned host memory once the stream has drained (an explicit
+  // D2H copy was measured at ~4 ms per call when another HIP user, e.g. PyTorch, shares the process)
+  static const bool dbg = getenv("NAVGPU_DEBUG_TIMING") != nullptr;
+  timespec t0, t1, t2;
+  if (dbg) clock_gettime(CLOCK_MONOTONIC, &t0);
+  HIP_TRY(waitStream(f->stream));
+  if (dbg) clock_gettime(CLOCK_MONOTONIC, &t1);
+  memcpy(results, f->hp_result + first, sizeof(navgpu_plan_result) * count);
+  if (dbg) {
+    clock_gettime(CLOCK_MONOTONIC, &t2);
+    fprintf(stderr, "results: wait %.3f ms, memcpy %.3f ms\n", (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6,
+            (t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_nsec - t1.tv_nsec) * 1e-6);
+  }
   return NAVGPU_OK;
 }
 
 int navgpu_planner_trajectory(navgpu_fleet* f, uint32_t instance, double* xyth, uint32_t cap) {
   if (!f || !xyth || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
-  navgpu_plan_result r;
-  HIP_TRY(hipMemcpyAsync(&r, f->pl.result + instance, sizeof(r), hipMemcpyDeviceToHost, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
+  const navgpu_plan_result r = f->hp_result[instance];
   uint32_t n = std::min<uint32_t>(r.n_points > 0 ? r.n_points : 0, cap);
   if (n) {
     HIP_TRY(hipMemcpyAsync(xyth, f->pl.traj + (size_t)instance * f->pl.max_sim_steps * 3, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, f->stream));
-    HIP_TRY(hipStreamSynchronize(f->stream));
+    HIP_TRY(waitStream(f->stream));
   }
   return r.n_points;
 }
@@ -858,13 +916,13 @@ int navgpu_planner_samples(navgpu_fleet* f, uint32_t instance, double* costs, in
   if (!pl.sample_cost) return NAVGPU_ERR_STATE;
   int32_t cnt[4];
   HIP_TRY(hipMemcpyAsync(cnt, pl.axis_count + 4 * instance, sizeof(cnt), hipMemcpyDeviceToHost, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   const uint32_t n = std::min<uint32_t>(cnt[3], cap);
   if (costs && n) HIP_TRY(hipMemcpyAsync(costs, pl.sample_cost + (size_t)instance * pl.max_samples, sizeof(double) * n, hipMemcpyDeviceToHost, f->stream));
   if (status && n) HIP_TRY(hipMemcpyAsync(status, pl.sample_status + (size_t)instance * pl.max_samples, sizeof(int32_t) * n, hipMemcpyDeviceToHost, f->stream));
   std::vector<float> ax((size_t)3 * pl.max_axis);
   if (vel && n) HIP_TRY(hipMemcpyAsync(ax.data(), pl.axis_samples + (size_t)instance * 3 * pl.max_axis, sizeof(float) * ax.size(), hipMemcpyDeviceToHost, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   if (vel)
     for (uint32_t s = 0; s < n; ++s) {
       const int ix = s / (cnt[1] * cnt[2]), rem = s - ix * (cnt[1] * cnt[2]), iy = rem / cnt[2], it = rem - iy * cnt[2];
@@ -887,7 +945,7 @@ int navgpu_planner_check_trajectory(navgpu_fleet* f, uint32_t instance, const fl
   int idx;
   HIP_TRY(hipMemcpyAsync(&cost, pl.part_cost + (size_t)instance * pl.score_blocks, sizeof(double), hipMemcpyDeviceToHost, f->stream));
   HIP_TRY(hipMemcpyAsync(&idx, pl.part_index + (size_t)instance * pl.score_blocks, sizeof(int), hipMemcpyDeviceToHost, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   *ok = (idx != 0x7FFFFFFF) ? 1 : 0;
   return checkLaunch();
 }
@@ -896,14 +954,14 @@ int navgpu_planner_get_oscillation(navgpu_fleet* f, uint32_t first, uint32_t cou
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
   if (flags) HIP_TRY(hipMemcpyAsync(flags, f->pl.osc_flags + first, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, f->stream));
   if (prev) HIP_TRY(hipMemcpyAsync(prev, f->pl.osc_prev + (size_t)first * 3, sizeof(float) * 3 * count, hipMemcpyDeviceToHost, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   return NAVGPU_OK;
 }
 int navgpu_planner_set_oscillation(navgpu_fleet* f, uint32_t first, uint32_t count, const uint32_t* flags, const float* prev) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
   if (flags) HIP_TRY(hipMemcpyAsync(f->pl.osc_flags + first, flags, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
   if (prev) HIP_TRY(hipMemcpyAsync(f->pl.osc_prev + (size_t)first * 3, prev, sizeof(float) * 3 * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipStreamSynchronize(f->stream));
+  HIP_TRY(waitStream(f->stream));
   return NAVGPU_OK;
 }
 

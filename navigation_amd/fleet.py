@@ -219,6 +219,13 @@ class Fleet:
         check(self.L.navgpu_planner_results(self.h, first, count, C.cast(r, C.c_void_p)), "planner_results")
         return list(r)
 
+    def results_into(self, buf, first=0):
+        """Same as results() but into a caller-owned (PlanResult * count) array: no Python allocation on
+        the per-cycle path (a list of 256 fresh ctypes objects per call makes the interpreter's garbage
+        collector the slowest part of a cycle once a large package such as torch is imported)."""
+        check(self.L.navgpu_planner_results(self.h, first, len(buf), C.cast(buf, C.c_void_p)), "planner_results")
+        return buf
+
     def find_best_path(self, pos, vel, plans, first=0):
         pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
         self.stage_planner(pos, vel, plans, first)
