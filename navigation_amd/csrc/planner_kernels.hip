@@ -332,8 +332,8 @@ __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
       uint32_t lw[RPT], rw[RPT];
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
-        lw[k] = cur[base_p + k * Wp - 1];
-        rw[k] = cur[base_p + k * Wp + 1];
+        lw[k] = (pl.debug & 64u) ? 0u : cur[base_p + k * Wp - 1];
+        rw[k] = (pl.debug & 64u) ? 0u : cur[base_p + k * Wp + 1];
       }
       uint32_t cand[RPT];
 #pragma unroll
@@ -351,7 +351,8 @@ __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
         any |= nf;
         nxt[base_p + k * Wp] = nf;
       }
-      if (lvl1 < (1u << kPlanes)) {
+      if (pl.debug & 16u) {
+      } else if (lvl1 < (1u << kPlanes)) {
 #pragma unroll
         for (int b = 0; b < kPlanes; ++b) {
           if (lvl1 & (1u << b)) {  // wave-uniform
@@ -375,10 +376,15 @@ __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
         }
       }
     }
-    if (any) s_flag[level % 3] = 1;
-    if (tid == 0) s_flag[(level + 1) % 3] = 0;
-    __syncthreads();
-    if (!s_flag[level % 3]) break;
+    if (pl.debug & 32u) {  // timing ablation: fixed 570 levels, no termination flag
+      __syncthreads();
+      if (level >= 570) break;
+    } else {
+      if (any) s_flag[level % 3] = 1;
+      if (tid == 0) s_flag[(level + 1) % 3] = 0;
+      __syncthreads();
+      if (!s_flag[level % 3]) break;
+    }
     uint32_t* t = cur;
     cur = nxt;
     nxt = t;
@@ -585,7 +591,9 @@ size_t bfs_scratch_words(uint32_t nx, uint32_t ny) {  // per instance, for k_bfs
   return bfs_lds_resident(nx, ny) ? 0 : (size_t)3 * 4 * ny * ((nx + 31) / 32);
 }
 
-void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
+void launch_bfs(const PlannerDev& pl_in, uint32_t first, uint32_t count, hipStream_t s) {
+  PlannerDev pl = pl_in;
+  if (const char* e = getenv("NAVGPU_DEBUG_BFS")) pl.debug = (uint32_t)atoi(e);  // timing ablations only
   dim3 grid(3, count);
   const size_t lds = bfs_lds_bytes(pl.nx, pl.ny);  // dense bit-parallel sweep (no LDS atomics in the loop)
   const int rpt = bfs_rows_per_thread(pl.nx, pl.ny);
