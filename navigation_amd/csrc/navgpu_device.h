@@ -98,6 +98,7 @@ struct PlannerDev {
   uint32_t *path, *goal, *goal_front;  // [n][cells] each
   uint32_t* bfs_scratch;      // k_bfs_global bitmaps (only for grids too large for LDS)
   uint32_t win;               // edge (cells) of the costmap window staged in LDS by k_score
+  uint32_t fp_rcells;         // Chebyshev radius (cells) that contains every footprint cell around the centre cell
   uint32_t use_tables, tab_steps, tab_nfp, tab_nth;
   uint32_t debug;             // timing ablation bits (NAVGPU_DEBUG_SCORE), 0 in product use  // k_score<TABLES>: shared per-(v_theta, step) tables in LDS
   double* sample_cost;        // [n][max_samples] or null

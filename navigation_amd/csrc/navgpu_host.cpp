@@ -590,6 +590,7 @@ static void updateWindow(navgpu_fleet* f) {
   double cells = ceil(reach / f->pl.res) + 2;
   uint32_t win = (uint32_t)std::min(cells * 2 + 1, 240.0);
   f->pl.win = win;
+  f->pl.fp_rcells = (uint32_t)ceil(f->fp_radius / f->pl.res) + 1;  // vertex cells lie within this Chebyshev radius of the centre cell
   // shared heading tables (k_score<TABLES>): constant velocity + fixed step count only
   uint32_t max_nfp = 0;
   for (uint32_t v : f->h_fp_n) max_nfp = std::max(max_nfp, v);
@@ -598,7 +599,7 @@ static void updateWindow(navgpu_fleet* f) {
     f->pl.tab_steps = (uint32_t)ceil(c.sim_time / c.sim_granularity);
     f->pl.tab_nfp = max_nfp;
     f->pl.tab_nth = (uint32_t)std::max(c.vth_samples, 2) + 1;
-    const size_t lds = (((size_t)win * win + 15) & ~(size_t)15) + score_table_bytes(f->pl);
+    const size_t lds = 3 * (((size_t)win * win + 15) & ~(size_t)15) + score_table_bytes(f->pl);
     if (f->pl.tab_steps >= 1 && f->pl.tab_steps <= f->pl.max_sim_steps && lds <= 60 * 1024) f->pl.use_tables = 1;
   }
 }

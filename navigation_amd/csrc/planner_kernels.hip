@@ -332,8 +332,8 @@ __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
       uint32_t lw[RPT], rw[RPT];
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
-        lw[k] = (pl.debug & 64u) ? 0u : cur[base_p + k * Wp - 1];
-        rw[k] = (pl.debug & 64u) ? 0u : cur[base_p + k * Wp + 1];
+        lw[k] = cur[base_p + k * Wp - 1];
+        rw[k] = cur[base_p + k * Wp + 1];
       }
       uint32_t cand[RPT];
 #pragma unroll
@@ -351,8 +351,7 @@ __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
         any |= nf;
         nxt[base_p + k * Wp] = nf;
       }
-      if (pl.debug & 16u) {
-      } else if (lvl1 < (1u << kPlanes)) {
+      if (lvl1 < (1u << kPlanes)) {
 #pragma unroll
         for (int b = 0; b < kPlanes; ++b) {
           if (lvl1 & (1u << b)) {  // wave-uniform
@@ -376,15 +375,10 @@ __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
         }
       }
     }
-    if (pl.debug & 32u) {  // timing ablation: fixed 570 levels, no termination flag
-      __syncthreads();
-      if (level >= 570) break;
-    } else {
-      if (any) s_flag[level % 3] = 1;
-      if (tid == 0) s_flag[(level + 1) % 3] = 0;
-      __syncthreads();
-      if (!s_flag[level % 3]) break;
-    }
+    if (any) s_flag[level % 3] = 1;
+    if (tid == 0) s_flag[(level + 1) % 3] = 0;
+    __syncthreads();
+    if (!s_flag[level % 3]) break;
     uint32_t* t = cur;
     cur = nxt;
     nxt = t;
@@ -591,9 +585,7 @@ size_t bfs_scratch_words(uint32_t nx, uint32_t ny) {  // per instance, for k_bfs
   return bfs_lds_resident(nx, ny) ? 0 : (size_t)3 * 4 * ny * ((nx + 31) / 32);
 }
 
-void launch_bfs(const PlannerDev& pl_in, uint32_t first, uint32_t count, hipStream_t s) {
-  PlannerDev pl = pl_in;
-  if (const char* e = getenv("NAVGPU_DEBUG_BFS")) pl.debug = (uint32_t)atoi(e);  // timing ablations only
+void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
   dim3 grid(3, count);
   const size_t lds = bfs_lds_bytes(pl.nx, pl.ny);  // dense bit-parallel sweep (no LDS atomics in the loop)
   const int rpt = bfs_rows_per_thread(pl.nx, pl.ny);
@@ -689,11 +681,35 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       s_win[i] = v;
     }
   }
+  // ---- free-space shortcut: a footprint whose centre cell has nothing but FREE_SPACE within the
+  // Chebyshev radius fp_rcells (>= circumscribed radius in cells + 1) touches only cost-0 cells, so
+  // ObstacleCostFunction's step cost is exactly 0 and no edge has to be walked.  Separable max filter
+  // of the window, once per workgroup.
+  const int win_bytes = (win * win + 15) & ~15;
+  uint8_t* s_m1 = s_dyn + win_bytes;        // row-wise OR of the window over +-fp_rcells
+  uint8_t* s_free = s_dyn + 2 * win_bytes;  // 0 where the whole (2*fp_rcells+1)^2 square around the cell is FREE_SPACE
+  const int rc = (int)pl.fp_rcells;
+  __syncthreads();
+  for (int i = tid; i < win * win; i += blockDim.x) {
+    const int ly = i / win, lx = i - ly * win;
+    uint8_t m = (lx - rc < 0 || lx + rc >= win) ? 255 : 0;  // squares leaving the window are never "free"
+    if (!m)
+      for (int d = -rc; d <= rc; ++d) m |= s_win[i + d];
+    s_m1[i] = m;
+  }
+  __syncthreads();
+  for (int i = tid; i < win * win; i += blockDim.x) {
+    const int ly = i / win;
+    uint8_t m = (ly - rc < 0 || ly + rc >= win) ? 255 : 0;
+    if (!m)
+      for (int d = -rc; d <= rc; ++d) m |= s_m1[i + d * win];
+    s_free[i] = m;
+  }
   // ---- TABLES: per-(v_theta sample, step) heading, trig, rotated footprint, forward-point offset
   const int K = TABLES ? (int)pl.tab_steps : 0;
   const int tnfp = TABLES ? (int)pl.tab_nfp : 0;
   const int nth_s = TABLES ? cnt[2] : 0;
-  double* s_trig = reinterpret_cast<double*>(s_dyn + ((win * win + 15) & ~15));  // [nth][K][4] cs, sn, cs2, sn2
+  double* s_trig = reinterpret_cast<double*>(s_dyn + 3 * win_bytes);  // [nth][K][4] cs, sn, cs2, sn2
   double* s_rot = s_trig + (size_t)pl.tab_nth * K * 4;                            // [nth][K][tnfp][2]
   float* s_th = reinterpret_cast<float*>(s_rot + (size_t)pl.tab_nth * K * tnfp * 2);  // [nth][K]
   if (TABLES) {
@@ -872,7 +888,12 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           }
           uint32_t cx = 0, cy = 0;
           const bool ok_c = w2m(x, y, cx, cy);
-          if (live_obs && !(pl.debug & 2u)) {
+          bool all_free = false;
+          if (live_obs && ok_c && nfp >= 3 && inWin((int)cx, (int)cy) && !(pl.debug & 4u))
+            all_free = s_free[((int)cy - wy0) * win + ((int)cx - wx0)] == 0;
+          if (live_obs && all_free) {
+            v_obs = c.sum_scores ? v_obs + 0.0 : 0.0;
+          } else if (live_obs && !(pl.debug & 2u)) {
             double f_cost = 0.0;
             bool bad = !ok_c;  // CostmapModel::footprintCost: centre off the map -> -1
             if (!bad) {
@@ -1161,7 +1182,7 @@ uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, c
   if (const char* e = getenv("NAVGPU_DEBUG_SCORE")) pl.debug = (uint32_t)atoi(e);          // timing ablations only
   if (const char* e = getenv("NAVGPU_DEBUG_SCORE_LDS")) extra_lds = (size_t)atoi(e);       // occupancy experiments only
   if (const char* e = getenv("NAVGPU_DEBUG_NO_TABLES")) pl.use_tables = atoi(e) ? 0 : pl.use_tables;
-  const size_t win_bytes = (((size_t)pl.win * pl.win + 15) & ~(size_t)15) + extra_lds;
+  const size_t win_bytes = 3 * (((size_t)pl.win * pl.win + 15) & ~(size_t)15) + extra_lds;  // window + two filter planes
   if (explicit_sample) {
     hipLaunchKernelGGL(k_score_explicit, dim3(1, count), dim3(kScoreThreads), win_bytes, s, pl, first, explicit_sample);
     return 1;
