@@ -419,6 +419,336 @@ __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_bfs_wave: the strip sweep of k_bfs with the lanes of a wave laid out as whole row segments
+// (W bitmap words + one idle separator lane per strip), so the left/right neighbour words come from
+// the adjacent LANES (DPP wave shifts, plain VALU) and only the first/last row of every strip goes
+// through LDS.  A wave none of whose lanes holds or borders a frontier cell skips the level.  The
+// candidate mask is `& ~blocked` with blocked = obstacle | outside | reached, so every candidate is a
+// free cell; the obstacle cells TOUCHED by an expanded cell (map_grid.cpp:195-215: they get
+// obstacleCosts()) are found once, after the sweep, as the obstacle neighbours of the expanded set.
+// ------------------------------------------------------------------------------------------------
+// free-cell bitmap word of one map row (bit b = cell wi*32+b is traversable)
+__device__ __forceinline__ uint32_t bfsFreeWord(const uint8_t* master, uint32_t row, uint32_t nx, uint32_t wi,
+                                                uint32_t unknown_is_obstacle) {
+  const uint32_t nb = min(32u, nx - wi * 32);
+  uint32_t bits = 0;
+  if ((nx & 3) == 0) {
+    const uint32_t* p4 = reinterpret_cast<const uint32_t*>(master + row * nx + wi * 32);
+    for (uint32_t q = 0; q < nb / 4; ++q) {
+      const uint32_t v = p4[q];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t cst = (v >> (8 * j)) & 0xFFu;
+        const bool obstacle = cst == kLethal || cst == kInscribed || (cst == kNoInfo && unknown_is_obstacle);
+        bits |= (obstacle ? 0u : 1u) << (4 * q + j);
+      }
+    }
+  } else {
+    const uint8_t* p = master + row * nx + wi * 32;
+    for (uint32_t b = 0; b < nb; ++b) {
+      const uint32_t cst = p[b];
+      const bool obstacle = cst == kLethal || cst == kInscribed || (cst == kNoInfo && unknown_is_obstacle);
+      bits |= (obstacle ? 0u : 1u) << b;
+    }
+  }
+  return bits;
+}
+// value of the lane below / above in the wave (0 at the wave's ends)
+__device__ __forceinline__ uint32_t fromLaneBelow(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t fromLaneAbove(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+}
+
+template <int RPT>
+__global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first) {
+  extern __shared__ __align__(16) uint32_t sm[];
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_flag[3];
+  const int which = blockIdx.x;
+  const uint32_t inst = first + blockIdx.y;
+  const uint32_t tid = threadIdx.x;
+  const Geom g = geomOf(pl, inst);
+  const uint32_t nx = pl.nx, ny = pl.ny, W = (nx + 31) >> 5;
+  const uint32_t strips = (ny + RPT - 1) / RPT;
+  const uint32_t L = W + 1, spw = 64u / L;  // lanes per strip (one separator), strips per wave
+  const uint32_t lane = tid & 63u, slot = lane / L;
+  const uint32_t strip_of = (tid >> 6) * spw + slot;
+  const bool owner = slot < spw && lane - slot * L < W && strip_of < strips;
+  const uint32_t wi = owner ? lane - slot * L : 0u;
+  const uint32_t strip = owner ? strip_of : strips;  // everyone else reads/writes the zero border strip
+  const uint32_t r0 = strip * RPT;
+  // LDS: seed bitmap, late bitmap (both [rows][W]), two edge buffers [strips + 2][first,last][W]
+  const uint32_t rows_p = strips * RPT;
+  uint32_t* seedm = sm;
+  uint32_t* late = sm + rows_p * W;
+  uint32_t* edge = sm + 2 * rows_p * W;
+  const uint32_t edge_words = (strips + 2) * 2 * W;
+  const uint8_t* master = pl.master + (size_t)inst * pl.cells_padded;
+  uint32_t* dist = (which == 0 ? pl.path : (which == 1 ? pl.goal : pl.goal_front)) + (size_t)inst * pl.cells;
+  const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
+  const uint32_t unknown_is_obstacle = pl.cfg.allow_unknown != 0 ? 0u : 1u;
+  const uint32_t last_mask = (nx & 31) ? ((1u << (nx & 31)) - 1u) : 0xFFFFFFFFu;
+  const uint32_t col_mask = (wi + 1 == W) ? last_mask : 0xFFFFFFFFu;
+  const bool aligned4 = (nx & 3) == 0;
+
+  for (uint32_t i = tid; i < 2 * rows_p * W + 2 * edge_words; i += blockDim.x) sm[i] = 0;
+  if (tid < 3) s_flag[tid] = 0;
+  __syncthreads();
+
+  // --- seeds from the plan (as k_bfs)
+  {
+    const uint32_t n = pl.plan_count[inst];
+    const double* P = pl.plan + (size_t)inst * pl.max_plan * 2;
+    const bool ovr = which == 2;
+    const double lx = pl.front_last[2 * inst], ly = pl.front_last[2 * inst + 1];
+    const uint32_t chunk = (n + blockDim.x - 1) / blockDim.x;
+    const uint32_t i0 = min(n, tid * chunk), i1 = min(n, i0 + chunk);
+    uint32_t mine = 0;
+    for (uint32_t i = i0; i < i1; ++i) mine += adjustedPoints(P, i, lx, ly, ovr, n, g.res, true, [](uint32_t, double, double) {});
+    uint32_t total;
+    const uint32_t base = blockExclusiveScan1024(mine, s_wave, &total);
+    auto valid = [&](double x, double y, uint32_t& cell) {
+      uint32_t mx, my;
+      if (!worldToMap(g, x, y, mx, my)) return false;
+      cell = my * nx + mx;
+      return master[cell] != kNoInfo;
+    };
+    uint32_t fmin_ = 0xFFFFFFFFu, b = base;
+    for (uint32_t i = i0; i < i1; ++i)
+      b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+        uint32_t cell;
+        if (valid(x, y, cell)) fmin_ = min(fmin_, b + k);
+      });
+    const uint32_t f = blockMin1024(fmin_, s_wave);
+    if (f != 0xFFFFFFFFu) {
+      uint32_t emin = total;
+      b = base;
+      for (uint32_t i = i0; i < i1; ++i)
+        b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+          uint32_t cell;
+          if (b + k > f && !valid(x, y, cell)) emin = min(emin, b + k);
+        });
+      const uint32_t e = blockMin1024(emin, s_wave);
+      b = base;
+      for (uint32_t i = i0; i < i1; ++i)
+        b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+          const uint32_t idx = b + k;
+          const bool seed = (which == 0) ? (idx >= f && idx < e) : (idx == e - 1);
+          if (!seed) return;
+          uint32_t cell;
+          if (!valid(x, y, cell)) return;
+          const uint32_t my = cell / nx, mx = cell - my * nx;
+          atomicOr(&seedm[my * W + (mx >> 5)], 1u << (mx & 31));  // a few hundred seeds, once
+        });
+    }
+  }
+  __syncthreads();
+
+  uint32_t blocked[RPT], fr[RPT];
+  uint32_t plane[kPlanes][RPT];
+#pragma unroll
+  for (int b = 0; b < kPlanes; ++b)
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) plane[b][k] = 0;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    blocked[k] = 0xFFFFFFFFu;  // rows beyond the grid and idle lanes never take part
+    fr[k] = 0;
+    const uint32_t row = r0 + k;
+    if (owner && row < ny) {
+      fr[k] = seedm[row * W + wi];  // seeds expand whatever their cost (map_grid.cpp:160-187)
+      blocked[k] = ~(bfsFreeWord(master, row, nx, wi, unknown_is_obstacle) & col_mask) | fr[k];
+    }
+  }
+  // edge rows of the frontier: E(buffer, strip s, first/last, wi); strip index shifted by one (zero border)
+  const uint32_t e_mine = (strip + 1) * 2 * W + wi;
+  const uint32_t e_top = strip * 2 * W + W + wi;        // last row of the strip above
+  const uint32_t e_bot = (strip + 2) * 2 * W + wi;      // first row of the strip below
+  uint32_t* ecur = edge;
+  uint32_t* enxt = edge + edge_words;
+  if (owner) {
+    ecur[e_mine] = fr[0];
+    ecur[e_mine + W] = fr[RPT - 1];
+  }
+  __syncthreads();
+
+  // --- level-synchronous expansion, ONE barrier per level (three rotating "anything new" flags).
+  // Levels are recorded bit-sliced relative to an epoch of 2^kPlanes - 1 levels; in the rare case of a
+  // longer search the cells of a finished epoch are written out and the planes start again.
+  const uint32_t base_w = r0 * W + wi;
+  constexpr uint32_t kEpoch = (1u << kPlanes) - 1u;
+  constexpr int kLow = 3;  // planes 0..2 are updated every level, the others once per block of 8 levels
+  uint32_t level = 0, epoch_base = 0;
+  uint32_t bstart[RPT];    // `blocked` at the start of the current block
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) bstart[k] = blocked[k];
+  auto closeBlock = [&](uint32_t hi) {  // cells reached since the block began get the block's high bits
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const uint32_t got = blocked[k] & ~bstart[k];
+      bstart[k] = blocked[k];
+#pragma unroll
+      for (int b = kLow; b < kPlanes; ++b)
+        if ((hi >> (b - kLow)) & 1u) plane[b][k] |= got;
+    }
+  };
+  // one neighbour-expansion of row k: fc = the row's frontier, up/down = the rows above/below
+  auto expandRow = [&](int k, uint32_t fc, uint32_t up, uint32_t down) -> uint32_t {
+    const uint32_t lwv = fromLaneBelow(fc), rwv = fromLaneAbove(fc);
+    const uint32_t x = __builtin_amdgcn_alignbit(fc, lwv, 31) | __builtin_amdgcn_alignbit(rwv, fc, 1) | up;
+    const uint32_t cand = (x | down) & ~blocked[k];
+    blocked[k] = blocked[k] | x | down;
+    return cand;
+  };
+  uint32_t group = 0, any_grp = 0;  // termination is checked once per block of 2^kLow levels
+  while (true) {
+    bool done = false;
+    uint32_t code = 0;
+    while (true) {
+      code = level + 1 - epoch_base;  // 1..kEpoch: distance of this round's cells, relative to the epoch
+      const uint32_t top = ecur[e_top], bot = ecur[e_bot];
+      // rows 1..RPT-2 first: they do not wait for the LDS reads
+      const uint32_t old_first = fr[0], old_second = fr[1], old_before_last = fr[RPT - 2];
+      uint32_t prev = old_first, held = 0;
+#pragma unroll
+      for (int k = 1; k < RPT - 1; ++k) {
+        const uint32_t fc = fr[k];
+        const uint32_t cand = expandRow(k, fc, prev, fr[k + 1]);
+        prev = fc;
+        if (k > 1) fr[k - 1] = held;  // row k-1's new frontier, once row k has used the old one
+        held = cand;
+      }
+      fr[RPT - 2] = held;
+      fr[0] = expandRow(0, old_first, top, old_second);
+      fr[RPT - 1] = expandRow(RPT - 1, fr[RPT - 1], old_before_last, bot);
+      enxt[e_mine] = fr[0];
+      enxt[e_mine + W] = fr[RPT - 1];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) any_grp |= fr[k];
+#pragma unroll
+      for (int b = 0; b < kLow; ++b) {
+        if (code & (1u << b)) {  // wave-uniform
+          asm volatile("" ::: "memory");  // keep it a branch: half of these are skipped
+#pragma unroll
+          for (int k = 0; k < RPT; ++k) plane[b][k] |= fr[k];
+        }
+      }
+      const bool group_end = (code & ((1u << kLow) - 1u)) == (1u << kLow) - 1u;
+      if (group_end) {
+        closeBlock(code >> kLow);
+        if (any_grp) s_flag[group % 3] = 1;
+        if (tid == 0) s_flag[(group + 1) % 3] = 0;
+      }
+      __syncthreads();
+      uint32_t* t = ecur;
+      ecur = enxt;
+      enxt = t;
+      ++level;
+      if (group_end) {
+        done = !s_flag[group % 3];  // nothing new in a whole block of levels: the search is over
+        ++group;
+        any_grp = 0;
+        if (done || code == kEpoch) break;
+      }
+    }
+    if (done) break;
+    // epoch full: write its cells out, remember them in `late`, restart the planes
+    {
+      uint32_t cell0 = r0 * nx + wi * 32;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int b = 0; b < kPlanes; ++b) m |= plane[b][k];
+        if (m) late[base_w + k * W] |= m;
+        while (m) {
+          const uint32_t bpos = (uint32_t)__ffs(m) - 1u;
+          m &= m - 1;
+          uint32_t code = 0;
+#pragma unroll
+          for (int b = 0; b < kPlanes; ++b) code |= ((plane[b][k] >> bpos) & 1u) << b;
+          dist[cell0 + k * nx + bpos] = epoch_base + code;
+        }
+#pragma unroll
+        for (int b = 0; b < kPlanes; ++b) plane[b][k] = 0;
+      }
+      epoch_base += kEpoch;
+    }
+  }
+
+  // --- expanded set = reached free cells + seeds; its obstacle neighbours were touched
+  uint32_t ex[RPT], freeb[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const uint32_t row = r0 + k;
+    const bool in = owner && row < ny;
+    freeb[k] = in ? (bfsFreeWord(master, row, nx, wi, unknown_is_obstacle) & col_mask) : 0u;
+    ex[k] = in ? ((blocked[k] & freeb[k]) | seedm[row * W + wi]) : 0u;
+  }
+  if (owner) {
+    enxt[e_mine] = ex[0];
+    enxt[e_mine + W] = ex[RPT - 1];
+  }
+  __syncthreads();
+  {
+    uint32_t prev = enxt[e_top];
+    const uint32_t bot = enxt[e_bot];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const uint32_t fc = ex[k];
+      const uint32_t lwv = fromLaneBelow(fc), rwv = fromLaneAbove(fc);
+      const uint32_t d = k + 1 < RPT ? ex[k + 1 < RPT ? k + 1 : 0] : bot;
+      const uint32_t nb = (fc << 1) | (lwv >> 31) | (fc >> 1) | (rwv << 31) | prev | d;
+      prev = fc;
+      blocked[k] = nb & ~freeb[k] & ~fc & col_mask;  // reuse: the touched obstacle cells
+    }
+  }
+  // --- decode: expanded -> level (0 for seeds); touched obstacle -> obstacleCosts(); else unreachableCellCosts()
+  if (owner) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      if (r0 + k >= ny) continue;
+      const uint32_t exk = ex[k], tk = blocked[k], lt = late[base_w + k * W];
+      uint32_t* drow = dist + (r0 + k) * nx + wi * 32;
+      const uint32_t nb = min(32u, nx - wi * 32);
+      auto value = [&](uint32_t bpos) -> uint32_t {
+        uint32_t lvl = 0;
+#pragma unroll
+        for (int b = 0; b < kPlanes; ++b) lvl |= ((plane[b][k] >> bpos) & 1u) << b;
+        if ((exk >> bpos) & 1u) return lvl ? epoch_base + lvl : 0u;  // relative code 0 == a seed
+        return ((tk >> bpos) & 1u) ? N_obst : N_unreach;
+      };
+      if (aligned4 && lt == 0) {
+        for (uint32_t q = 0; q < nb / 4; ++q) {
+          uint4 v;
+          v.x = value(4 * q);
+          v.y = value(4 * q + 1);
+          v.z = value(4 * q + 2);
+          v.w = value(4 * q + 3);
+          *reinterpret_cast<uint4*>(drow + 4 * q) = v;
+        }
+      } else {
+        for (uint32_t bpos = 0; bpos < nb; ++bpos)
+          if (!((lt >> bpos) & 1u)) drow[bpos] = value(bpos);
+      }
+    }
+  }
+}
+// k_bfs_wave applies when all strips fit the 16 waves of one workgroup
+static bool bfs_wave_fits(uint32_t nx, uint32_t ny, int rpt) {
+  const uint32_t W = (nx + 31) / 32;
+  if (W + 1 > 64) return false;
+  const uint32_t spw = 64u / (W + 1), strips = (ny + rpt - 1) / rpt;
+  return strips <= 16u * spw;
+}
+static size_t bfs_wave_lds(uint32_t nx, uint32_t ny, int rpt) {
+  const uint32_t W = (nx + 31) / 32, strips = (ny + rpt - 1) / rpt;
+  return ((size_t)2 * strips * rpt * W + (size_t)2 * (strips + 2) * 2 * W) * 4;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_bfs_global: fallback for grids whose frontier bitmaps do not fit in LDS (e.g. 1000x1000): the
 // same level-synchronous bit-parallel sweep with the four bitmaps in a global scratch buffer
 // (L2-resident, 4 x words x 4 B per grid) and direct distance stores.  One workgroup per grid;
@@ -595,8 +925,15 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(k_bfs<R>, grid, dim3(1024), lds, s, pl, first);                                           \
   }
-    if (rpt == 6) NAVGPU_BFS(6)
-    else if (rpt == 12) NAVGPU_BFS(12)
+    if (rpt == 6) {
+      if (bfs_wave_fits(pl.nx, pl.ny, 7) && !getenv("NAVGPU_DEBUG_BFS_LDS")) {
+        const size_t lds_w = bfs_wave_lds(pl.nx, pl.ny, 7);
+        if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
+        hipLaunchKernelGGL(k_bfs_wave<7>, grid, dim3(1024), lds_w, s, pl, first);
+        return;
+      }
+      NAVGPU_BFS(6)
+    } else if (rpt == 12) NAVGPU_BFS(12)
     else NAVGPU_BFS(24)
 #undef NAVGPU_BFS
     return;
