@@ -98,7 +98,7 @@ void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStr
 // Kept from the reference: seeds are distance 0 whatever their cost (only != 255 is checked) and
 // do propagate; an obstacle cell gets obstacleCosts() = N only when a visited free neighbour
 // touches it, else it stays unreachableCellCosts() = N+1; obstacle cells never propagate.
-// blockIdx.x: 0 = path_costs_ (and alignment_costs_), 1 = goal_costs_, 2 = goal_front_costs_.
+// which: 0 = path_costs_ (and alignment_costs_), 1 = goal_costs_, 2 = goal_front_costs_.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t blockExclusiveScan1024(uint32_t v, uint32_t* s_wave, uint32_t* total) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
   extern __shared__ __align__(16) uint32_t sm[];
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_flag[3];
-  const int which = blockIdx.x;
-  const uint32_t inst = first + blockIdx.y;
+  const int which = 2 - (int)blockIdx.y;  // longest searches (goal grids) are dispatched first
+  const uint32_t inst = first + blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const Geom g = geomOf(pl, inst);
   const uint32_t nx = pl.nx, ny = pl.ny, W = (nx + 31) >> 5;
@@ -466,8 +466,9 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
   extern __shared__ __align__(16) uint32_t sm[];
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_flag[3];
-  const int which = blockIdx.x;
-  const uint32_t inst = first + blockIdx.y;
+  __shared__ uint32_t s_prog[18];  // levels published by wave w at [w + 1]; [0] and [17] are sentinels
+  const int which = 2 - (int)blockIdx.y;  // longest searches (goal grids) are dispatched first
+  const uint32_t inst = first + blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const Geom g = geomOf(pl, inst);
   const uint32_t nx = pl.nx, ny = pl.ny, W = (nx + 31) >> 5;
@@ -572,6 +573,7 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
     ecur[e_mine] = fr[0];
     ecur[e_mine + W] = fr[RPT - 1];
   }
+  if (tid < 18) s_prog[tid] = (tid == 0 || tid == 17) ? 0xFFFFFFFFu : 1u;
   __syncthreads();
 
   // --- level-synchronous expansion, ONE barrier per level (three rotating "anything new" flags).
@@ -599,49 +601,73 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
     const uint32_t lwv = fromLaneBelow(fc), rwv = fromLaneAbove(fc);
     const uint32_t x = __builtin_amdgcn_alignbit(fc, lwv, 31) | __builtin_amdgcn_alignbit(rwv, fc, 1) | up;
     const uint32_t cand = (x | down) & ~blocked[k];
-    blocked[k] = blocked[k] | x | down;
+    uint32_t nb;  // blocked | x | down in ONE instruction (the compiler shares x | down and spends two)
+    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(nb) : "v"(blocked[k]), "v"(x), "v"(down));
+    blocked[k] = nb;
     return cand;
   };
+  volatile uint32_t* vprog = s_prog;
+  const uint32_t wave_id = tid >> 6;
   uint32_t group = 0, any_grp = 0;  // termination is checked once per block of 2^kLow levels
+  uint32_t had = 0;                 // OR of this lane's frontier words
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) had |= fr[k];
   while (true) {
     bool done = false;
     uint32_t code = 0;
     while (true) {
       code = level + 1 - epoch_base;  // 1..kEpoch: distance of this round's cells, relative to the epoch
-      const uint32_t top = ecur[e_top], bot = ecur[e_bot];
-      // rows 1..RPT-2 first: they do not wait for the LDS reads
-      const uint32_t old_first = fr[0], old_second = fr[1], old_before_last = fr[RPT - 2];
-      uint32_t prev = old_first, held = 0;
-#pragma unroll
-      for (int k = 1; k < RPT - 1; ++k) {
-        const uint32_t fc = fr[k];
-        const uint32_t cand = expandRow(k, fc, prev, fr[k + 1]);
-        prev = fc;
-        if (k > 1) fr[k - 1] = held;  // row k-1's new frontier, once row k has used the old one
-        held = cand;
+      // A level needs the edge rows of the strips above and below only, i.e. of the two neighbouring
+      // WAVES: wait for those instead of a workgroup barrier, so the waves of a SIMD drift apart and
+      // fill each other's stalls (edge buffers alternate by level; a neighbour is at most one level ahead)
+      for (uint32_t spins = 0; spins < (1u << 20); ++spins) {  // bounded: a wave is never left spinning
+        const uint32_t pa = vprog[wave_id], pb = vprog[wave_id + 2];
+        if (__builtin_amdgcn_readfirstlane(min(pa, pb)) >= level + 1) break;
+        __builtin_amdgcn_s_sleep(1);
       }
-      fr[RPT - 2] = held;
-      fr[0] = expandRow(0, old_first, top, old_second);
-      fr[RPT - 1] = expandRow(RPT - 1, fr[RPT - 1], old_before_last, bot);
-      enxt[e_mine] = fr[0];
-      enxt[e_mine + W] = fr[RPT - 1];
+      asm volatile("" ::: "memory");
+      const uint32_t top = ecur[e_top], bot = ecur[e_bot];
+      // a wave none of whose lanes holds or borders a frontier cell has nothing to do this level
+      if (__builtin_amdgcn_ballot_w64((had | top | bot) != 0) != 0) {
+        asm volatile("" ::: "memory");
+        // rows 1..RPT-2 first: they do not wait for the LDS reads
+        const uint32_t old_first = fr[0], old_second = fr[1], old_before_last = fr[RPT - 2];
+        uint32_t prev = old_first, held = 0;
 #pragma unroll
-      for (int k = 0; k < RPT; ++k) any_grp |= fr[k];
+        for (int k = 1; k < RPT - 1; ++k) {
+          const uint32_t fc = fr[k];
+          const uint32_t cand = expandRow(k, fc, prev, fr[k + 1]);
+          prev = fc;
+          if (k > 1) fr[k - 1] = held;  // row k-1's new frontier, once row k has used the old one
+          held = cand;
+        }
+        fr[RPT - 2] = held;
+        fr[0] = expandRow(0, old_first, top, old_second);
+        fr[RPT - 1] = expandRow(RPT - 1, fr[RPT - 1], old_before_last, bot);
+        had = 0;
 #pragma unroll
-      for (int b = 0; b < kLow; ++b) {
-        if (code & (1u << b)) {  // wave-uniform
-          asm volatile("" ::: "memory");  // keep it a branch: half of these are skipped
+        for (int k = 0; k < RPT; ++k) had |= fr[k];
+        any_grp |= had;
 #pragma unroll
-          for (int k = 0; k < RPT; ++k) plane[b][k] |= fr[k];
+        for (int b = 0; b < kLow; ++b) {
+          if (code & (1u << b)) {  // wave-uniform
+            asm volatile("" ::: "memory");  // keep it a branch: half of these are skipped
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) plane[b][k] |= fr[k];
+          }
         }
       }
+      enxt[e_mine] = fr[0];
+      enxt[e_mine + W] = fr[RPT - 1];
+      asm volatile("" ::: "memory");
+      if (lane == 0) vprog[wave_id + 1] = level + 2;  // LDS keeps a wave's operations in order
       const bool group_end = (code & ((1u << kLow) - 1u)) == (1u << kLow) - 1u;
       if (group_end) {
         closeBlock(code >> kLow);
         if (any_grp) s_flag[group % 3] = 1;
         if (tid == 0) s_flag[(group + 1) % 3] = 0;
+        __syncthreads();
       }
-      __syncthreads();
       uint32_t* t = ecur;
       ecur = enxt;
       enxt = t;
@@ -756,12 +782,12 @@ static size_t bfs_wave_lds(uint32_t nx, uint32_t ny, int rpt) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_bfs_global(PlannerDev pl, uint32_t first, uint32_t* scratch) {
   __shared__ uint32_t s_wave[16];
-  const int which = blockIdx.x;
-  const uint32_t inst = first + blockIdx.y;
+  const int which = 2 - (int)blockIdx.y;  // longest searches (goal grids) are dispatched first
+  const uint32_t inst = first + blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const Geom g = geomOf(pl, inst);
   const uint32_t nx = pl.nx, ny = pl.ny, W = (nx + 31) >> 5, words = ny * W;
-  uint32_t* base = scratch + ((size_t)(blockIdx.y * 3 + which)) * 4 * words;
+  uint32_t* base = scratch + ((size_t)(blockIdx.x * 3 + which)) * 4 * words;
   uint32_t* vis = base;
   uint32_t* fre = base + words;
   uint32_t* cur = base + 2 * words;
@@ -916,7 +942,7 @@ size_t bfs_scratch_words(uint32_t nx, uint32_t ny) {  // per instance, for k_bfs
 }
 
 void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
-  dim3 grid(3, count);
+  dim3 grid(count, 3);
   const size_t lds = bfs_lds_bytes(pl.nx, pl.ny);  // dense bit-parallel sweep (no LDS atomics in the loop)
   const int rpt = bfs_rows_per_thread(pl.nx, pl.ny);
   if (rpt != 0 && lds <= 156u * 1024u) {
