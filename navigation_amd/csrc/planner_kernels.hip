@@ -1053,17 +1053,22 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   uint8_t* s_free = s_dyn + 2 * win_bytes;  // 0 where the whole (2*fp_rcells+1)^2 square around the cell is FREE_SPACE
   const int rc = (int)pl.fp_rcells;
   __syncthreads();
+  // bit 0: some cell of the square is not FREE_SPACE; bit 1: some cell fails pointCost (lethal / unknown)
+  const uint8_t fail_span_w = (pl.cfg.allow_unknown != 0) ? 0 : 1;
   for (int i = tid; i < win * win; i += blockDim.x) {
     const int ly = i / win, lx = i - ly * win;
-    uint8_t m = (lx - rc < 0 || lx + rc >= win) ? 255 : 0;  // squares leaving the window are never "free"
+    uint8_t m = (lx - rc < 0 || lx + rc >= win) ? 3 : 0;  // squares leaving the window are never "free"
     if (!m)
-      for (int d = -rc; d <= rc; ++d) m |= s_win[i + d];
+      for (int d = -rc; d <= rc; ++d) {
+        const uint8_t cc = s_win[i + d];
+        m |= (cc != 0 ? 1 : 0) | ((uint8_t)(cc - kLethal) <= fail_span_w ? 2 : 0);
+      }
     s_m1[i] = m;
   }
   __syncthreads();
   for (int i = tid; i < win * win; i += blockDim.x) {
     const int ly = i / win;
-    uint8_t m = (ly - rc < 0 || ly + rc >= win) ? 255 : 0;
+    uint8_t m = (ly - rc < 0 || ly + rc >= win) ? 3 : 0;
     if (!m)
       for (int d = -rc; d <= rc; ++d) m |= s_m1[i + d * win];
     s_free[i] = m;
@@ -1251,9 +1256,14 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           }
           uint32_t cx = 0, cy = 0;
           const bool ok_c = w2m(x, y, cx, cy);
+          // all_free: every cell the footprint can touch is FREE_SPACE -> the step costs exactly 0.
+          // Without sum_scores only the LAST point's footprint cost survives (obstacle_cost_function.cpp:
+          // cost = f_cost), the earlier points only have to be legal: no failing cell in reach is enough.
           bool all_free = false;
-          if (live_obs && ok_c && nfp >= 3 && inWin((int)cx, (int)cy) && !(pl.debug & 4u))
-            all_free = s_free[((int)cy - wy0) * win + ((int)cx - wx0)] == 0;
+          if (live_obs && ok_c && nfp >= 3 && inWin((int)cx, (int)cy) && !(pl.debug & 4u)) {
+            const uint8_t fl = s_free[((int)cy - wy0) * win + ((int)cx - wx0)];
+            all_free = fl == 0 || (!c.sum_scores && step != num_steps - 1 && !(fl & 2));
+          }
           if (live_obs && all_free) {
             v_obs = c.sum_scores ? v_obs + 0.0 : 0.0;
           } else if (live_obs && !(pl.debug & 2u)) {
