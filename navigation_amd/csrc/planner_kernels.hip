@@ -606,7 +606,10 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
     blocked[k] = nb;
     return cand;
   };
-  volatile uint32_t* vprog = s_prog;
+  // explicit LDS pointer: a plain volatile pointer degrades to FLAT accesses, which are neither cheap
+  // nor ordered with the ds_writes of the edge rows
+  typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
+  lds_vu32* vprog = (lds_vu32*)s_prog;
   const uint32_t wave_id = tid >> 6;
   uint32_t group = 0, any_grp = 0;  // termination is checked once per block of 2^kLow levels
   uint32_t had = 0;                 // OR of this lane's frontier words
