@@ -100,6 +100,8 @@ struct PlannerDev {
   uint32_t win;               // edge (cells) of the costmap window staged in LDS by k_score
   uint32_t fp_rcells;         // Chebyshev radius (cells) that contains every footprint cell around the centre cell
   uint32_t use_tables, tab_steps, tab_nfp, tab_nth;
+  uint8_t* prep;              // [n][prep_stride] LDS image of k_score (window, reach bitmaps, heading tables), built per cycle by k_score_prep*
+  uint32_t prep_stride, prep_bytes;
   uint32_t debug;             // timing ablation bits (NAVGPU_DEBUG_SCORE), 0 in product use  // k_score<TABLES>: shared per-(v_theta, step) tables in LDS
   double* sample_cost;        // [n][max_samples] or null
   int32_t* sample_status;     // [n][max_samples] or null
@@ -130,6 +132,8 @@ uint32_t launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, cons
 void launch_select(const PlannerDev& pl, uint32_t first, uint32_t count, uint32_t n_blocks, hipStream_t s);
 size_t bfs_lds_bytes(uint32_t nx, uint32_t ny);
 size_t score_table_bytes(const PlannerDev& pl);
+size_t score_window_bytes(uint32_t win);
+size_t score_prep_bytes(const PlannerDev& pl);
 bool bfs_lds_resident(uint32_t nx, uint32_t ny);
 size_t bfs_scratch_words(uint32_t nx, uint32_t ny);
 

@@ -599,9 +599,24 @@ static void updateWindow(navgpu_fleet* f) {
     f->pl.tab_steps = (uint32_t)ceil(c.sim_time / c.sim_granularity);
     f->pl.tab_nfp = max_nfp;
     f->pl.tab_nth = (uint32_t)std::max(c.vth_samples, 2) + 1;
-    const size_t lds = 3 * (((size_t)win * win + 15) & ~(size_t)15) + score_table_bytes(f->pl);
+    const size_t lds = score_window_bytes(win) + score_table_bytes(f->pl);
     if (f->pl.tab_steps >= 1 && f->pl.tab_steps <= f->pl.max_sim_steps && lds <= 60 * 1024) f->pl.use_tables = 1;
   }
+}
+
+// (re)allocate the per-robot LDS images of k_score for the current window / table geometry
+static int ensurePrep(navgpu_fleet* f) {
+  PlannerDev tmp = f->pl;
+  tmp.use_tables = 1;  // upper bound: the image with tables, whatever the launch decides
+  const size_t need = (score_prep_bytes(tmp) + 255) & ~(size_t)255;
+  if (f->pl.prep && need <= f->pl.prep_stride) return NAVGPU_OK;
+  HIP_TRY(waitStream(f->stream));
+  f->release(f->pl.prep);
+  f->pl.prep = nullptr;
+  int rc = f->alloc(&f->pl.prep, (size_t)f->desc.n_instances * need);
+  if (rc != NAVGPU_OK) return rc;
+  f->pl.prep_stride = (uint32_t)need;
+  return NAVGPU_OK;
 }
 
 int navgpu_set_footprint(navgpu_fleet* f, uint32_t first, uint32_t count, const double* xy, uint32_t nv) {
@@ -617,7 +632,11 @@ int navgpu_set_footprint(navgpu_fleet* f, uint32_t first, uint32_t count, const 
                          sizeof(double) * kMaxFootprint * 2 * count, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(hipMemcpyAsync(f->pl.fp_n + first, &f->h_fp_n[first], sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(waitStream(f->stream));
-  if (f->planner_configured) updateWindow(f);
+  if (f->planner_configured) {
+    updateWindow(f);
+    int rc = ensurePrep(f);
+    if (rc != NAVGPU_OK) return rc;
+  }
   return NAVGPU_OK;
 }
 
@@ -823,6 +842,10 @@ int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
   pl.scale_obstacle = pl.res * cfg.occdist_scale;
   f->planner_configured = true;
   updateWindow(f);
+  {
+    int rc = ensurePrep(f);
+    if (rc != NAVGPU_OK) return rc;
+  }
   HIP_TRY(waitStream(f->stream));
   return NAVGPU_OK;
 }

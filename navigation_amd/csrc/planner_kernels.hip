@@ -998,7 +998,13 @@ struct ScoreOut {
 // per (v_theta sample, step) by the workgroup into LDS and shared by all (vx, vy) samples, and lanes
 // are mapped so that a wave shares one v_theta: identical edge shapes => convergent Bresenham loops.
 // The arithmetic per value is unchanged (same operations, same rounding), only deduplicated.
-template <bool EXPLICIT, bool TABLES, int THREADS>
+__host__ __device__ inline size_t score_bits_bytes(int win) {  // 2 x [win][nw][2] words, 16-byte aligned
+  return (((size_t)4 * win * ((win + 31) >> 5) * 4) + 15) & ~(size_t)15;
+}
+// PREP: 0 = build the LDS image (window, bitmaps, tables) in this workgroup; 1 = build it and store it to
+// pl.prep (k_score_prep*, one workgroup per robot); 2 = load the stored image (the scoring workgroups of
+// a robot all use the same one: 74 of them in the 32x32x16 configuration)
+template <bool EXPLICIT, bool TABLES, int THREADS, int PREP = 0>
 __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first, const float* explicit_sample) {
   extern __shared__ __align__(16) uint8_t s_dyn[];
   uint8_t* s_win = s_dyn;
@@ -1039,7 +1045,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     fy = fmin(fmax(fy, -1.0e6), 1.0e6);
     wx0 = (int)fx - win / 2;
     wy0 = (int)fy - win / 2;
-    for (int i = tid; i < win * win; i += blockDim.x) {
+    for (int i = tid; PREP != 2 && i < win * win; i += blockDim.x) {
       int ly = i / win, lx = i - ly * win;
       int gx = wx0 + lx, gy = wy0 + ly;
       uint8_t v = 0;
@@ -1047,43 +1053,69 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       s_win[i] = v;
     }
   }
-  // ---- free-space shortcut: a footprint whose centre cell has nothing but FREE_SPACE within the
-  // Chebyshev radius fp_rcells (>= circumscribed radius in cells + 1) touches only cost-0 cells, so
-  // ObstacleCostFunction's step cost is exactly 0 and no edge has to be walked.  Separable max filter
-  // of the window, once per workgroup.
+  // ---- footprint shortcuts.  The cells a footprint with centre cell c can touch lie within the
+  // Chebyshev radius fp_rcells of c (>= circumscribed radius in cells + 1).  Two bitmaps of the window,
+  // dilated by that radius, are built once per workgroup (bit-parallel: rows of 32-cell words, shifts
+  // for the horizontal pass, word ORs for the vertical one; everything outside the window counts as set):
+  //   s_fb[..][0]: some cell in reach is not FREE_SPACE  -> clear = the point's footprint cost is exactly 0
+  //   s_fb[..][1]: some cell in reach fails pointCost    -> clear = the point is legal (cost not needed)
   const int win_bytes = (win * win + 15) & ~15;
-  uint8_t* s_m1 = s_dyn + win_bytes;        // row-wise OR of the window over +-fp_rcells
-  uint8_t* s_free = s_dyn + 2 * win_bytes;  // 0 where the whole (2*fp_rcells+1)^2 square around the cell is FREE_SPACE
+  const int nw = (win + 31) >> 5;
+  uint32_t* s_ba = reinterpret_cast<uint32_t*>(s_dyn + win_bytes);  // [win][nw][2] raw, later the result
+  uint32_t* s_bb = s_ba + 2 * win * nw;                               // [win][nw][2] after the horizontal pass
+  uint32_t* s_fb = s_ba;
   const int rc = (int)pl.fp_rcells;
-  __syncthreads();
-  // bit 0: some cell of the square is not FREE_SPACE; bit 1: some cell fails pointCost (lethal / unknown)
   const uint8_t fail_span_w = (pl.cfg.allow_unknown != 0) ? 0 : 1;
-  for (int i = tid; i < win * win; i += blockDim.x) {
-    const int ly = i / win, lx = i - ly * win;
-    uint8_t m = (lx - rc < 0 || lx + rc >= win) ? 3 : 0;  // squares leaving the window are never "free"
-    if (!m)
-      for (int d = -rc; d <= rc; ++d) {
-        const uint8_t cc = s_win[i + d];
-        m |= (cc != 0 ? 1 : 0) | ((uint8_t)(cc - kLethal) <= fail_span_w ? 2 : 0);
+  __syncthreads();
+  if (PREP != 2) {
+  for (int it = tid; it < win * nw; it += blockDim.x) {
+    const int y = it / nw, j = it - y * nw;
+    uint32_t nf = 0, fl = 0;
+    for (int b = 0; b < 32; ++b) {
+      const int lx = 32 * j + b;
+      uint32_t o = 1, f = 1;
+      if (lx < win) {
+        const uint8_t cc = s_win[y * win + lx];
+        o = cc != 0 ? 1u : 0u;
+        f = (uint8_t)(cc - kLethal) <= fail_span_w ? 1u : 0u;
       }
-    s_m1[i] = m;
+      nf |= o << b;
+      fl |= f << b;
+    }
+    s_ba[2 * it] = nf;
+    s_ba[2 * it + 1] = fl;
   }
   __syncthreads();
-  for (int i = tid; i < win * win; i += blockDim.x) {
-    const int ly = i / win;
-    uint8_t m = (ly - rc < 0 || ly + rc >= win) ? 3 : 0;
+  for (int it = tid; it < 2 * win * nw; it += blockDim.x) {
+    const int cell = it >> 1, f = it & 1;
+    const int y = cell / nw, j = cell - y * nw;
+    const uint32_t cur = s_ba[it];
+    const uint32_t left = j > 0 ? s_ba[it - 2] : 0xFFFFFFFFu, right = j + 1 < nw ? s_ba[it + 2] : 0xFFFFFFFFu;
+    uint32_t m = cur;
+    if (rc > 31) m = 0xFFFFFFFFu;  // reach beyond the neighbouring words: no shortcut
+    for (int d = 1; d <= rc && d < 32; ++d)
+      m |= (cur << d) | (left >> (32 - d)) | (cur >> d) | (right << (32 - d));
+    (void)f;
+    s_bb[it] = m;
+  }
+  __syncthreads();
+  for (int it = tid; it < 2 * win * nw; it += blockDim.x) {
+    const int cell = it >> 1;
+    const int y = cell / nw;
+    uint32_t m = (y - rc < 0 || y + rc >= win) ? 0xFFFFFFFFu : 0u;
     if (!m)
-      for (int d = -rc; d <= rc; ++d) m |= s_m1[i + d * win];
-    s_free[i] = m;
+      for (int d = -rc; d <= rc; ++d) m |= s_bb[it + 2 * d * nw];
+    s_fb[it] = m;
+  }
   }
   // ---- TABLES: per-(v_theta sample, step) heading, trig, rotated footprint, forward-point offset
   const int K = TABLES ? (int)pl.tab_steps : 0;
   const int tnfp = TABLES ? (int)pl.tab_nfp : 0;
   const int nth_s = TABLES ? cnt[2] : 0;
-  double* s_trig = reinterpret_cast<double*>(s_dyn + 3 * win_bytes);  // [nth][K][4] cs, sn, cs2, sn2
+  double* s_trig = reinterpret_cast<double*>(s_dyn + win_bytes + score_bits_bytes(win));  // [nth][K][4] cs, sn, cs2, sn2
   double* s_rot = s_trig + (size_t)pl.tab_nth * K * 4;                            // [nth][K][tnfp][2]
   float* s_th = reinterpret_cast<float*>(s_rot + (size_t)pl.tab_nth * K * tnfp * 2);  // [nth][K]
-  if (TABLES) {
+  if (TABLES && PREP != 2) {
     __syncthreads();  // s_axis, s_fp staged
     const double dt_t = c.sim_time / K;
     if ((int)tid < nth_s) {
@@ -1112,6 +1144,17 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     }
   }
   __syncthreads();
+  if (PREP != 0) {  // the LDS image as 16-byte words: [0, prep_bytes)
+    uint4* img = reinterpret_cast<uint4*>(pl.prep + (size_t)inst * pl.prep_stride);
+    uint4* lds = reinterpret_cast<uint4*>(s_dyn);
+    const uint32_t n16 = pl.prep_bytes >> 4;
+    if (PREP == 1) {
+      for (uint32_t i = tid; i < n16; i += blockDim.x) img[i] = lds[i];
+      return;
+    }
+    for (uint32_t i = tid; i < n16; i += blockDim.x) lds[i] = img[i];
+    __syncthreads();
+  }
 
   // NOTE: the LDS read is unconditional (clamped index) and the global fallback sits in its own
   // rarely-taken branch; a `cond ? lds[i] : global[j]` form makes hipcc merge both into one FLAT load.
@@ -1190,6 +1233,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       num_steps = (int)ns;
       if (num_steps <= 0) reject = true;  // `return num_steps > 0` (:250)
       if (num_steps > (int)pl.max_sim_steps) num_steps = (int)pl.max_sim_steps;  // host validates the capacity
+      if (pl.debug & 8u) num_steps = 1;  // timing ablation: setup + epilogue only
     }
     // DWAPlanner::checkTrajectory ignores generateTrajectory's return value and scores whatever
     // points exist (dwa_planner.cpp:229-230): a rejected sample is an empty trajectory, cost 0.
@@ -1264,8 +1308,10 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           // cost = f_cost), the earlier points only have to be legal: no failing cell in reach is enough.
           bool all_free = false;
           if (live_obs && ok_c && nfp >= 3 && inWin((int)cx, (int)cy) && !(pl.debug & 4u)) {
-            const uint8_t fl = s_free[((int)cy - wy0) * win + ((int)cx - wx0)];
-            all_free = fl == 0 || (!c.sum_scores && step != num_steps - 1 && !(fl & 2));
+            const int lxw = (int)cx - wx0;
+            const uint2 fb = reinterpret_cast<const uint2*>(s_fb)[((int)cy - wy0) * nw + (lxw >> 5)];
+            const bool not_free = (fb.x >> (lxw & 31)) & 1u, can_fail = (fb.y >> (lxw & 31)) & 1u;
+            all_free = !not_free || (!c.sum_scores && step != num_steps - 1 && !can_fail);
           }
           if (live_obs && all_free) {
             v_obs = c.sum_scores ? v_obs + 0.0 : 0.0;
@@ -1540,17 +1586,29 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
 // in 512-thread workgroups (3 per CU by LDS => 24 waves/CU; measured 2.39 vs 2.59 ms at 256 threads)
 constexpr int kScoreThreadsTab = 512;
 __global__ __launch_bounds__(kScoreThreadsTab, 6) void k_score_tab(PlannerDev pl, uint32_t first, const float* explicit_sample) {
-  score_body<false, true, kScoreThreadsTab>(pl, first, explicit_sample);
+  score_body<false, true, kScoreThreadsTab, 2>(pl, first, explicit_sample);
 }
 __global__ __launch_bounds__(kScoreThreads) void k_score_gen(PlannerDev pl, uint32_t first, const float* explicit_sample) {
-  score_body<false, false, kScoreThreads>(pl, first, explicit_sample);
+  score_body<false, false, kScoreThreads, 2>(pl, first, explicit_sample);
+}
+__global__ __launch_bounds__(kScoreThreadsTab) void k_score_prep_tab(PlannerDev pl, uint32_t first) {
+  score_body<false, true, kScoreThreadsTab, 1>(pl, first, nullptr);
+}
+__global__ __launch_bounds__(kScoreThreads) void k_score_prep_gen(PlannerDev pl, uint32_t first) {
+  score_body<false, false, kScoreThreads, 1>(pl, first, nullptr);
 }
 __global__ __launch_bounds__(kScoreThreads) void k_score_explicit(PlannerDev pl, uint32_t first, const float* explicit_sample) {
   score_body<true, false, kScoreThreads>(pl, first, explicit_sample);
 }
 
+size_t score_window_bytes(uint32_t win) {  // costmap window + the two dilated bitmaps (raw/result + horizontal pass)
+  return (((size_t)win * win + 15) & ~(size_t)15) + score_bits_bytes((int)win);
+}
 size_t score_table_bytes(const PlannerDev& pl) {
-  return (size_t)pl.tab_nth * pl.tab_steps * ((4 + 2 * pl.tab_nfp) * sizeof(double) + sizeof(float));
+  return ((size_t)pl.tab_nth * pl.tab_steps * ((4 + 2 * pl.tab_nfp) * sizeof(double) + sizeof(float)) + 15) & ~(size_t)15;
+}
+size_t score_prep_bytes(const PlannerDev& pl) {  // the LDS image k_score_prep* stores per robot
+  return score_window_bytes(pl.win) + (pl.use_tables ? score_table_bytes(pl) : 0);
 }
 uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s) {
   PlannerDev pl = pl_in;
@@ -1558,19 +1616,28 @@ uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, c
   if (const char* e = getenv("NAVGPU_DEBUG_SCORE")) pl.debug = (uint32_t)atoi(e);          // timing ablations only
   if (const char* e = getenv("NAVGPU_DEBUG_SCORE_LDS")) extra_lds = (size_t)atoi(e);       // occupancy experiments only
   if (const char* e = getenv("NAVGPU_DEBUG_NO_TABLES")) pl.use_tables = atoi(e) ? 0 : pl.use_tables;
-  const size_t win_bytes = 3 * (((size_t)pl.win * pl.win + 15) & ~(size_t)15) + extra_lds;  // window + two filter planes
+  const size_t win_bytes = score_window_bytes(pl.win) + extra_lds;
   if (explicit_sample) {
     hipLaunchKernelGGL(k_score_explicit, dim3(1, count), dim3(kScoreThreads), win_bytes, s, pl, first, explicit_sample);
     return 1;
   }
+  pl.prep_bytes = (uint32_t)score_prep_bytes(pl);  // (after the debug overrides of use_tables)
   if (pl.use_tables) {
     const size_t lds = win_bytes + score_table_bytes(pl);
     const uint32_t blocks = (pl.max_samples + kScoreThreadsTab - 1) / kScoreThreadsTab;
-    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_score_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) {
+      hipFuncSetAttribute((const void*)k_score_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute((const void*)k_score_prep_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    hipLaunchKernelGGL(k_score_prep_tab, dim3(1, count), dim3(kScoreThreadsTab), lds, s, pl, first);
     hipLaunchKernelGGL(k_score_tab, dim3(blocks, count), dim3(kScoreThreadsTab), lds, s, pl, first, explicit_sample);
     return blocks;
   }
-  if (win_bytes > 48 * 1024) hipFuncSetAttribute((const void*)k_score_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes);
+  if (win_bytes > 48 * 1024) {
+    hipFuncSetAttribute((const void*)k_score_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes);
+    hipFuncSetAttribute((const void*)k_score_prep_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes);
+  }
+  hipLaunchKernelGGL(k_score_prep_gen, dim3(1, count), dim3(kScoreThreads), win_bytes, s, pl, first);
   hipLaunchKernelGGL(k_score_gen, dim3(pl.score_blocks, count), dim3(kScoreThreads), win_bytes, s, pl, first, explicit_sample);
   return pl.score_blocks;
 }
