@@ -715,3 +715,61 @@ def test_costmap_edge_cases(nav, orc):
     with pytest.raises(nav.NavgpuError):
         fl.set_footprint(np.zeros((40, 2)))
     fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# MapGrid wavefronts: searches longer than one level epoch (> 1023 levels), odd and non-square sizes
+# ----------------------------------------------------------------------------------------------
+def _mapgrid_case(nav, orc, master, plan, pos):
+    from navigation_amd import synth
+    N = L(nav)
+    ny, nx = master.shape
+    cfg = nav.DwaConfig(vx_samples=3, vy_samples=1, vth_samples=3, sim_time=0.5, sim_granularity=0.1, discretize_by_time=1)
+    fl = nav.Fleet(1, nx, ny, synth.RES, layers=N.LAYER_OBSTACLE, keep_sample_costs=True, max_sim_steps=16, max_plan=max(16, len(plan)))
+    fl.configure_planner(cfg)
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.upload(N.GRID_MASTER, master)
+    p = orc.DwaPlanner(master, synth.RES, 0.0, 0.0, orc.DwaConfig(**cfg.as_dict()))
+    fl.set_plan()
+    p.set_plan()
+    r = fl.find_best_path([pos], [[0.0, 0.0, 0.0]], [plan])[0]
+    o = p.cycle(np.asarray(pos, np.float32), np.zeros(3, np.float32), plan, synth.FOOTPRINT)[0]
+    levels = 0
+    for gid, which in ((N.GRID_PATH, 0), (N.GRID_GOAL, 1), (N.GRID_GOAL_FRONT, 2)):
+        g = fl.download(gid, 0, 1)[0].reshape(ny, nx)
+        og = p.grid(which).reshape(ny, nx)
+        assert np.array_equal(g.astype(np.float64), og), f"MapGrid {which} differs ({nx}x{ny})"
+        levels = max(levels, int(g[g < nx * ny].max()))
+    assert (r.best_index, r.n_valid) == (o.best_index, o.n_valid)
+    fl.close()
+    return levels
+
+
+def test_mapgrid_long_searches_and_odd_sizes(nav, orc):
+    from navigation_amd import synth
+    res = synth.RES
+    # serpentine corridors: the wavefront needs several thousand levels (level epochs are flushed and restarted)
+    for n in (200, 400):
+        m = np.zeros((n, n), np.uint8)
+        for k, row in enumerate(range(4, n - 2, 4)):
+            m[row, :] = LETHAL
+            if k % 2:
+                m[row, 1:3] = 0
+            else:
+                m[row, n - 3:n - 1] = 0
+        plan = np.stack([np.linspace(0.1, 0.6, 12), np.full(12, 0.08)], 1)  # first corridor only
+        levels = _mapgrid_case(nav, orc, m, plan, [0.3, 0.08, 0.0])
+        assert levels > 2 * 1023, levels
+    # odd and non-square sizes (ragged last bitmap word, partial last strip), random blobs, unknown cells
+    rs = np.random.RandomState(5)
+    for nx, ny in ((101, 77), (64, 64), (33, 250), (400, 37), (250, 399), (31, 31), (416, 416)):
+        m = np.zeros((ny, nx), np.uint8)
+        for _ in range(max(3, nx * ny // 900)):
+            cx, cy, r = rs.randint(0, nx), rs.randint(0, ny), rs.randint(1, 4)
+            m[max(0, cy - r):cy + r + 1, max(0, cx - r):cx + r + 1] = LETHAL
+        m[rs.random_sample(m.shape) < 0.01] = NOINFO
+        sx, sy = nx * res, ny * res
+        plan = np.stack([np.linspace(0.1 * sx, 0.9 * sx, 40), np.linspace(0.2 * sy, 0.8 * sy, 40)], 1)
+        for px, py in plan:  # keep the plan itself traversable
+            m[int(py / res), int(px / res)] = 0
+        _mapgrid_case(nav, orc, m, plan, [0.5 * sx, 0.5 * sy, 0.3])
