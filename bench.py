@@ -98,7 +98,8 @@ def hbm_traffic_from_profiles(kernel):
         return None, None
     try:
         d = json.load(open(files[-1]))
-        return d["kernels"][kernel]["hbm_bytes_raw"], os.path.relpath(files[-1], ROOT)
+        # MI355X_MICROARCH.md (HBM): gfx950 FETCH_SIZE tallies 128-B read requests at 64 B -> doubled; WRITE_SIZE is exact
+        return d["kernels"][kernel]["hbm_bytes_fetch_x2"], os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
 
@@ -130,7 +131,17 @@ def cpu_baseline(insts_sample, cfg, n_cells, masters):
     reps = 8
     dti = L.orc_bench_inflate(raw, n_inst, n_cells, n_cells, synth.RES, synth.INFLATION_RADIUS, synth.COST_SCALING,
                               synth.inscribed_radius(synth.FOOTPRINT), reps, cores)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return dict(value=scored.value / dt, unit="trajectories/s", cores=cores, kind="port",
+                per_core=scored.value / dt / cores, host_cpu=model, host_nproc=os.cpu_count(),
+                inflation_cells_per_s_per_core=n_inst * reps * n_cells * n_cells / dti / cores,
                 sample=f"{n_inst} instances x {cycles} planner cycles (4 MapGrid BFS + rollout + 6 critics, reference early-out), "
                        f"one instance per thread",
                 inflation_cells_per_s=n_inst * reps * n_cells * n_cells / dti,
@@ -236,6 +247,17 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": avg_ms[dom],
                          "frac_vs_measured_copy_peak_6290": achieved / 6290.0},
         }
+        # every kernel against the same roofline, and the whole step as SURVEY 8(d) defines it
+        per_kernel = {}
+        for k in avg_ms:
+            if avg_ms[k] > 0 and alg_bytes.get(k, 0) > 0:
+                gbs = alg_bytes[k] / (avg_ms[k] * 1e-3) / 1e9
+                tk, _ = hbm_traffic_from_profiles(k) if (n_inst, n_cells) == (256, 400) else (None, None)
+                per_kernel[k] = {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": avg_ms[k], "traffic": tk}
+        out["roofline_all"] = per_kernel
+        step_bytes = sum(alg_bytes.values())
+        out["roofline_step"] = {"algorithmic_bytes_per_step": step_bytes, "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9,
+                                "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"}
     # ---- extra legs on rank 0 at N=1 only
     if rank == 0 and world == 1:
         # full-window inflation throughput (the BASELINE.md probe shape)
@@ -264,19 +286,24 @@ def main():
         fl.stage_planner_raw(states_h, n_st, plans_h)
         step(fl)
         fl.sync()
-        kp = 10
+        kp = 50
         t1 = time.perf_counter()
         from navigation_amd._lib import PlanResult
         rbuf = (PlanResult * n_st)()  # reused: no per-cycle Python allocation (see Fleet.results_into)
+        cyc = []
         for _ in range(kp):
+            tc = time.perf_counter()
             fl.stage_observations_raw(poses_h, obs_arr, n_obs, pts_h)
             fl.stage_planner_raw(states_h, n_st, plans_h)
             step(fl)
             rr = fl.results_into(rbuf)
+            cyc.append(time.perf_counter() - tc)
         dp = time.perf_counter() - t1
         h2d = poses_h.nbytes + pts_h.nbytes + plans_h.nbytes + n_obs * 56 + n_st * 32
+        cyc.sort()
         out["pcie_inclusive"] = {"trajectories_per_s": sum(r.n_scored for r in rr) * kp / dp, "ms_per_step": dp / kp * 1e3,
-                                 "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": n_st * 72,
+                                 "cycle_ms_median": cyc[len(cyc) // 2] * 1e3, "cycle_ms_p99": cyc[min(len(cyc) - 1, int(0.99 * len(cyc)))] * 1e3,
+                                 "cycles": kp, "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": n_st * 72,
                                  "note": "caller buffers are pageable; the library stages them through pinned mirrors"}
         fl.upload(N.GRID_MASTER, raw)
         fl.inflate(boxes=full)

@@ -14,21 +14,26 @@ done
 python3 - "$out" "$tag" <<'PY'
 import csv, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
-res = collections.defaultdict(dict)
+# profiled regions of the library (navgpu_kernel_name) <- the device kernels they launch
+GROUPS = {"k_obstacle": ("k_obstacle",), "k_merge": ("k_merge",), "k_inflate": ("k_inflate", "k_inflate_bits"),
+          "k_bfs": ("k_bfs", "k_bfs_wave", "k_bfs_global"), "k_score": ("k_score_tab", "k_score_gen", "k_score_prep_tab", "k_score_prep_gen"),
+          "k_select": ("k_select",)}
+MAIN = {"k_score": ("k_score_tab", "k_score_gen")}
+raw = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    agg, cnt = collections.defaultdict(float), collections.Counter()
     for r in csv.DictReader(open(f"{out}/{tag}_pmc_{c.lower()}.csv")):
         if r["Counter_Name"] != c: continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("navgpu::", "")
-        k = k.split("<")[0]
-        agg[k] += float(r["Counter_Value"]); cnt[k] += 1
-    for k in agg:
-        res[k][c] = agg[k] / cnt[k] * 1024.0  # counters are in KB
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("navgpu::", "").split("<")[0]
+        raw[k][c].append(float(r["Counter_Value"]) * 1024.0)  # counters are in KB
 kern = {}
-for k, v in res.items():
-    f, w = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
-    kern[k] = dict(fetch_bytes_raw=f, write_bytes=w, hbm_bytes_raw=f + w, hbm_bytes_fetch_x2=2 * f + w)
-json.dump(dict(source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean per launch, KB x 1024",
+for g, members in GROUPS.items():
+    launches = max((len(raw[m]["WRITE_SIZE"]) for m in MAIN.get(g, members) if m in raw), default=0)
+    if not launches: continue
+    f = sum(sum(raw[m]["FETCH_SIZE"]) for m in members if m in raw) / launches
+    w = sum(sum(raw[m]["WRITE_SIZE"]) for m in members if m in raw) / launches
+    kern[g] = dict(fetch_bytes_raw=f, write_bytes=w, hbm_bytes_raw=f + w, hbm_bytes_fetch_x2=2 * f + w, launches=launches,
+                   device_kernels=[m for m in members if m in raw])
+json.dump(dict(source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean per launch of the profiled region, KB x 1024",
                caveat="gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x and is uncalibrated for gathers",
                kernels=kern), open(f"{out}/{tag}_hbm_traffic.json", "w"), indent=1)
 print(json.dumps(kern, indent=1))
