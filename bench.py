@@ -300,10 +300,12 @@ def main():
             cyc.append(time.perf_counter() - tc)
         dp = time.perf_counter() - t1
         h2d = poses_h.nbytes + pts_h.nbytes + plans_h.nbytes + n_obs * 56 + n_st * 32
+        worst = int(np.argmax(cyc))
+        worst_ms = cyc[worst] * 1e3
         cyc.sort()
         out["pcie_inclusive"] = {"trajectories_per_s": sum(r.n_scored for r in rr) * kp / dp, "ms_per_step": dp / kp * 1e3,
                                  "cycle_ms_median": cyc[len(cyc) // 2] * 1e3, "cycle_ms_p99": cyc[min(len(cyc) - 1, int(0.99 * len(cyc)))] * 1e3,
-                                 "cycles": kp, "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": n_st * 72,
+                                 "cycle_ms_max": worst_ms, "worst_cycle_index": worst, "cycles": kp, "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": n_st * 72,
                                  "note": "caller buffers are pageable; the library stages them through pinned mirrors"}
         fl.upload(N.GRID_MASTER, raw)
         fl.inflate(boxes=full)
