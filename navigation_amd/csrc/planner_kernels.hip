@@ -735,33 +735,79 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
     }
   }
   // --- decode: expanded -> level (0 for seeds); touched obstacle -> obstacleCosts(); else unreachableCellCosts()
-  if (owner) {
+  uint32_t lt[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) lt[k] = (owner && r0 + k < ny) ? late[base_w + k * W] : 0u;
+  auto cellValue = [&](const uint32_t (&pl10)[kPlanes], uint32_t exw, uint32_t tkw, uint32_t bpos) -> uint32_t {
+    uint32_t lvl = 0;
+#pragma unroll
+    for (int b = 0; b < kPlanes; ++b) lvl |= ((pl10[b] >> bpos) & 1u) << b;
+    if ((exw >> bpos) & 1u) return lvl ? epoch_base + lvl : 0u;  // relative code 0 == a seed
+    return ((tkw >> bpos) & 1u) ? N_obst : N_unreach;
+  };
+  // Coalesced path: a lane's word is 128 B of a row; stored directly, one instruction would put 16 B into
+  // 64 different lines.  The wave passes its words (planes, expanded, touched, late) through a private
+  // LDS area instead, 16 words per bitmap word, and eight lanes decode one word: a store instruction then
+  // covers 8 whole words = 1 KB of contiguous distances.
+  const uint32_t nwords = spw * W;
+  const bool coalesced = aligned4 && (size_t)16 * nwords * 16 <= (size_t)2 * rows_p * W + 2 * edge_words;
+  __syncthreads();  // everyone is done with seedm / late / the edge buffers
+  if (coalesced) {
+    uint4* stage = reinterpret_cast<uint4*>(sm) + (size_t)wave_id * nwords * 4;
+    const bool holder = slot < spw && lane - slot * L < W;
+    const uint32_t myw = holder ? slot * W + (lane - slot * L) : 0u;
+    const uint32_t c0 = 4u * (lane & 7u);
+    uint32_t cellbase[8], rowj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t wj = 8u * j + (lane >> 3);
+      const uint32_t sj = wj / W, wij = wj - sj * W, strip_j = wave_id * spw + sj;
+      const bool ok = wj < nwords && strip_j < strips && wij * 32 + c0 < nx;
+      rowj[j] = ok ? strip_j * RPT : 0xFFFFFF00u;  // rows of a word that does not exist are never < ny
+      cellbase[j] = strip_j * RPT * nx + wij * 32 + c0;
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      if (holder) {
+        stage[myw * 4 + 0] = make_uint4(plane[0][k], plane[1][k], plane[2][k], plane[3][k]);
+        stage[myw * 4 + 1] = make_uint4(plane[4][k], plane[5][k], plane[6][k], plane[7][k]);
+        stage[myw * 4 + 2] = make_uint4(plane[8][k], plane[9][k], ex[k], blocked[k]);
+        stage[myw * 4 + 3] = make_uint4(lt[k], 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (rowj[j] + k < ny) {
+          const uint32_t wj = 8u * j + (lane >> 3);
+          const uint4 a = stage[wj * 4 + 0], b4 = stage[wj * 4 + 1], c4 = stage[wj * 4 + 2], d4 = stage[wj * 4 + 3];
+          const uint32_t pl10[kPlanes] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w, c4.x, c4.y};
+          uint32_t* out = dist + cellbase[j] + k * nx;
+          uint4 v;
+          v.x = cellValue(pl10, c4.z, c4.w, c0);
+          v.y = cellValue(pl10, c4.z, c4.w, c0 + 1);
+          v.z = cellValue(pl10, c4.z, c4.w, c0 + 2);
+          v.w = cellValue(pl10, c4.z, c4.w, c0 + 3);
+          const uint32_t l4 = (d4.x >> c0) & 0xFu;  // cells already written when their epoch was flushed
+          if (l4 == 0) {
+            *reinterpret_cast<uint4*>(out) = v;
+          } else {
+            if (!(l4 & 1u)) out[0] = v.x;
+            if (!(l4 & 2u)) out[1] = v.y;
+            if (!(l4 & 4u)) out[2] = v.z;
+            if (!(l4 & 8u)) out[3] = v.w;
+          }
+        }
+      }
+    }
+  } else if (owner) {
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       if (r0 + k >= ny) continue;
-      const uint32_t exk = ex[k], tk = blocked[k], lt = late[base_w + k * W];
+      const uint32_t pl10[kPlanes] = {plane[0][k], plane[1][k], plane[2][k], plane[3][k], plane[4][k],
+                                      plane[5][k], plane[6][k], plane[7][k], plane[8][k], plane[9][k]};
       uint32_t* drow = dist + (r0 + k) * nx + wi * 32;
       const uint32_t nb = min(32u, nx - wi * 32);
-      auto value = [&](uint32_t bpos) -> uint32_t {
-        uint32_t lvl = 0;
-#pragma unroll
-        for (int b = 0; b < kPlanes; ++b) lvl |= ((plane[b][k] >> bpos) & 1u) << b;
-        if ((exk >> bpos) & 1u) return lvl ? epoch_base + lvl : 0u;  // relative code 0 == a seed
-        return ((tk >> bpos) & 1u) ? N_obst : N_unreach;
-      };
-      if (aligned4 && lt == 0) {
-        for (uint32_t q = 0; q < nb / 4; ++q) {
-          uint4 v;
-          v.x = value(4 * q);
-          v.y = value(4 * q + 1);
-          v.z = value(4 * q + 2);
-          v.w = value(4 * q + 3);
-          *reinterpret_cast<uint4*>(drow + 4 * q) = v;
-        }
-      } else {
-        for (uint32_t bpos = 0; bpos < nb; ++bpos)
-          if (!((lt >> bpos) & 1u)) drow[bpos] = value(bpos);
-      }
+      for (uint32_t bpos = 0; bpos < nb; ++bpos)
+        if (!((lt[k] >> bpos) & 1u)) drow[bpos] = cellValue(pl10, ex[k], blocked[k], bpos);
     }
   }
 }
