@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--size", type=int, default=400, help="costmap cells per side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-process rehearsal on a box with ONE GPU: every rank uses device 0, collectives over gloo")
     args = ap.parse_args()
 
     import torch
@@ -165,10 +167,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     import navigation_amd as nav
@@ -207,7 +214,8 @@ def main():
 
     # the only collective: throughput counters over RCCL (navigation_amd/sharding.py, gloo-tested on CPU)
     from navigation_amd.sharding import reduce_counters
-    elapsed_max, (total_scored, total_win) = reduce_counters(dist, elapsed, [scored, win_cells], device="cuda")
+    elapsed_max, (total_scored, total_win) = reduce_counters(dist, elapsed, [scored, win_cells],
+                                                             device="cpu" if args.rehearse_on_one_gpu else "cuda")
 
     out = None
     if rank == 0:
@@ -219,8 +227,8 @@ def main():
         alg_bytes = {
             "k_score": BYTES_PER_TRAJ * scored,
             "k_bfs": BYTES_PER_BFS_CELL * 3 * n_cells * n_cells * n_inst,
-            "k_inflate": BYTES_PER_INFL_CELL * win_cells / world,
-            "k_merge": BYTES_PER_MERGE_CELL * win_cells / world,
+            "k_inflate": BYTES_PER_INFL_CELL * win_cells,
+            "k_merge": BYTES_PER_MERGE_CELL * win_cells,
             "k_obstacle": 0.0, "k_select": 0.0,
         }
         achieved = alg_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
