@@ -773,3 +773,30 @@ def test_mapgrid_long_searches_and_odd_sizes(nav, orc):
         for px, py in plan:  # keep the plan itself traversable
             m[int(py / res), int(px / res)] = 0
         _mapgrid_case(nav, orc, m, plan, [0.5 * sx, 0.5 * sy, 0.3])
+
+
+def test_planner_reconfigure_same_fleet(nav, orc):
+    """Window, heading tables and the per-robot LDS image are re-sized when the planner configuration or the
+    footprint changes on a live fleet (navgpu_planner_configure / navgpu_set_footprint called again)."""
+    from navigation_amd import synth
+    N = L(nav)
+    n = 160
+    ins = _inflated_instance(orc, n, 11, synth)
+    m = ins["master"]
+    size = n * synth.RES
+    fl = nav.Fleet(1, n, n, synth.RES, layers=N.LAYER_OBSTACLE, keep_sample_costs=True, max_sim_steps=64, max_footprint=16)
+    fl.upload(N.GRID_MASTER, m)
+    big = np.array([[0.45, 0.3], [0.45, -0.3], [-0.45, -0.3], [-0.45, 0.3]])
+    steps = [(dict(vx_samples=5, vy_samples=3, vth_samples=6, sim_time=0.8, sim_granularity=0.1, discretize_by_time=1), synth.FOOTPRINT),
+             (dict(vx_samples=5, vy_samples=3, vth_samples=6, sim_time=3.0, sim_granularity=0.1, discretize_by_time=1), synth.FOOTPRINT),
+             (dict(vx_samples=5, vy_samples=3, vth_samples=6, sim_time=3.0, sim_granularity=0.1, discretize_by_time=1), big),
+             (dict(vx_samples=4, vy_samples=2, vth_samples=9, sim_time=1.5, sim_granularity=0.05, discretize_by_time=0), big)]
+    for cfgk, fp in steps:
+        cfg = nav.DwaConfig(**cfgk)
+        fl.configure_planner(cfg)
+        fl.set_footprint(fp)
+        fl.set_plan()
+        p = orc.DwaPlanner(m, synth.RES, 0.0, 0.0, orc.DwaConfig(**cfg.as_dict()))
+        p.set_plan()
+        _compare_cycle(fl, p, [size / 2, size / 2, 0.4], [0.2, 0.0, 0.1], ins["plan"], fp)
+    fl.close()
