@@ -1001,7 +1001,8 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
     hipLaunchKernelGGL(k_bfs<R>, grid, dim3(1024), lds, s, pl, first);                                           \
   }
     if (rpt == 6) {
-      if (bfs_wave_fits(pl.nx, pl.ny, 7) && !getenv("NAVGPU_DEBUG_BFS_LDS")) {
+      static const bool force_lds_kernel = getenv("NAVGPU_DEBUG_BFS_LDS") != nullptr;  // A/B timing only
+      if (bfs_wave_fits(pl.nx, pl.ny, 7) && !force_lds_kernel) {
         const size_t lds_w = bfs_wave_lds(pl.nx, pl.ny, 7);
         if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
         hipLaunchKernelGGL(k_bfs_wave<7>, grid, dim3(1024), lds_w, s, pl, first);
@@ -1659,9 +1660,13 @@ size_t score_prep_bytes(const PlannerDev& pl) {  // the LDS image k_score_prep* 
 uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s) {
   PlannerDev pl = pl_in;
   size_t extra_lds = 0;
-  if (const char* e = getenv("NAVGPU_DEBUG_SCORE")) pl.debug = (uint32_t)atoi(e);          // timing ablations only
-  if (const char* e = getenv("NAVGPU_DEBUG_SCORE_LDS")) extra_lds = (size_t)atoi(e);       // occupancy experiments only
-  if (const char* e = getenv("NAVGPU_DEBUG_NO_TABLES")) pl.use_tables = atoi(e) ? 0 : pl.use_tables;
+  // timing ablations / occupancy experiments only (tools/probe_score.py); read once, all off in product use
+  static const uint32_t dbg_bits = getenv("NAVGPU_DEBUG_SCORE") ? (uint32_t)atoi(getenv("NAVGPU_DEBUG_SCORE")) : 0u;
+  static const size_t dbg_lds = getenv("NAVGPU_DEBUG_SCORE_LDS") ? (size_t)atoi(getenv("NAVGPU_DEBUG_SCORE_LDS")) : 0;
+  static const bool dbg_no_tables = getenv("NAVGPU_DEBUG_NO_TABLES") && atoi(getenv("NAVGPU_DEBUG_NO_TABLES"));
+  pl.debug = dbg_bits;
+  extra_lds = dbg_lds;
+  if (dbg_no_tables) pl.use_tables = 0;
   const size_t win_bytes = score_window_bytes(pl.win) + extra_lds;
   if (explicit_sample) {
     hipLaunchKernelGGL(k_score_explicit, dim3(1, count), dim3(kScoreThreads), win_bytes, s, pl, first, explicit_sample);
