@@ -289,6 +289,81 @@ int navgpu_planner_set_oscillation(navgpu_fleet* fleet, uint32_t first, uint32_t
                                    const float* prev_stationary_pos_xyz);
 
 /* ------------------------------------------------------------------------------------------ */
+/* DWAPlannerROS control cycle: the steps around findBestPath         */
+/* ------------------------------------------------------------------------------------------ */
+/* Host-side mirror, free of ROS types, of DWAPlannerROS::setPlan / computeVelocityCommands /
+ * isGoalReached (dwa_local_planner/src/dwa_planner_ros.cpp:130-158,176-300), of
+ * LocalPlannerUtil::getLocalPlan (base_local_planner/src/local_planner_util.cpp:105-123) with
+ * goal_functions.cpp's transformGlobalPlan / prunePlan / getGoalPose / stopped (:69-174,175-255) and of
+ * LatchedStopRotateController (src/latched_stop_rotate_controller.cpp:37-273).  Poses are (x, y, yaw)
+ * triples; the tf lookup is replaced by an optional planar plan->global transform handed in by the
+ * caller (identity when NULL).  tf's own 3-D arithmetic and the `angles` package are not part of the
+ * reference tree: their formulas are restated (angles::normalize_angle: fmod form), parity unpinned. */
+typedef struct {
+  double xy_goal_tolerance, yaw_goal_tolerance;  /* LocalPlannerLimits (local_planner_limits.h)            */
+  double rot_stopped_vel, trans_stopped_vel;
+  double max_rot_vel, min_rot_vel;
+  double acc_lim_x, acc_lim_y, acc_lim_theta;    /* limits.getAccLimits()                                   */
+  double sim_period;                             /* DWAPlanner::getSimPeriod()                              */
+  int32_t prune_plan;                            /* LocalPlannerLimits::prune_plan                          */
+  int32_t latch_xy_goal_tolerance;               /* ~/latch_xy_goal_tolerance                               */
+} navgpu_local_limits;
+
+typedef struct {
+  double pose[3];      /* costmap_ros_->getRobotPose(): x, y, yaw in the costmap's global frame             */
+  double odom_vel[3];  /* OdometryHelperRos: twist.linear.x, twist.linear.y, twist.angular.z               */
+  int32_t have_pose;   /* 0: getRobotPose failed -> computeVelocityCommands returns false                   */
+  int32_t reserved;
+} navgpu_robot_input;
+
+typedef enum {
+  NAVGPU_BRANCH_NONE = 0,     /* returned before dispatching (no pose, no plan, empty local plan)           */
+  NAVGPU_BRANCH_DWA = 1,      /* dwaComputeVelocityCommands                                                 */
+  NAVGPU_BRANCH_STOP = 2,     /* stop-rotate: stopWithAccLimits                                             */
+  NAVGPU_BRANCH_ROTATE = 3,   /* stop-rotate: rotateToGoal                                                  */
+  NAVGPU_BRANCH_AT_GOAL = 4   /* stop-rotate: goal orientation reached, zero command                        */
+} navgpu_branch;
+
+typedef struct {
+  double cmd_vel[3];          /* geometry_msgs::Twist linear.x, linear.y, angular.z                         */
+  int32_t ok;                 /* return value of computeVelocityCommands                                    */
+  int32_t branch;             /* navgpu_branch                                                              */
+  int32_t local_plan_points;  /* poses of the transformed + pruned plan handed to updatePlanAndLocalCosts   */
+  int32_t trajectory_points;  /* points of the published local plan (winning trajectory; 0 unless DWA ok)   */
+} navgpu_cmd_result;
+
+/* transformGlobalPlan (goal_functions.cpp:88-174) followed, when `prune` is set, by prunePlan
+ * (:69-86) on a plan of n (x, y, yaw) triples.  dist_threshold = max(size_x, size_y) * resolution / 2
+ * (:119-120).  Writes the local plan to out_xyyaw (capacity poses), its length to *n_out and the number
+ * of poses prunePlan erased from the FRONT OF THE STORED GLOBAL PLAN to *n_erased (it erases both plans in
+ * lockstep from their beginnings).  Pure host function: needs no fleet and no GPU.
+ * Returns NAVGPU_OK, NAVGPU_ERR_INVALID (n == 0: "Received plan with zero length") or NAVGPU_ERR_CAPACITY. */
+int navgpu_local_plan_window(const double* plan_xyyaw, uint32_t n, const double pose[3], const double* plan_to_global,
+                             double dist_threshold, int32_t prune, double* out_xyyaw, uint32_t capacity,
+                             uint32_t* n_out, uint32_t* n_erased);
+/* angles::shortest_angular_distance(from, to) as restated here (exposed for the parity tests) */
+double navgpu_shortest_angular_distance(double from, double to);
+
+/* LocalPlannerUtil::reconfigureCB limits + LatchedStopRotateController parameters, for the whole fleet */
+int navgpu_local_planner_configure(navgpu_fleet* fleet, const navgpu_local_limits* limits);
+/* DWAPlannerROS::setPlan: stores the global plan of one instance (n (x, y, yaw) triples in the plan's own
+ * frame), clears the goal-tolerance latch and resets the oscillation flags.  plan_to_global = NULL: the
+ * plan is already expressed in the costmap's global frame. */
+int navgpu_local_planner_set_plan(navgpu_fleet* fleet, uint32_t instance, const double* plan_xyyaw, uint32_t n,
+                                  const double* plan_to_global);
+/* DWAPlannerROS::computeVelocityCommands for instances [first, first+count): getLocalPlan ->
+ * updatePlanAndLocalCosts -> isPositionReached ? computeVelocityCommandsStopRotate (checkTrajectory on
+ * the GPU as the obstacle check, MapGrids NOT refreshed: the reference does not call prepare() there)
+ * : dwaComputeVelocityCommands (navgpu_planner_cycle over the instances on that branch). */
+int navgpu_local_planner_compute_velocity_commands(navgpu_fleet* fleet, uint32_t first, uint32_t count,
+                                                   const navgpu_robot_input* in, navgpu_cmd_result* out);
+/* DWAPlannerROS::isGoalReached -> LatchedStopRotateController::isGoalReached */
+int navgpu_local_planner_is_goal_reached(navgpu_fleet* fleet, uint32_t first, uint32_t count,
+                                         const navgpu_robot_input* in, int32_t* reached);
+/* the stored global plan of one instance after pruning; returns its length (poses) or < 0 */
+int navgpu_local_planner_get_plan(navgpu_fleet* fleet, uint32_t instance, double* xyyaw, uint32_t capacity);
+
+/* ------------------------------------------------------------------------------------------ */
 /* measurement                                                                                */
 /* ------------------------------------------------------------------------------------------ */
 typedef enum {

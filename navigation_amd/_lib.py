@@ -88,6 +88,25 @@ class PlanResult(C.Structure):
                 ("cost", C.c_double), ("drive", C.c_double * 3)]
 
 
+class LocalLimits(C.Structure):
+    _fields_ = [("xy_goal_tolerance", C.c_double), ("yaw_goal_tolerance", C.c_double), ("rot_stopped_vel", C.c_double),
+                ("trans_stopped_vel", C.c_double), ("max_rot_vel", C.c_double), ("min_rot_vel", C.c_double),
+                ("acc_lim_x", C.c_double), ("acc_lim_y", C.c_double), ("acc_lim_theta", C.c_double),
+                ("sim_period", C.c_double), ("prune_plan", C.c_int32), ("latch_xy_goal_tolerance", C.c_int32)]
+
+
+class RobotInput(C.Structure):
+    _fields_ = [("pose", C.c_double * 3), ("odom_vel", C.c_double * 3), ("have_pose", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CmdResult(C.Structure):
+    _fields_ = [("cmd_vel", C.c_double * 3), ("ok", C.c_int32), ("branch", C.c_int32), ("local_plan_points", C.c_int32),
+                ("trajectory_points", C.c_int32)]
+
+
+BRANCH_NONE, BRANCH_DWA, BRANCH_STOP, BRANCH_ROTATE, BRANCH_AT_GOAL = range(5)
+
+
 def lib_path():
     return os.path.join(_HERE, "libnavgpu.so")
 
@@ -134,6 +153,13 @@ SYMBOLS = [
     ("navgpu_planner_check_trajectory", C.c_int, [vp, u32, vp, C.POINTER(i32)]),
     ("navgpu_planner_get_oscillation", C.c_int, [vp, u32, u32, vp, vp]),
     ("navgpu_planner_set_oscillation", C.c_int, [vp, u32, u32, vp, vp]),
+    ("navgpu_local_plan_window", C.c_int, [vp, u32, vp, vp, dbl, i32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),
+    ("navgpu_shortest_angular_distance", dbl, [dbl, dbl]),
+    ("navgpu_local_planner_configure", C.c_int, [vp, C.POINTER(LocalLimits)]),
+    ("navgpu_local_planner_set_plan", C.c_int, [vp, u32, vp, u32, vp]),
+    ("navgpu_local_planner_compute_velocity_commands", C.c_int, [vp, u32, u32, vp, vp]),
+    ("navgpu_local_planner_is_goal_reached", C.c_int, [vp, u32, u32, vp, vp]),
+    ("navgpu_local_planner_get_plan", C.c_int, [vp, u32, vp, u32]),
     ("navgpu_profile_enable", C.c_int, [vp, i32]),
     ("navgpu_profile_reset", C.c_int, [vp]),
     ("navgpu_profile_read", C.c_int, [vp, i32, C.POINTER(dbl), C.POINTER(C.c_uint64)]),

@@ -266,6 +266,48 @@ class Fleet:
         p = None if prev is None else _ptr(np.ascontiguousarray(prev, np.float32))
         check(self.L.navgpu_planner_set_oscillation(self.h, first, len(flags), _ptr(flags), p), "set_oscillation")
 
+    # ---------------------------------------------------------------- DWAPlannerROS control cycle
+    def configure_local_planner(self, **limits):
+        """LocalPlannerLimits + LatchedStopRotateController parameters (navgpu_local_limits)."""
+        lim = N.LocalLimits(**limits)
+        check(self.L.navgpu_local_planner_configure(self.h, C.byref(lim)), "local_planner_configure")
+
+    def set_global_plan(self, instance, plan_xyyaw, plan_to_global=None):
+        """DWAPlannerROS::setPlan for one robot."""
+        plan = np.ascontiguousarray(plan_xyyaw, np.float64).reshape(-1, 3)
+        T = None if plan_to_global is None else _ptr(np.ascontiguousarray(plan_to_global, np.float64))
+        check(self.L.navgpu_local_planner_set_plan(self.h, instance, _ptr(plan), len(plan), T), "local_planner_set_plan")
+
+    def global_plan(self, instance):
+        n = check(self.L.navgpu_local_planner_get_plan(self.h, instance, None, 0), "local_planner_get_plan")
+        out = np.zeros((n, 3))
+        if n:
+            check(self.L.navgpu_local_planner_get_plan(self.h, instance, _ptr(out), n), "local_planner_get_plan")
+        return out
+
+    def _robot_inputs(self, poses, odom_vels, have_pose):
+        poses = np.asarray(poses, np.float64).reshape(-1, 3)
+        vels = np.asarray(odom_vels, np.float64).reshape(-1, 3)
+        arr = (N.RobotInput * len(poses))()
+        for k in range(len(poses)):
+            arr[k].pose[:] = [float(v) for v in poses[k]]
+            arr[k].odom_vel[:] = [float(v) for v in vels[k]]
+            arr[k].have_pose = 1 if have_pose is None else int(bool(have_pose[k]))
+        return arr
+
+    def compute_velocity_commands(self, poses, odom_vels, first=0, have_pose=None):
+        """DWAPlannerROS::computeVelocityCommands for len(poses) robots -> list of CmdResult."""
+        arr = self._robot_inputs(poses, odom_vels, have_pose)
+        out = (N.CmdResult * len(arr))()
+        check(self.L.navgpu_local_planner_compute_velocity_commands(self.h, first, len(arr), arr, out), "compute_velocity_commands")
+        return list(out)
+
+    def is_goal_reached(self, poses, odom_vels, first=0, have_pose=None):
+        arr = self._robot_inputs(poses, odom_vels, have_pose)
+        out = (C.c_int32 * len(arr))()
+        check(self.L.navgpu_local_planner_is_goal_reached(self.h, first, len(arr), arr, out), "is_goal_reached")
+        return [bool(v) for v in out]
+
     # ---------------------------------------------------------------- measurement
     def profile(self, enable=True):
         check(self.L.navgpu_profile_enable(self.h, int(enable)), "profile_enable")

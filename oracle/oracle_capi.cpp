@@ -457,6 +457,13 @@ int orc_dwa_cycle(void* h, const float* pos, const float* vel, const double* pla
   }
   return (int)rec.size();
 }
+// DWAPlanner::updatePlanAndLocalCosts alone (what DWAPlannerROS::computeVelocityCommands always calls, :274)
+void orc_dwa_update_plan(void* h, const float* pos, const double* plan_xy, uint32_t n_plan) {
+  auto* p = static_cast<PlannerHandle*>(h);
+  V3f ps;
+  for (int i = 0; i < 3; ++i) ps[i] = pos[i];
+  p->planner.updatePlanAndLocalCosts(ps, toPts(plan_xy, n_plan));
+}
 int orc_dwa_check_trajectory(void* h, const float* pos, const float* vel, const float* sample) {
   auto* p = static_cast<PlannerHandle*>(h);
   V3f ps, vl, s;

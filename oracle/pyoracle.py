@@ -138,6 +138,7 @@ def lib():
     sig("orc_dwa_cycle", i, vp, f32p, f32p, f64p, u, f64p, u, C.POINTER(PlanResult), C.c_void_p, i,
         C.c_void_p, C.c_void_p, C.c_void_p, i)
     sig("orc_dwa_check_trajectory", i, vp, f32p, f32p, f32p)
+    sig("orc_dwa_update_plan", None, vp, f32p, f64p, u)
     sig("orc_dwa_get_grid", None, vp, i, f64p)
     sig("orc_dwa_alignment_scale", d, vp)
     sig("orc_dwa_get_oscillation", None, vp, C.POINTER(u), f32p)
@@ -402,6 +403,10 @@ class DwaPlanner:
                                  cfull.ctypes.data if want_samples else None,
                                  status.ctypes.data if want_samples else None, cap if want_samples else 0)
         return res, traj[:max(res.n_points, 0)].copy(), cref[:n].copy(), cfull[:n].copy(), status[:n].copy()
+
+    def update_plan(self, pos, plan):
+        plan = _f64(plan).reshape(-1, 2)
+        self.L.orc_dwa_update_plan(self.h, _f32(pos), plan, len(plan))
 
     def check_trajectory(self, pos, vel, sample):
         return bool(self.L.orc_dwa_check_trajectory(self.h, _f32(pos), _f32(vel), _f32(sample)))

@@ -800,3 +800,90 @@ def test_planner_reconfigure_same_fleet(nav, orc):
         p.set_plan()
         _compare_cycle(fl, p, [size / 2, size / 2, 0.4], [0.2, 0.0, 0.1], ins["plan"], fp)
     fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# DWAPlannerROS control cycle: getLocalPlan -> updatePlanAndLocalCosts ->
+# DWA or latched stop-rotate, closed loop until isGoalReached; every cycle compared with the oracle
+# ----------------------------------------------------------------------------------------------
+def test_dwa_planner_ros_control_cycle(nav, orc):
+    from navigation_amd import synth
+    from oracle import local_planner_oracle as lpo
+    N = L(nav)
+    n, n_inst = 200, 3
+    size = n * synth.RES
+    cfg = nav.DwaConfig(vx_samples=8, vy_samples=3, vth_samples=9, sim_time=1.2, sim_granularity=0.1, discretize_by_time=1)
+    limits = dict(xy_goal_tolerance=0.15, yaw_goal_tolerance=0.08, rot_stopped_vel=0.01, trans_stopped_vel=0.01,
+                  max_rot_vel=cfg.max_rot_vel, min_rot_vel=cfg.min_rot_vel, acc_lim_x=cfg.acc_lim_x, acc_lim_y=cfg.acc_lim_y,
+                  acc_lim_theta=cfg.acc_lim_theta, sim_period=cfg.sim_period, prune_plan=1, latch_xy_goal_tolerance=0)
+    insts = [_inflated_instance(orc, n, 40 + i, synth) for i in range(n_inst)]
+    fl = nav.Fleet(n_inst, n, n, synth.RES, layers=N.LAYER_OBSTACLE, max_sim_steps=32, max_plan=512)
+    fl.configure_planner(cfg)
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.upload(N.GRID_MASTER, np.stack([i["master"] for i in insts]))
+    fl.configure_local_planner(**limits)
+    # before setPlan: every robot returns false, nothing is dispatched
+    r0 = fl.compute_velocity_commands(np.zeros((n_inst, 3)), np.zeros((n_inst, 3)))
+    assert all(not r.ok and r.branch == N.BRANCH_NONE for r in r0)
+    oracles, plans, Ts = [], [], []
+    for k, ins in enumerate(insts):
+        lim = dict(limits)
+        lim["latch_xy_goal_tolerance"] = 0
+        o = lpo.DwaPlannerRos(orc.DwaPlanner(ins["master"], synth.RES, 0.0, 0.0, orc.DwaConfig(**cfg.as_dict())), lim, n, n,
+                              synth.RES, synth.FOOTPRINT)
+        cx = cy = size / 2
+        length = 1.6 + 0.3 * k  # short straight-ish paths inside the obstacle-free disc around the robot
+        s = np.linspace(0.0, length, int(length / 0.05) + 1)
+        ang = 0.5 * k
+        gx, gy = cx + s * np.cos(ang), cy + s * np.sin(ang) + 0.05 * np.sin(3 * s)
+        gplan = np.stack([gx, gy, np.full_like(s, ang + 1.0)], 1)  # goal heading differs from the travel direction
+        T = None
+        if k == 1:  # this robot's plan arrives in another frame: plan = T^-1 (global)
+            T = (0.7, -0.4, 0.3)
+            c, sn = np.cos(T[2]), np.sin(T[2])
+            dx, dy = gplan[:, 0] - T[0], gplan[:, 1] - T[1]
+            gplan = np.stack([c * dx + sn * dy, -sn * dx + c * dy, gplan[:, 2] - T[2]], 1)
+        plans.append(gplan)
+        Ts.append(T)
+        oracles.append(o)
+        fl.set_global_plan(k, gplan, T)
+        o.set_plan(gplan, T)
+    pose = np.array([[size / 2, size / 2, 0.5 * k + 0.2] for k in range(n_inst)])
+    vel = np.zeros((n_inst, 3))
+    seen = [set() for _ in range(n_inst)]
+    reached = [False] * n_inst
+    dt = cfg.sim_period
+    for cyc in range(400):
+        have = [not (cyc == 5 and k == 2) for k in range(n_inst)]  # one robot loses its pose for a cycle
+        got = fl.compute_velocity_commands(pose, vel, have_pose=have)
+        for k in range(n_inst):
+            want = oracles[k].compute_velocity_commands(pose[k], vel[k], have_pose=have[k])
+            g = got[k]
+            assert bool(g.ok) == bool(want["ok"]), (cyc, k, g.branch, want)
+            assert g.branch == want["branch"], (cyc, k, g.branch, want["branch"])
+            assert tuple(g.cmd_vel) == tuple(float(v) for v in want["cmd"]), (cyc, k, tuple(g.cmd_vel), want["cmd"])
+            assert g.local_plan_points == want["local_plan_points"] and g.trajectory_points == want["trajectory_points"]
+            assert np.array_equal(fl.global_plan(k), np.asarray(oracles[k].global_plan).reshape(-1, 3)), "pruned plan differs"
+            seen[k].add(g.branch)
+        gr = fl.is_goal_reached(pose, vel)
+        for k in range(n_inst):
+            assert gr[k] == oracles[k].is_goal_reached(pose[k], vel[k])
+            reached[k] = reached[k] or gr[k]
+        if all(reached):
+            break
+        # unicycle-with-strafe integration of the commanded velocity; odometry reports the command
+        for k in range(n_inst):
+            c = got[k].cmd_vel
+            th = pose[k, 2]
+            pose[k, 0] += (c[0] * np.cos(th) - c[1] * np.sin(th)) * dt
+            pose[k, 1] += (c[0] * np.sin(th) + c[1] * np.cos(th)) * dt
+            pose[k, 2] += c[2] * dt
+            vel[k] = c
+    # parity held on every cycle above; the scenario itself must have exercised every branch
+    assert sum(reached) >= 2, (reached, [sorted(s) for s in seen], pose)
+    for k in range(n_inst):
+        assert N.BRANCH_DWA in seen[k]
+        if reached[k]:
+            assert {N.BRANCH_ROTATE, N.BRANCH_AT_GOAL} <= seen[k], sorted(seen[k])
+    assert any(N.BRANCH_STOP in s for s in seen) and any(N.BRANCH_NONE in s for s in seen)
+    fl.close()
