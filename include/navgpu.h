@@ -364,6 +364,84 @@ int navgpu_local_planner_is_goal_reached(navgpu_fleet* fleet, uint32_t first, ui
 int navgpu_local_planner_get_plan(navgpu_fleet* fleet, uint32_t instance, double* xyyaw, uint32_t capacity);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Legacy base_local_planner::TrajectoryPlanner ("Trajectory Rollout")              */
+/* ------------------------------------------------------------------------------------------ */
+/* The second nav_core::BaseLocalPlanner of the reference (TrajectoryPlannerROS).  Same structure as the
+ * DWA path - two MapGrid wavefronts (path_map_ with the cells under the robot's own footprint marked
+ * within_robot, goal_map_), a rollout per velocity sample with footprint and grid look-ups - but fp64
+ * state with acceleration-limited velocities, a different sample enumeration and a sequential, stateful
+ * selection (in-place rotation / strafing / backing up with oscillation and escape flags).  The GPU rolls
+ * out every candidate sample of createTrajectories; the host replays the reference's selection over the
+ * per-sample results.  heading_scoring and simple_attractor (both default false) are not supported. */
+typedef struct {
+  double acc_lim_x, acc_lim_y, acc_lim_theta;
+  double sim_time, sim_granularity, angular_sim_granularity;
+  double pdist_scale, gdist_scale, occdist_scale; /* after the meter_scoring multiplication, if any */
+  double heading_lookahead, oscillation_reset_dist, escape_reset_dist, escape_reset_theta;
+  double max_vel_x, min_vel_x, max_vel_th, min_vel_th, min_in_place_vel_th;
+  double backup_vel;                              /* escape_vel */
+  double sim_period;
+  double y_vels[8];
+  int32_t n_y_vels;
+  int32_t vx_samples, vtheta_samples;
+  int32_t holonomic_robot, dwa, allow_unknown;
+  int32_t heading_scoring, simple_attractor;      /* must be 0 */
+} navgpu_tp_config;
+
+/* TrajectoryPlanner members that persist between cycles (trajectory_planner.h:290-300) */
+#define NAVGPU_TP_STUCK_LEFT (1u << 0)
+#define NAVGPU_TP_STUCK_RIGHT (1u << 1)
+#define NAVGPU_TP_ROTATING_LEFT (1u << 2)
+#define NAVGPU_TP_ROTATING_RIGHT (1u << 3)
+#define NAVGPU_TP_STUCK_LEFT_STRAFE (1u << 4)
+#define NAVGPU_TP_STUCK_RIGHT_STRAFE (1u << 5)
+#define NAVGPU_TP_STRAFE_LEFT (1u << 6)
+#define NAVGPU_TP_STRAFE_RIGHT (1u << 7)
+#define NAVGPU_TP_ESCAPING (1u << 8)
+typedef struct {
+  uint32_t flags;
+  uint32_t reserved;
+  double prev_x, prev_y, escape_x, escape_y, escape_theta;
+} navgpu_tp_state;
+
+typedef struct {
+  double xv, yv, thetav, cost;   /* the returned Trajectory                                             */
+  double drive[3];               /* drive_velocities (zeros when cost < 0)                              */
+  int32_t n_points;              /* points of that trajectory                                           */
+  int32_t n_samples;             /* generateTrajectory calls the reference would have made this cycle   */
+  int32_t best_sample;           /* index of the winner among them (call order)                         */
+  int32_t reserved;
+} navgpu_tp_result;
+
+/* one generateTrajectory call as the reference makes it (call order) */
+typedef struct {
+  double vx, vy, vtheta;         /* the sample                                                          */
+  double cost;                   /* traj.cost_: >= 0, -1 (off map / collision) or -2 (no path to goal)  */
+  int32_t n_points;
+  int32_t reserved;
+} navgpu_tp_sample;
+
+/* replaces: TrajectoryPlanner::TrajectoryPlanner / reconfigure (trajectory_planner.cpp:58-172); footprint
+ * from navgpu_set_footprint.  Also sizes the per-robot sample buffers. */
+int navgpu_tp_configure(navgpu_fleet* fleet, const navgpu_tp_config* config);
+/* replaces: TrajectoryPlanner::updatePlan(new_plan, compute_dists) (:474-500) for one instance; plan_xy =
+ * n x {x, y} in the costmap's global frame. */
+int navgpu_tp_update_plan(navgpu_fleet* fleet, uint32_t instance, const double* plan_xy, uint32_t n, int32_t compute_dists);
+/* replaces: TrajectoryPlanner::findBestPath (:908-984) for instances [first, first+count): pos / vel of
+ * `states` are the Eigen::Vector3f the reference builds (plan fields ignored). */
+int navgpu_tp_find_best_path(navgpu_fleet* fleet, uint32_t first, uint32_t count, const navgpu_robot_state* states,
+                             navgpu_tp_result* results);
+/* the winning trajectory's points (x, y, theta); returns n_points or < 0 */
+int navgpu_tp_trajectory(navgpu_fleet* fleet, uint32_t instance, double* xyth, uint32_t capacity_points);
+/* the generateTrajectory calls of the last cycle of one instance, in the reference's call order */
+int navgpu_tp_samples(navgpu_fleet* fleet, uint32_t instance, navgpu_tp_sample* samples, uint32_t capacity);
+/* replaces: TrajectoryPlanner::scoreTrajectory / checkTrajectory (:502-531) against the current grids */
+int navgpu_tp_score_trajectory(navgpu_fleet* fleet, uint32_t instance, const double pose[3], const double vel[3],
+                               const double vel_samples[3], double* cost);
+int navgpu_tp_get_state(navgpu_fleet* fleet, uint32_t first, uint32_t count, navgpu_tp_state* states);
+int navgpu_tp_set_state(navgpu_fleet* fleet, uint32_t first, uint32_t count, const navgpu_tp_state* states);
+
+/* ------------------------------------------------------------------------------------------ */
 /* measurement                                                                                */
 /* ------------------------------------------------------------------------------------------ */
 typedef enum {

@@ -4,9 +4,9 @@ The product is the C-ABI shared library built from navigation_amd/csrc (HIP kern
 this package is the ctypes binding the tests, bench.py and the fleet harness use.  It never
 imports the CPU oracle and has no CPU fallback: loading fails loudly when libnavgpu.so is missing.
 """
-from ._lib import (DwaConfig, FleetDesc, InflationParams, NavgpuError, Observation, ObstacleParams, PlanResult,
+from ._lib import (TpConfig, DwaConfig, FleetDesc, InflationParams, NavgpuError, Observation, ObstacleParams, PlanResult,
                    RobotState, build, lib, lib_path)
 from .fleet import Fleet
 
-__all__ = ["Fleet", "DwaConfig", "FleetDesc", "InflationParams", "ObstacleParams", "Observation", "PlanResult",
+__all__ = ["Fleet", "TpConfig", "DwaConfig", "FleetDesc", "InflationParams", "ObstacleParams", "Observation", "PlanResult",
            "RobotState", "NavgpuError", "build", "lib", "lib_path"]

@@ -107,6 +107,57 @@ class CmdResult(C.Structure):
 BRANCH_NONE, BRANCH_DWA, BRANCH_STOP, BRANCH_ROTATE, BRANCH_AT_GOAL = range(5)
 
 
+class TpConfig(C.Structure):
+    """navgpu_tp_config; defaults are BaseLocalPlanner.cfg's (base_local_planner/cfg/BaseLocalPlanner.cfg)."""
+    _fields_ = [(n, C.c_double) for n in (
+        "acc_lim_x", "acc_lim_y", "acc_lim_theta", "sim_time", "sim_granularity", "angular_sim_granularity",
+        "pdist_scale", "gdist_scale", "occdist_scale", "heading_lookahead", "oscillation_reset_dist",
+        "escape_reset_dist", "escape_reset_theta", "max_vel_x", "min_vel_x", "max_vel_th", "min_vel_th",
+        "min_in_place_vel_th", "backup_vel", "sim_period")] + [("y_vels", C.c_double * 8)] + [
+        (n, C.c_int32) for n in ("n_y_vels", "vx_samples", "vtheta_samples", "holonomic_robot", "dwa", "allow_unknown",
+                                 "heading_scoring", "simple_attractor")]
+
+    DEFAULTS = dict(acc_lim_x=2.5, acc_lim_y=2.5, acc_lim_theta=3.2, sim_time=1.7, sim_granularity=0.025,
+                    angular_sim_granularity=0.025, pdist_scale=0.6, gdist_scale=0.8, occdist_scale=0.01,
+                    heading_lookahead=0.325, oscillation_reset_dist=0.05, escape_reset_dist=0.10,
+                    escape_reset_theta=1.5707963267948966, max_vel_x=0.55, min_vel_x=0.0, max_vel_th=1.0, min_vel_th=-1.0,
+                    min_in_place_vel_th=0.4, backup_vel=-0.1, sim_period=0.05, y_vels=(-0.3, -0.1, 0.1, 0.3),
+                    vx_samples=20, vtheta_samples=20, holonomic_robot=1, dwa=0, allow_unknown=1, heading_scoring=0,
+                    simple_attractor=0)
+
+    def __init__(self, **kw):
+        super().__init__()
+        d = dict(self.DEFAULTS)
+        d.update(kw)
+        yv = list(d.pop("y_vels"))
+        d.pop("n_y_vels", None)
+        for k, v in d.items():
+            setattr(self, k, v)
+        self.n_y_vels = len(yv)
+        for i, v in enumerate(yv):
+            self.y_vels[i] = float(v)
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("y_vels", "n_y_vels")}
+        d["y_vels"] = tuple(self.y_vels[i] for i in range(self.n_y_vels))
+        return d
+
+
+class TpState(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("reserved", C.c_uint32), ("prev_x", C.c_double), ("prev_y", C.c_double),
+                ("escape_x", C.c_double), ("escape_y", C.c_double), ("escape_theta", C.c_double)]
+
+
+class TpResult(C.Structure):
+    _fields_ = [("xv", C.c_double), ("yv", C.c_double), ("thetav", C.c_double), ("cost", C.c_double), ("drive", C.c_double * 3),
+                ("n_points", C.c_int32), ("n_samples", C.c_int32), ("best_sample", C.c_int32), ("reserved", C.c_int32)]
+
+
+class TpSample(C.Structure):
+    _fields_ = [("vx", C.c_double), ("vy", C.c_double), ("vtheta", C.c_double), ("cost", C.c_double), ("n_points", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 def lib_path():
     return os.path.join(_HERE, "libnavgpu.so")
 
@@ -160,6 +211,14 @@ SYMBOLS = [
     ("navgpu_local_planner_compute_velocity_commands", C.c_int, [vp, u32, u32, vp, vp]),
     ("navgpu_local_planner_is_goal_reached", C.c_int, [vp, u32, u32, vp, vp]),
     ("navgpu_local_planner_get_plan", C.c_int, [vp, u32, vp, u32]),
+    ("navgpu_tp_configure", C.c_int, [vp, C.POINTER(TpConfig)]),
+    ("navgpu_tp_update_plan", C.c_int, [vp, u32, vp, u32, i32]),
+    ("navgpu_tp_find_best_path", C.c_int, [vp, u32, u32, vp, vp]),
+    ("navgpu_tp_trajectory", C.c_int, [vp, u32, vp, u32]),
+    ("navgpu_tp_samples", C.c_int, [vp, u32, vp, u32]),
+    ("navgpu_tp_score_trajectory", C.c_int, [vp, u32, vp, vp, vp, C.POINTER(dbl)]),
+    ("navgpu_tp_get_state", C.c_int, [vp, u32, u32, vp]),
+    ("navgpu_tp_set_state", C.c_int, [vp, u32, u32, vp]),
     ("navgpu_profile_enable", C.c_int, [vp, i32]),
     ("navgpu_profile_reset", C.c_int, [vp]),
     ("navgpu_profile_read", C.c_int, [vp, i32, C.POINTER(dbl), C.POINTER(C.c_uint64)]),

@@ -97,6 +97,8 @@ struct PlannerDev {
   int32_t* axis_count;        // [n][4]  (nx, ny, nth, total)
   uint32_t *path, *goal, *goal_front;  // [n][cells] each
   uint32_t* bfs_scratch;      // k_bfs_global bitmaps (only for grids too large for LDS)
+  uint32_t bfs_grids;         // wavefronts per robot: 3 (DWA: path, goal, goal_front) or 2 (legacy TrajectoryPlanner)
+  const uint32_t* within;     // [n][ny][W] MapCell::within_robot bits of path_map_ (legacy planner), else null
   uint32_t win;               // edge (cells) of the costmap window staged in LDS by k_score
   uint32_t fp_rcells;         // Chebyshev radius (cells) that contains every footprint cell around the centre cell
   uint32_t use_tables, tab_steps, tab_nfp, tab_nth;
@@ -113,6 +115,31 @@ struct PlannerDev {
   navgpu_plan_result* result; // [n]
   double* traj;               // [n][max_sim_steps][3]
 };
+
+// legacy TrajectoryPlanner (tp_kernels.hip)
+struct TpOut {  // per generateTrajectory call
+  double cost;
+  double ex, ey, eth;  // Trajectory::getEndpoint
+  double ahead;        // goal_map_ at the heading_lookahead point of the endpoint
+  int32_t n_points;
+  int32_t ahead_ok;    // that point is on the map
+};
+struct TpDev {
+  navgpu_tp_config cfg;
+  uint32_t max_samples;   // capacity per robot
+  double* samples;        // [n][max_samples][3] vx, vy, vtheta
+  uint32_t* n_samples;    // [n]
+  double* start;          // [n][6] x, y, theta, vx, vy, vtheta (fp64 promotions of the Vector3f)
+  TpOut* out;             // [n][max_samples]
+  int32_t* winner;        // [n] sample whose points k_tp_rollout stores (second pass), -1 none
+  double* points;         // [n][max_sim_steps][3]
+  uint32_t* within_cells; // [n][max_within] cell indices under the robot
+  uint32_t* within_count; // [n]
+  uint32_t max_within;
+  uint32_t* within_bits;  // [n][ny][W]
+};
+void launch_tp_within(const PlannerDev& pl, const TpDev& tp, uint32_t first, uint32_t count, hipStream_t s);
+void launch_tp_rollout(const PlannerDev& pl, const TpDev& tp, uint32_t first, uint32_t count, int store_points, hipStream_t s);
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------------
 void launch_obstacle(const CostmapDev& cm, uint32_t first, uint32_t count, const double* bounds_in, int only_bounds,

@@ -173,12 +173,17 @@ __device__ __forceinline__ uint32_t adjustedPoints(const double* P, uint32_t i, 
 // Measured on MI355X (tools/microbench/lds_latency.hip): barrier 64 clk, dependent LDS read ~90 clk,
 // returning LDS atomics ~1 lane/clk/CU — hence no atomics anywhere in the level loop.
 constexpr int kPlanes = 10;
+// MapCell::within_robot (set by the legacy TrajectoryPlanner for path_map_ only, trajectory_planner.cpp:918-930):
+// obstacle cells under the robot's own footprint propagate like free cells (map_grid.cpp:109-115)
+__device__ __forceinline__ uint32_t bfsWithinWord(const PlannerDev& pl, int which, uint32_t inst, uint32_t row, uint32_t W, uint32_t wi) {
+  return (pl.within != nullptr && which == 0) ? pl.within[((size_t)inst * pl.ny + row) * W + wi] : 0u;
+}
 template <int RPT>
 __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
   extern __shared__ __align__(16) uint32_t sm[];
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_flag[3];
-  const int which = 2 - (int)blockIdx.y;  // longest searches (goal grids) are dispatched first
+  const int which = (int)pl.bfs_grids - 1 - (int)blockIdx.y;  // longest searches (goal grids) are dispatched first
   const uint32_t inst = first + blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const Geom g = geomOf(pl, inst);
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
           bits |= (obstacle ? 0u : 1u) << b;
         }
       }
-      freeb[k] = bits;
+      freeb[k] = bits | (bfsWithinWord(pl, which, inst, row, W, wi) & col_mask);
       visited[k] = ~col_mask;  // bits past the last column count as visited
       late[row * W + wi] = 0;
     }
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_flag[3];
   __shared__ uint32_t s_prog[18];  // levels published by wave w at [w + 1]; [0] and [17] are sentinels
-  const int which = 2 - (int)blockIdx.y;  // longest searches (goal grids) are dispatched first
+  const int which = (int)pl.bfs_grids - 1 - (int)blockIdx.y;  // longest searches (goal grids) are dispatched first
   const uint32_t inst = first + blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const Geom g = geomOf(pl, inst);
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
     const uint32_t row = r0 + k;
     if (owner && row < ny) {
       fr[k] = seedm[row * W + wi];  // seeds expand whatever their cost (map_grid.cpp:160-187)
-      blocked[k] = ~(bfsFreeWord(master, row, nx, wi, unknown_is_obstacle) & col_mask) | fr[k];
+      blocked[k] = ~((bfsFreeWord(master, row, nx, wi, unknown_is_obstacle) | bfsWithinWord(pl, which, inst, row, W, wi)) & col_mask) | fr[k];
     }
   }
   // edge rows of the frontier: E(buffer, strip s, first/last, wi); strip index shifted by one (zero border)
@@ -713,7 +718,7 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
   for (int k = 0; k < RPT; ++k) {
     const uint32_t row = r0 + k;
     const bool in = owner && row < ny;
-    freeb[k] = in ? (bfsFreeWord(master, row, nx, wi, unknown_is_obstacle) & col_mask) : 0u;
+    freeb[k] = in ? ((bfsFreeWord(master, row, nx, wi, unknown_is_obstacle) | bfsWithinWord(pl, which, inst, row, W, wi)) & col_mask) : 0u;
     ex[k] = in ? ((blocked[k] & freeb[k]) | seedm[row * W + wi]) : 0u;
   }
   if (owner) {
@@ -831,7 +836,7 @@ static size_t bfs_wave_lds(uint32_t nx, uint32_t ny, int rpt) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_bfs_global(PlannerDev pl, uint32_t first, uint32_t* scratch) {
   __shared__ uint32_t s_wave[16];
-  const int which = 2 - (int)blockIdx.y;  // longest searches (goal grids) are dispatched first
+  const int which = (int)pl.bfs_grids - 1 - (int)blockIdx.y;  // longest searches (goal grids) are dispatched first
   const uint32_t inst = first + blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const Geom g = geomOf(pl, inst);
@@ -856,7 +861,7 @@ __global__ __launch_bounds__(1024) void k_bfs_global(PlannerDev pl, uint32_t fir
       const bool obstacle = cst == kLethal || cst == kInscribed || (cst == kNoInfo && unknown_is_obstacle);
       bits |= (obstacle ? 0u : 1u) << b;
     }
-    fre[w] = bits;
+    fre[w] = bits | (bfsWithinWord(pl, which, inst, row, W, wi) & ((wi + 1 == W) ? last_mask : 0xFFFFFFFFu));
     vis[w] = (wi + 1 == W) ? ~last_mask : 0u;
     cur[w] = 0;
     nxt[w] = 0;
@@ -991,7 +996,7 @@ size_t bfs_scratch_words(uint32_t nx, uint32_t ny) {  // per instance, for k_bfs
 }
 
 void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
-  dim3 grid(count, 3);
+  dim3 grid(count, pl.bfs_grids);
   const size_t lds = bfs_lds_bytes(pl.nx, pl.ny);  // dense bit-parallel sweep (no LDS atomics in the loop)
   const int rpt = bfs_rows_per_thread(pl.nx, pl.ny);
   if (rpt != 0 && lds <= 156u * 1024u) {

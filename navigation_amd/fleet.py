@@ -308,6 +308,54 @@ class Fleet:
         check(self.L.navgpu_local_planner_is_goal_reached(self.h, first, len(arr), arr, out), "is_goal_reached")
         return [bool(v) for v in out]
 
+    # ---------------------------------------------------------------- legacy TrajectoryPlanner
+    def configure_trajectory_planner(self, cfg):
+        check(self.L.navgpu_tp_configure(self.h, C.byref(cfg)), "tp_configure")
+
+    def tp_update_plan(self, instance, plan_xy, compute_dists=False):
+        plan = np.ascontiguousarray(plan_xy, np.float64).reshape(-1, 2)
+        check(self.L.navgpu_tp_update_plan(self.h, instance, _ptr(plan) if len(plan) else None, len(plan), int(compute_dists)),
+              "tp_update_plan")
+
+    def tp_find_best_path(self, pos, vel, first=0):
+        """TrajectoryPlanner::findBestPath for len(pos) robots -> list of TpResult."""
+        pos = np.asarray(pos, np.float32).reshape(-1, 3)
+        vel = np.asarray(vel, np.float32).reshape(-1, 3)
+        st = (N.RobotState * len(pos))()
+        for k in range(len(pos)):
+            st[k].pos[:] = [float(v) for v in pos[k]]
+            st[k].vel[:] = [float(v) for v in vel[k]]
+        out = (N.TpResult * len(pos))()
+        check(self.L.navgpu_tp_find_best_path(self.h, first, len(pos), st, out), "tp_find_best_path")
+        return list(out)
+
+    def tp_trajectory(self, instance):
+        buf = np.zeros((self.desc.max_sim_steps, 3))
+        n = check(self.L.navgpu_tp_trajectory(self.h, instance, _ptr(buf), len(buf)), "tp_trajectory")
+        return buf[:n].copy()
+
+    def tp_samples(self, instance):
+        n = check(self.L.navgpu_tp_samples(self.h, instance, None, 0), "tp_samples")
+        arr = (N.TpSample * max(n, 1))()
+        check(self.L.navgpu_tp_samples(self.h, instance, arr, n), "tp_samples")
+        return [(a.vx, a.vy, a.vtheta, a.cost, a.n_points) for a in arr[:n]]
+
+    def tp_score_trajectory(self, instance, pose, vel, vel_samples):
+        cost = C.c_double()
+        a, b, c3 = (np.ascontiguousarray(v, np.float64) for v in (pose, vel, vel_samples))
+        check(self.L.navgpu_tp_score_trajectory(self.h, instance, _ptr(a), _ptr(b), _ptr(c3), C.byref(cost)), "tp_score_trajectory")
+        return cost.value
+
+    def tp_state(self, first=0, count=None):
+        first, count = self._range(first, count)
+        arr = (N.TpState * count)()
+        check(self.L.navgpu_tp_get_state(self.h, first, count, arr), "tp_get_state")
+        return list(arr)
+
+    def tp_set_state(self, states, first=0):
+        arr = (N.TpState * len(states))(*states)
+        check(self.L.navgpu_tp_set_state(self.h, first, len(states), arr), "tp_set_state")
+
     # ---------------------------------------------------------------- measurement
     def profile(self, enable=True):
         check(self.L.navgpu_profile_enable(self.h, int(enable)), "profile_enable")

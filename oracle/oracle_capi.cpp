@@ -4,6 +4,7 @@
 
 #include "../include/navgpu.h"  // POD layouts only (navgpu_dwa_config, navgpu_plan_result)
 #include "planner_oracle.hpp"
+#include "trajectory_planner_oracle.hpp"
 
 using namespace oracle;
 
@@ -544,4 +545,150 @@ double orc_bench_inflate(const uint8_t* cells, uint32_t n_maps, uint32_t sx, uin
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// legacy TrajectoryPlanner (trajectory_planner_oracle.hpp)
+// ---------------------------------------------------------------------------------------------
+struct TpHandle {
+  Grid2D grid;
+  TrajectoryPlannerOracle tp;
+};
+static TpConfig toTpCfg(const navgpu_tp_config& c) {
+  TpConfig o;
+  o.acc_lim_x = c.acc_lim_x;
+  o.acc_lim_y = c.acc_lim_y;
+  o.acc_lim_theta = c.acc_lim_theta;
+  o.sim_time = c.sim_time;
+  o.sim_granularity = c.sim_granularity;
+  o.angular_sim_granularity = c.angular_sim_granularity;
+  o.vx_samples = c.vx_samples <= 0 ? 1 : c.vx_samples;  // trajectory_planner.cpp:98-107
+  o.vtheta_samples = c.vtheta_samples <= 0 ? 1 : c.vtheta_samples;
+  o.pdist_scale = c.pdist_scale;
+  o.gdist_scale = c.gdist_scale;
+  o.occdist_scale = c.occdist_scale;
+  o.heading_lookahead = c.heading_lookahead;
+  o.oscillation_reset_dist = c.oscillation_reset_dist;
+  o.escape_reset_dist = c.escape_reset_dist;
+  o.escape_reset_theta = c.escape_reset_theta;
+  o.holonomic_robot = c.holonomic_robot;
+  o.max_vel_x = c.max_vel_x;
+  o.min_vel_x = c.min_vel_x;
+  o.max_vel_th = c.max_vel_th;
+  o.min_vel_th = c.min_vel_th;
+  o.min_in_place_vel_th = c.min_in_place_vel_th;
+  o.backup_vel = c.backup_vel;
+  o.dwa = c.dwa;
+  o.sim_period = c.sim_period;
+  o.n_y_vels = c.n_y_vels;
+  for (int i = 0; i < 8; ++i) o.y_vels[i] = c.y_vels[i];
+  o.allow_unknown = c.allow_unknown;
+  return o;
+}
+void* orc_tp_create(uint32_t sx, uint32_t sy, double res, double ox, double oy, const uint8_t* cells, const navgpu_tp_config* c,
+                    const double* fp_xy, uint32_t nfp) {
+  auto* h = new TpHandle();
+  h->grid.resize(sx, sy, res, ox, oy);
+  std::copy(cells, cells + size_t(sx) * sy, h->grid.cells.begin());
+  h->tp.bind(&h->grid, toTpCfg(*c), toPts(fp_xy, nfp));
+  return h;
+}
+void orc_tp_destroy(void* h) { delete static_cast<TpHandle*>(h); }
+void orc_tp_set_costmap(void* h, const uint8_t* cells) {
+  auto* p = static_cast<TpHandle*>(h);
+  std::copy(cells, cells + p->grid.cells.size(), p->grid.cells.begin());
+}
+void orc_tp_update_plan(void* h, const double* plan_xy, uint32_t n, int compute_dists) {
+  static_cast<TpHandle*>(h)->tp.updatePlan(toPts(plan_xy, n), compute_dists != 0);
+}
+int orc_tp_find_best_path(void* h, const float* pos, const float* vel, navgpu_tp_result* out, double* traj_xyth, int traj_cap,
+                          navgpu_tp_sample* samples, int sample_cap) {
+  auto* p = static_cast<TpHandle*>(h);
+  V3f ps, vl;
+  for (int i = 0; i < 3; ++i) {
+    ps[i] = pos[i];
+    vl[i] = vel[i];
+  }
+  double drive[3];
+  Trajectory best = p->tp.findBestPath(ps, vl, drive);
+  const auto& rec = p->tp.records;
+  if (out) {
+    *out = navgpu_tp_result();
+    out->xv = best.xv;
+    out->yv = best.yv;
+    out->thetav = best.thetav;
+    out->cost = best.cost;
+    for (int i = 0; i < 3; ++i) out->drive[i] = drive[i];
+    out->n_points = (int)best.x.size();
+    out->n_samples = (int)rec.size();
+    out->best_sample = -1;
+  }
+  for (size_t i = 0; i < best.x.size() && (int)i < traj_cap; ++i) {
+    traj_xyth[3 * i] = best.x[i];
+    traj_xyth[3 * i + 1] = best.y[i];
+    traj_xyth[3 * i + 2] = best.th[i];
+  }
+  for (size_t i = 0; i < rec.size() && (int)i < sample_cap; ++i)
+    samples[i] = navgpu_tp_sample{rec[i].vx, rec[i].vy, rec[i].vth, rec[i].cost, rec[i].n_points, 0};
+  return (int)rec.size();
+}
+double orc_tp_score_trajectory(void* h, const double* pose, const double* vel, const double* vs) {
+  return static_cast<TpHandle*>(h)->tp.scoreTrajectory(pose[0], pose[1], pose[2], vel[0], vel[1], vel[2], vs[0], vs[1], vs[2]);
+}
+// raw generateTrajectory with explicit acceleration limits and impossible_cost (utest.cpp:75-102)
+double orc_tp_generate(void* h, const double* pose, const double* vel, const double* vs, const double* acc, double impossible_cost) {
+  Trajectory t;
+  static_cast<TpHandle*>(h)->tp.generateTrajectory(pose[0], pose[1], pose[2], vel[0], vel[1], vel[2], vs[0], vs[1], vs[2], acc[0], acc[1],
+                                                   acc[2], impossible_cost, t);
+  return t.cost;
+}
+void orc_tp_get_grid(void* h, int which, double* out) {
+  auto* p = static_cast<TpHandle*>(h);
+  const MapGridOracle& g = which == 0 ? p->tp.path_map : p->tp.goal_map;
+  std::copy(g.dist.begin(), g.dist.end(), out);
+}
+void orc_tp_get_state(void* h, navgpu_tp_state* s) {
+  const TrajectoryPlannerOracle& t = static_cast<TpHandle*>(h)->tp;
+  s->flags = (t.stuck_left ? NAVGPU_TP_STUCK_LEFT : 0) | (t.stuck_right ? NAVGPU_TP_STUCK_RIGHT : 0) |
+             (t.rotating_left ? NAVGPU_TP_ROTATING_LEFT : 0) | (t.rotating_right ? NAVGPU_TP_ROTATING_RIGHT : 0) |
+             (t.stuck_left_strafe ? NAVGPU_TP_STUCK_LEFT_STRAFE : 0) | (t.stuck_right_strafe ? NAVGPU_TP_STUCK_RIGHT_STRAFE : 0) |
+             (t.strafe_left ? NAVGPU_TP_STRAFE_LEFT : 0) | (t.strafe_right ? NAVGPU_TP_STRAFE_RIGHT : 0) |
+             (t.escaping ? NAVGPU_TP_ESCAPING : 0);
+  s->reserved = 0;
+  s->prev_x = t.prev_x;
+  s->prev_y = t.prev_y;
+  s->escape_x = t.escape_x;
+  s->escape_y = t.escape_y;
+  s->escape_theta = t.escape_theta;
+}
+void orc_tp_set_state(void* h, const navgpu_tp_state* s) {
+  TrajectoryPlannerOracle& t = static_cast<TpHandle*>(h)->tp;
+  t.stuck_left = s->flags & NAVGPU_TP_STUCK_LEFT;
+  t.stuck_right = s->flags & NAVGPU_TP_STUCK_RIGHT;
+  t.rotating_left = s->flags & NAVGPU_TP_ROTATING_LEFT;
+  t.rotating_right = s->flags & NAVGPU_TP_ROTATING_RIGHT;
+  t.stuck_left_strafe = s->flags & NAVGPU_TP_STUCK_LEFT_STRAFE;
+  t.stuck_right_strafe = s->flags & NAVGPU_TP_STUCK_RIGHT_STRAFE;
+  t.strafe_left = s->flags & NAVGPU_TP_STRAFE_LEFT;
+  t.strafe_right = s->flags & NAVGPU_TP_STRAFE_RIGHT;
+  t.escaping = s->flags & NAVGPU_TP_ESCAPING;
+  t.prev_x = s->prev_x;
+  t.prev_y = s->prev_y;
+  t.escape_x = s->escape_x;
+  t.escape_y = s->escape_y;
+  t.escape_theta = s->escape_theta;
+}
+// FootprintHelper::getFootprintCells on a map of the given geometry; returns the number of cells
+int orc_tp_footprint_cells(uint32_t sx, uint32_t sy, double res, double ox, double oy, const float* pos, const double* fp_xy, uint32_t nfp,
+                           int fill, int32_t* out_xy, int cap) {
+  Grid2D g;
+  g.resize(sx, sy, res, ox, oy);
+  V3f ps;
+  for (int i = 0; i < 3; ++i) ps[i] = pos[i];
+  std::vector<FpCell> c = getFootprintCells(ps, toPts(fp_xy, nfp), g, fill != 0);
+  for (size_t i = 0; i < c.size() && (int)i < cap; ++i) {
+    out_xy[2 * i] = c[i].x;
+    out_xy[2 * i + 1] = c[i].y;
+  }
+  return (int)c.size();
+}
 }  // extern "C"

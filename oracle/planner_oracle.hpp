@@ -342,6 +342,7 @@ struct MapGridOracle {
   uint32_t size_x = 0, size_y = 0;
   std::vector<double> dist;
   std::vector<uint8_t> mark;
+  std::vector<uint8_t> within_robot;  // MapCell::within_robot; only TrajectoryPlanner::findBestPath sets it (path_map_)
   double goal_x = 0, goal_y = 0;
   bool allow_unknown = true;
   double obstacleCosts() const { return (double)dist.size(); }
@@ -350,6 +351,7 @@ struct MapGridOracle {
     if (dist.size() != size_t(sx) * sy) {
       dist.resize(size_t(sx) * sy);
       mark.resize(size_t(sx) * sy);
+      within_robot.assign(size_t(sx) * sy, 0);
     }
     size_x = sx;
     size_y = sy;
@@ -359,6 +361,7 @@ struct MapGridOracle {
       dist[i] = unreachableCellCosts();
       mark[i] = 0;
     }
+    within_robot.assign(dist.size(), 0);  // map_grid.cpp:126-132
   }
   static void adjustPlanResolution(const std::vector<Pt2>& in, std::vector<Pt2>& out, double resolution) {  // :135-171
     if (in.size() == 0) return;
@@ -384,9 +387,9 @@ struct MapGridOracle {
       last_y = loop_y;
     }
   }
-  bool updatePathCell(size_t cur, size_t chk, const Grid2D& cm) {  // :103-122 (within_robot always false, :131)
+  bool updatePathCell(size_t cur, size_t chk, const Grid2D& cm) {  // :103-122
     uint8_t cost = cm.cells[chk];
-    if (cost == LETHAL_OBSTACLE || cost == INSCRIBED_INFLATED_OBSTACLE || (cost == NO_INFORMATION && !allow_unknown)) {
+    if (!(chk < within_robot.size() && within_robot[chk]) && (cost == LETHAL_OBSTACLE || cost == INSCRIBED_INFLATED_OBSTACLE || (cost == NO_INFORMATION && !allow_unknown))) {
       dist[chk] = obstacleCosts();
       return false;
     }

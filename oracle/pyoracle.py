@@ -143,6 +143,17 @@ def lib():
     sig("orc_dwa_alignment_scale", d, vp)
     sig("orc_dwa_get_oscillation", None, vp, C.POINTER(u), f32p)
     sig("orc_dwa_set_oscillation", None, vp, u, f32p)
+    sig("orc_tp_create", vp, u, u, d, d, d, u8p, C.c_void_p, f64p, u)
+    sig("orc_tp_destroy", None, vp)
+    sig("orc_tp_set_costmap", None, vp, u8p)
+    sig("orc_tp_update_plan", None, vp, C.c_void_p, u, i)
+    sig("orc_tp_find_best_path", i, vp, f32p, f32p, C.c_void_p, C.c_void_p, i, C.c_void_p, i)
+    sig("orc_tp_score_trajectory", d, vp, f64p, f64p, f64p)
+    sig("orc_tp_generate", d, vp, f64p, f64p, f64p, f64p, d)
+    sig("orc_tp_get_grid", None, vp, i, f64p)
+    sig("orc_tp_get_state", None, vp, C.c_void_p)
+    sig("orc_tp_set_state", None, vp, C.c_void_p)
+    sig("orc_tp_footprint_cells", i, u, u, d, d, d, f32p, f64p, u, i, C.c_void_p, i)
     sig("orc_bench_dwa", d, u, u, d, u8p, u, C.POINTER(DwaConfig), f32p, f32p, f64p, u, f64p, f64p, u, u, u,
         C.POINTER(C.c_uint64))
     sig("orc_bench_inflate", d, u8p, u, u, u, d, d, d, d, u, u)
@@ -424,3 +435,64 @@ class DwaPlanner:
 
     def set_oscillation(self, flags, prev=(0, 0, 0)):
         self.L.orc_dwa_set_oscillation(self.h, int(flags), _f32(prev))
+
+
+class TrajectoryPlanner:
+    """Legacy base_local_planner::TrajectoryPlanner oracle (trajectory_planner_oracle.hpp).  `cfg`, result, state and
+    sample records use the product's POD layouts (ctypes mirrors passed in by the tests) - layouts only."""
+
+    def __init__(self, grid, res, cfg, footprint, ox=0.0, oy=0.0):
+        self.L = lib()
+        g = np.ascontiguousarray(grid, np.uint8)
+        self.shape = g.shape
+        fp = _f64(footprint).reshape(-1, 2)
+        self.h = self.L.orc_tp_create(g.shape[1], g.shape[0], res, ox, oy, g, C.addressof(cfg), fp, len(fp))
+
+    def __del__(self):
+        try:
+            self.L.orc_tp_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_costmap(self, grid):
+        self.L.orc_tp_set_costmap(self.h, np.ascontiguousarray(grid, np.uint8))
+
+    def update_plan(self, plan_xy, compute_dists=False):
+        plan = _f64(plan_xy).reshape(-1, 2)
+        self.L.orc_tp_update_plan(self.h, plan.ctypes.data if len(plan) else None, len(plan), int(compute_dists))
+
+    def find_best_path(self, pos, vel, result_type, sample_type, traj_cap=1024, sample_cap=4096):
+        res = result_type()
+        traj = np.zeros((traj_cap, 3), np.float64)
+        samples = (sample_type * sample_cap)()
+        n = self.L.orc_tp_find_best_path(self.h, _f32(pos), _f32(vel), C.addressof(res), traj.ctypes.data, traj_cap,
+                                         C.addressof(samples), sample_cap)
+        return res, traj[:res.n_points].copy(), [(s.vx, s.vy, s.vtheta, s.cost, s.n_points) for s in samples[:n]]
+
+    def score_trajectory(self, pose, vel, vel_samples):
+        return self.L.orc_tp_score_trajectory(self.h, _f64(pose), _f64(vel), _f64(vel_samples))
+
+    def generate(self, pose, vel, vel_samples, acc, impossible_cost):
+        return self.L.orc_tp_generate(self.h, _f64(pose), _f64(vel), _f64(vel_samples), _f64(acc), float(impossible_cost))
+
+    def grid(self, which):
+        out = np.zeros(self.shape, np.float64)
+        self.L.orc_tp_get_grid(self.h, which, out)
+        return out
+
+    def state(self, state_type):
+        s = state_type()
+        self.L.orc_tp_get_state(self.h, C.addressof(s))
+        return s
+
+    def set_state(self, s):
+        self.L.orc_tp_set_state(self.h, C.addressof(s))
+
+
+def footprint_cells(size_x, size_y, res, pos, footprint, fill=True, ox=0.0, oy=0.0, cap=65536):
+    """FootprintHelper::getFootprintCells -> list of (x, y) cells in the reference's order."""
+    L = lib()
+    fp = _f64(footprint).reshape(-1, 2)
+    out = np.zeros((cap, 2), np.int32)
+    n = L.orc_tp_footprint_cells(size_x, size_y, res, ox, oy, _f32(pos), fp, len(fp), int(fill), out.ctypes.data, cap)
+    return [tuple(int(v) for v in c) for c in out[:n]]

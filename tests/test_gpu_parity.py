@@ -887,3 +887,127 @@ def test_dwa_planner_ros_control_cycle(nav, orc):
             assert {N.BRANCH_ROTATE, N.BRANCH_AT_GOAL} <= seen[k], sorted(seen[k])
     assert any(N.BRANCH_STOP in s for s in seen) and any(N.BRANCH_NONE in s for s in seen)
     fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# Legacy base_local_planner::TrajectoryPlanner: MapGrids with within_robot, every
+# generateTrajectory call (sample, cost, points), the stateful selection, scoreTrajectory
+# ----------------------------------------------------------------------------------------------
+def _tp_compare_cycle(fl, N, oracles, pos, vel, cyc=0):
+    got = fl.tp_find_best_path(pos, vel)
+    for k, o in enumerate(oracles):
+        want, wtraj, wsamples = o.find_best_path(pos[k], vel[k], N.TpResult, N.TpSample)
+        g = got[k]
+        ny, nx = o.shape
+        for gid, which in ((N.GRID_PATH, 0), (N.GRID_GOAL, 1)):
+            gg = fl.download(gid, k, 1)[0].reshape(ny, nx).astype(np.float64)
+            assert np.array_equal(gg, o.grid(which)), f"MapGrid {which} differs (robot {k}, cycle {cyc})"
+        gs = fl.tp_samples(k)
+        assert len(gs) == len(wsamples) == g.n_samples == want.n_samples, (cyc, k, len(gs), len(wsamples))
+        for a, b in zip(gs, wsamples):
+            assert a[:3] == b[:3], ("sample velocities differ", cyc, k, a, b)
+            assert (a[3] < 0) == (b[3] < 0) and a[4] == b[4], ("legality / length differs", cyc, k, a, b)
+            if b[3] < 0:
+                assert a[3] == b[3], ("failure code differs", cyc, k, a, b)
+            else:
+                assert abs(a[3] - b[3]) <= 1e-9 * max(1.0, abs(b[3])), ("cost differs", cyc, k, a, b)
+        assert (g.xv, g.yv, g.thetav) == (want.xv, want.yv, want.thetav), (cyc, k, (g.xv, g.yv, g.thetav), (want.xv, want.yv, want.thetav))
+        assert abs(g.cost - want.cost) <= 1e-9 * max(1.0, abs(want.cost)) and tuple(g.drive) == tuple(want.drive)
+        assert g.n_points == want.n_points
+        t = fl.tp_trajectory(k)
+        assert t.shape == wtraj.shape and np.allclose(t, wtraj, rtol=0, atol=1e-12)
+        gst, wst = fl.tp_state(k, 1)[0], o.state(N.TpState)
+        assert (gst.flags, gst.prev_x, gst.prev_y, gst.escape_x, gst.escape_y, gst.escape_theta) == \
+               (wst.flags, wst.prev_x, wst.prev_y, wst.escape_x, wst.escape_y, wst.escape_theta), (cyc, k, gst.flags, wst.flags)
+    return got
+
+
+@pytest.mark.parametrize("holonomic,dwa", [(1, 0), (0, 1)])
+def test_trajectory_planner_cycles(nav, orc, holonomic, dwa):
+    from navigation_amd import synth
+    N = L(nav)
+    n, n_inst = 160, 3
+    size = n * synth.RES
+    cfg = N.TpConfig(vx_samples=6, vtheta_samples=9, sim_time=1.2, sim_granularity=0.05, angular_sim_granularity=0.05,
+                     holonomic_robot=holonomic, dwa=dwa)
+    insts = [_inflated_instance(orc, n, 60 + i, synth) for i in range(n_inst)]
+    # robot 2 starts boxed in by a lethal ring: nothing legal but backing up -> escape mode
+    c = n // 2
+    ring = insts[2]["master"]
+    d = np.abs(np.arange(-6, 7))
+    ring[c - 6:c + 7, c - 6:c + 7] = np.where((d[:, None] >= 5) | (d[None, :] >= 5), LETHAL, ring[c - 6:c + 7, c - 6:c + 7])
+    fl = nav.Fleet(n_inst, n, n, synth.RES, layers=N.LAYER_OBSTACLE, max_sim_steps=64, max_plan=256)
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.upload(N.GRID_MASTER, np.stack([i["master"] for i in insts]))
+    fl.configure_trajectory_planner(cfg)
+    oracles = [orc.TrajectoryPlanner(i["master"], synth.RES, cfg, synth.FOOTPRINT) for i in insts]
+    for k, ins in enumerate(insts):
+        fl.tp_update_plan(k, ins["plan"], compute_dists=(k == 0))
+        oracles[k].update_plan(ins["plan"], compute_dists=(k == 0))
+    # updatePlan(compute_dists=true) fills the grids without within_robot
+    for gid, which in ((N.GRID_PATH, 0), (N.GRID_GOAL, 1)):
+        assert np.array_equal(fl.download(gid, 0, 1)[0].reshape(n, n).astype(np.float64), oracles[0].grid(which))
+    pos = np.array([[size / 2, size / 2, 0.3 + 0.9 * k] for k in range(n_inst)], np.float32)
+    vel = np.zeros((n_inst, 3), np.float32)
+    vel[0] = (0.2, 0.0, 0.1)
+    stages = set()
+    for cyc in range(14):
+        got = _tp_compare_cycle(fl, N, oracles, pos, vel, cyc)
+        # scoreTrajectory / checkTrajectory against the grids of this cycle
+        for k in range(n_inst):
+            for vs in ((0.3, 0.0, 0.2), (0.0, 0.0, -0.8), (-0.1, 0.0, 0.0)):
+                a = fl.tp_score_trajectory(k, pos[k].astype(np.float64), vel[k].astype(np.float64), vs)
+                b = oracles[k].score_trajectory(pos[k].astype(np.float64), vel[k].astype(np.float64), vs)
+                assert (a < 0 and a == b) or (a >= 0 and abs(a - b) <= 1e-9 * max(1.0, abs(b))), (cyc, k, vs, a, b)
+        dt = 0.1
+        for k in range(n_inst):
+            r = got[k]
+            stages.add((k, r.xv > 0, r.thetav != 0, r.cost))
+            th = float(pos[k, 2])
+            pos[k, 0] += (r.drive[0] * np.cos(th) - r.drive[1] * np.sin(th)) * dt
+            pos[k, 1] += (r.drive[0] * np.sin(th) + r.drive[1] * np.cos(th)) * dt
+            pos[k, 2] += r.drive[2] * dt
+            vel[k] = r.drive
+        if cyc == 6:  # a new, shorter plan for robot 1 (final-goal speed cap); an empty plan for nobody
+            fl.tp_update_plan(1, insts[1]["plan"][:25])
+            oracles[1].update_plan(insts[1]["plan"][:25])
+    # state equality is asserted every cycle above; the boxed-in robot must have gone through escape mode
+    assert any(c == 1.0 for (k, fwd, rot, c) in stages if k == 2), sorted(stages)
+    fl.close()
+
+
+def test_trajectory_planner_edge_cases(nav, orc):
+    """Other wavefront kernels (600x600 -> k_bfs<12>, 1000x1000 -> k_bfs_global) with within_robot, a circular
+    (2-vertex) footprint, an empty plan, a robot next to the map border, unsupported options."""
+    from navigation_amd import synth
+    N = L(nav)
+    for n, fp in ((600, synth.FOOTPRINT), (1000, synth.FOOTPRINT5), (120, np.array([[0.1, 0.0], [-0.1, 0.0]]))):
+        ins = _inflated_instance(orc, n, 70, synth)
+        m = ins["master"]
+        size = n * synth.RES
+        cc = n // 2
+        m[cc - 2:cc + 3, cc - 2:cc + 3] = LETHAL  # an obstacle under the robot: within_robot lets the wavefront through
+        cfg = N.TpConfig(vx_samples=4, vtheta_samples=5, sim_time=1.0, sim_granularity=0.05, angular_sim_granularity=0.05)
+        fl = nav.Fleet(1, n, n, synth.RES, layers=N.LAYER_OBSTACLE, max_sim_steps=64, max_plan=256, max_footprint=16)
+        fl.set_footprint(fp)
+        fl.upload(N.GRID_MASTER, m)
+        fl.configure_trajectory_planner(cfg)
+        o = orc.TrajectoryPlanner(m, synth.RES, cfg, fp)
+        fl.tp_update_plan(0, ins["plan"])
+        o.update_plan(ins["plan"])
+        pos = np.array([[size / 2, size / 2, 0.7]], np.float32)
+        _tp_compare_cycle(fl, N, [o], pos, np.zeros((1, 3), np.float32))
+        if n == 120:
+            # empty plan: every cell unreachable; nothing forward is legal, the planner falls through to backing up
+            fl.tp_update_plan(0, np.zeros((0, 2)))
+            o.update_plan(np.zeros((0, 2)))
+            got = _tp_compare_cycle(fl, N, [o], pos, np.zeros((1, 3), np.float32), 1)
+            assert got[0].xv == cfg.backup_vel and got[0].best_sample == got[0].n_samples - 1
+            # robot at the map border: samples leave the map
+            fl.tp_update_plan(0, ins["plan"])
+            o.update_plan(ins["plan"])
+            edge = np.array([[size - 0.12, size / 2, 0.0]], np.float32)
+            _tp_compare_cycle(fl, N, [o], edge, np.array([[0.3, 0.0, 0.0]], np.float32), 2)
+            with pytest.raises(nav.NavgpuError):
+                fl.configure_trajectory_planner(N.TpConfig(heading_scoring=1))
+        fl.close()

@@ -364,3 +364,44 @@ def test_inflation_exact_equals_pq_on_reference_fixtures(orc, ten_by_ten):
         scenarios.append(outs)
     for a, b in zip(*scenarios):
         assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ base_local_planner/test/footprint_helper_test.cpp:44-132
+def test_footprint_helper_cells_in_reference_order(orc):
+    fp = [[2, 2], [2, -2], [-2, -2], [-2, 2]]
+    c = orc.footprint_cells(10, 10, 1.0, [4.5, 4.5, 0.0], fp, fill=False)
+    assert len(c) == 20
+    assert c[0:5] == [(6, 6), (6, 5), (6, 4), (6, 3), (6, 2)]      # front line first
+    assert c[5:10] == [(6, 2), (5, 2), (4, 2), (3, 2), (2, 2)]     # right line
+    assert c[10:15] == [(2, 2), (2, 3), (2, 4), (2, 5), (2, 6)]    # back line
+    assert c[15:20] == [(2, 6), (3, 6), (4, 6), (5, 6), (6, 6)]    # left line
+    c = orc.footprint_cells(10, 10, 1.0, [4.5, 4.5, math.pi / 2], fp, fill=False)
+    assert c[0:5] == [(2, 6), (3, 6), (4, 6), (5, 6), (6, 6)]
+    assert c[5:10] == [(6, 6), (6, 5), (6, 4), (6, 3), (6, 2)]
+    assert c[10:15] == [(6, 2), (5, 2), (4, 2), (3, 2), (2, 2)]
+    assert c[15:20] == [(2, 2), (2, 3), (2, 4), (2, 5), (2, 6)]
+    # fill (used by TrajectoryPlanner::findBestPath for within_robot): outline + interior, every cell of the square covered
+    filled = set(orc.footprint_cells(10, 10, 1.0, [4.5, 4.5, 0.0], fp, fill=True))
+    assert filled == {(x, y) for x in range(2, 7) for y in range(2, 7)}
+
+
+# ------------------------------------------------------------------ base_local_planner/test/utest.cpp:56-102
+def test_trajectory_planner_footprint_obstacles(orc):
+    """TrajectoryPlannerTest::footprintObstacles: tc(cm, map, footprint, acc 0/1/1, sim_time 1, sim_granularity 1, vx_samples 2)."""
+    from navigation_amd import _lib as N  # POD layout of the configuration only
+    cfg = N.TpConfig(acc_lim_x=0.0, acc_lim_y=1.0, acc_lim_theta=1.0, sim_time=1.0, sim_granularity=1.0, vx_samples=2)
+    fp = [[2, 2], [2, -2], [-2, -2], [-2, 2]]
+    g = np.zeros((10, 10), np.uint8)
+    g[6, 4] = LETHAL  # map_(4, 6).target_dist = 1; wa->synchronize()
+    tp = orc.TrajectoryPlanner(g, 1.0, cfg, fp)
+    # generateTrajectory(4.5, 4.5, M_PI_2, 0, 0, 0, 4, 0, 0, 4, 0, 0, DBL_MAX, traj): drives into the obstacle
+    assert tp.generate([4.5, 4.5, math.pi / 2], [0, 0, 0], [4, 0, 0], [4, 0, 0], 1.7976931348623157e308) == -1.0
+    for y in (1, 3, 4, 5, 6, 7):  # the wall next to the footprint
+        g[y, 7] = LETHAL
+    tp.set_costmap(g)
+    # generateTrajectory(4.5, 4.5, M_PI_2, 0, 0, 0, 0, 0, M_PI_2, 0, 0, M_PI_4, 100, traj): rotates into the wall
+    assert tp.generate([4.5, 4.5, math.pi / 2], [0, 0, 0], [0, 0, math.pi / 2], [0, 0, math.pi / 4], 100) == -1.0
+    # and without the obstacles the same two commands are legal (the -1 above comes from the footprint test)
+    tp.set_costmap(np.zeros((10, 10), np.uint8))
+    tp.update_plan([[4.5, 8.5]], compute_dists=True)
+    assert tp.generate([4.5, 4.5, math.pi / 2], [0, 0, 0], [0, 0, math.pi / 2], [0, 0, math.pi / 4], 100) >= 0
