@@ -104,6 +104,46 @@ def hbm_traffic_from_profiles(kernel):
         return None, None
 
 
+def legacy_leg(nav, insts, n_cells, masters, with_cpu, device):
+    """SURVEY 8f-3: TrajectoryPlanner::findBestPath (BaseLocalPlanner.cfg defaults: 20 x 20 samples, two wavefronts)
+    for a fleet of 32 robots; PCIe- and host-selection-inclusive by construction.  CPU: the oracle, one thread."""
+    from navigation_amd import _lib as N, synth
+    ns = min(len(masters), 32)
+    cfg = N.TpConfig()
+    fl = nav.Fleet(ns, n_cells, n_cells, synth.RES, layers=N.LAYER_OBSTACLE, max_sim_steps=96, max_plan=256, device=device)
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.upload(N.GRID_MASTER, np.ascontiguousarray(masters[:ns]))
+    fl.configure_trajectory_planner(cfg)
+    for k in range(ns):
+        fl.tp_update_plan(k, insts[k]["plan"])
+    pos = np.stack([i["pos"] for i in insts[:ns]]).astype(np.float32)
+    vel = np.stack([i["vel"] for i in insts[:ns]]).astype(np.float32)
+    r = fl.tp_find_best_path(pos, vel)
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = fl.tp_find_best_path(pos, vel)
+    dt = time.perf_counter() - t0
+    calls = sum(x.n_samples for x in r)
+    out = {"workload": f"{ns} robots, {n_cells}x{n_cells}, vx_samples 20 x vtheta_samples 20, sim_time 1.7 / 0.025",
+           "ms_per_cycle": dt / reps * 1e3, "trajectories_per_s": calls * reps / dt, "generate_calls_per_cycle": calls}
+    fl.close()
+    if with_cpu:
+        from oracle import pyoracle as orc
+        k_cpu = min(ns, 4)
+        oracles = [orc.TrajectoryPlanner(masters[k], synth.RES, cfg, synth.FOOTPRINT) for k in range(k_cpu)]
+        for k, o in enumerate(oracles):
+            o.update_plan(insts[k]["plan"])
+        t0 = time.perf_counter()
+        n_calls = 0
+        for k, o in enumerate(oracles):
+            res, _, _ = o.find_best_path(pos[k], vel[k], N.TpResult, N.TpSample)
+            n_calls += res.n_samples
+        dc = time.perf_counter() - t0
+        out["cpu_port"] = {"trajectories_per_s": n_calls / dc, "cores": 1, "sample": f"{k_cpu} robots x 1 cycle"}
+    return out
+
+
 def step(fl):
     fl.update_map()
     fl.planner_cycle()
@@ -334,6 +374,8 @@ def main():
                                    "ms_per_cycle": d1 / k1 * 1e3, "trajectories_per_s": r1.n_scored * k1 / d1,
                                    "n_scored": r1.n_scored}
             f1.close()
+        if not args.no_single:
+            out["legacy_trajectory_planner"] = legacy_leg(nav, insts, n_cells, masters, not args.no_cpu_baseline, local_rank)
         if not args.no_cpu_baseline:
             ns = min(n_inst, 32)
             out["cpu_baseline"] = cpu_baseline(insts[:ns], cfg, n_cells, masters[:ns])

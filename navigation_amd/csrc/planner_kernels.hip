@@ -466,13 +466,15 @@ __device__ __forceinline__ uint32_t fromLaneAbove(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 }
 
-template <int RPT>
+// LEGACY = the two-grid launch of the legacy TrajectoryPlanner with within_robot bits; the DWA instantiation
+// keeps the constants (and the register allocation) it was tuned with
+template <int RPT, bool LEGACY>
 __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first) {
   extern __shared__ __align__(16) uint32_t sm[];
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_flag[3];
   __shared__ uint32_t s_prog[18];  // levels published by wave w at [w + 1]; [0] and [17] are sentinels
-  const int which = (int)pl.bfs_grids - 1 - (int)blockIdx.y;  // longest searches (goal grids) are dispatched first
+  const int which = (LEGACY ? 1 : 2) - (int)blockIdx.y;  // longest searches (goal grids) are dispatched first
   const uint32_t inst = first + blockIdx.x;
   const uint32_t tid = threadIdx.x;
   const Geom g = geomOf(pl, inst);
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
     const uint32_t row = r0 + k;
     if (owner && row < ny) {
       fr[k] = seedm[row * W + wi];  // seeds expand whatever their cost (map_grid.cpp:160-187)
-      blocked[k] = ~((bfsFreeWord(master, row, nx, wi, unknown_is_obstacle) | bfsWithinWord(pl, which, inst, row, W, wi)) & col_mask) | fr[k];
+      blocked[k] = ~((bfsFreeWord(master, row, nx, wi, unknown_is_obstacle) | (LEGACY ? bfsWithinWord(pl, which, inst, row, W, wi) : 0u)) & col_mask) | fr[k];
     }
   }
   // edge rows of the frontier: E(buffer, strip s, first/last, wi); strip index shifted by one (zero border)
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
   for (int k = 0; k < RPT; ++k) {
     const uint32_t row = r0 + k;
     const bool in = owner && row < ny;
-    freeb[k] = in ? ((bfsFreeWord(master, row, nx, wi, unknown_is_obstacle) | bfsWithinWord(pl, which, inst, row, W, wi)) & col_mask) : 0u;
+    freeb[k] = in ? ((bfsFreeWord(master, row, nx, wi, unknown_is_obstacle) | (LEGACY ? bfsWithinWord(pl, which, inst, row, W, wi) : 0u)) & col_mask) : 0u;
     ex[k] = in ? ((blocked[k] & freeb[k]) | seedm[row * W + wi]) : 0u;
   }
   if (owner) {
@@ -1009,8 +1011,13 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
       static const bool force_lds_kernel = getenv("NAVGPU_DEBUG_BFS_LDS") != nullptr;  // A/B timing only
       if (bfs_wave_fits(pl.nx, pl.ny, 7) && !force_lds_kernel) {
         const size_t lds_w = bfs_wave_lds(pl.nx, pl.ny, 7);
-        if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
-        hipLaunchKernelGGL(k_bfs_wave<7>, grid, dim3(1024), lds_w, s, pl, first);
+        if (pl.bfs_grids == 2) {
+          if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
+          hipLaunchKernelGGL((k_bfs_wave<7, true>), grid, dim3(1024), lds_w, s, pl, first);
+        } else {
+          if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
+          hipLaunchKernelGGL((k_bfs_wave<7, false>), grid, dim3(1024), lds_w, s, pl, first);
+        }
         return;
       }
       NAVGPU_BFS(6)

@@ -42,15 +42,17 @@ def test_struct_sizes_match_header(nav, tmp_path):
     from navigation_amd import _lib
     from oracle import pyoracle
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "navgpu.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "navgpu.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(navgpu_fleet_desc),sizeof(navgpu_observation),sizeof(navgpu_obstacle_params),'
                    'sizeof(navgpu_inflation_params),sizeof(navgpu_dwa_config),sizeof(navgpu_robot_state),'
-                   'sizeof(navgpu_plan_result));return 0;}\n')
+                   'sizeof(navgpu_plan_result),sizeof(navgpu_local_limits),sizeof(navgpu_robot_input),sizeof(navgpu_cmd_result),'
+                   'sizeof(navgpu_tp_config),sizeof(navgpu_tp_state),sizeof(navgpu_tp_result),sizeof(navgpu_tp_sample));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     mirrors = [_lib.FleetDesc, _lib.Observation, _lib.ObstacleParams, _lib.InflationParams, _lib.DwaConfig, _lib.RobotState,
-               _lib.PlanResult]
+               _lib.PlanResult, _lib.LocalLimits, _lib.RobotInput, _lib.CmdResult, _lib.TpConfig, _lib.TpState, _lib.TpResult,
+               _lib.TpSample]
     assert sizes == [C.sizeof(m) for m in mirrors]
     assert C.sizeof(pyoracle.DwaConfig) == C.sizeof(_lib.DwaConfig)
     assert C.sizeof(pyoracle.PlanResult) == C.sizeof(_lib.PlanResult)
