@@ -468,7 +468,9 @@ __device__ __forceinline__ uint32_t fromLaneAbove(uint32_t v) {
 
 // LEGACY = the two-grid launch of the legacy TrajectoryPlanner with within_robot bits; the DWA instantiation
 // keeps the constants (and the register allocation) it was tuned with
-template <int RPT, bool LEGACY>
+// PL = level planes kept in registers: 10 (epochs of 1023 levels) for RPT 7; 3 (epochs of 7 levels, the cells written out
+// at every epoch end) for RPT 13, which extends the kernel to maps of up to 640 x 624 cells
+template <int RPT, bool LEGACY, int PL>
 __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first) {
   extern __shared__ __align__(16) uint32_t sm[];
   __shared__ uint32_t s_wave[16];
@@ -555,9 +557,9 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
   __syncthreads();
 
   uint32_t blocked[RPT], fr[RPT];
-  uint32_t plane[kPlanes][RPT];
+  uint32_t plane[PL][RPT];
 #pragma unroll
-  for (int b = 0; b < kPlanes; ++b)
+  for (int b = 0; b < PL; ++b)
 #pragma unroll
     for (int k = 0; k < RPT; ++k) plane[b][k] = 0;
 #pragma unroll
@@ -584,10 +586,10 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
   __syncthreads();
 
   // --- level-synchronous expansion, ONE barrier per level (three rotating "anything new" flags).
-  // Levels are recorded bit-sliced relative to an epoch of 2^kPlanes - 1 levels; in the rare case of a
+  // Levels are recorded bit-sliced relative to an epoch of 2^PL - 1 levels; in the rare case of a
   // longer search the cells of a finished epoch are written out and the planes start again.
   const uint32_t base_w = r0 * W + wi;
-  constexpr uint32_t kEpoch = (1u << kPlanes) - 1u;
+  constexpr uint32_t kEpoch = (1u << PL) - 1u;
   constexpr int kLow = 3;  // planes 0..2 are updated every level, the others once per block of 8 levels
   uint32_t level = 0, epoch_base = 0;
   uint32_t bstart[RPT];    // `blocked` at the start of the current block
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
       const uint32_t got = blocked[k] & ~bstart[k];
       bstart[k] = blocked[k];
 #pragma unroll
-      for (int b = kLow; b < kPlanes; ++b)
+      for (int b = kLow; b < PL; ++b)
         if ((hi >> (b - kLow)) & 1u) plane[b][k] |= got;
     }
   };
@@ -697,18 +699,18 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
       for (int k = 0; k < RPT; ++k) {
         uint32_t m = 0;
 #pragma unroll
-        for (int b = 0; b < kPlanes; ++b) m |= plane[b][k];
+        for (int b = 0; b < PL; ++b) m |= plane[b][k];
         if (m) late[base_w + k * W] |= m;
         while (m) {
           const uint32_t bpos = (uint32_t)__ffs(m) - 1u;
           m &= m - 1;
           uint32_t code = 0;
 #pragma unroll
-          for (int b = 0; b < kPlanes; ++b) code |= ((plane[b][k] >> bpos) & 1u) << b;
+          for (int b = 0; b < PL; ++b) code |= ((plane[b][k] >> bpos) & 1u) << b;
           dist[cell0 + k * nx + bpos] = epoch_base + code;
         }
 #pragma unroll
-        for (int b = 0; b < kPlanes; ++b) plane[b][k] = 0;
+        for (int b = 0; b < PL; ++b) plane[b][k] = 0;
       }
       epoch_base += kEpoch;
     }
@@ -745,10 +747,10 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
   uint32_t lt[RPT];
 #pragma unroll
   for (int k = 0; k < RPT; ++k) lt[k] = (owner && r0 + k < ny) ? late[base_w + k * W] : 0u;
-  auto cellValue = [&](const uint32_t (&pl10)[kPlanes], uint32_t exw, uint32_t tkw, uint32_t bpos) -> uint32_t {
+  auto cellValue = [&](const uint32_t (&pl10)[PL], uint32_t exw, uint32_t tkw, uint32_t bpos) -> uint32_t {
     uint32_t lvl = 0;
 #pragma unroll
-    for (int b = 0; b < kPlanes; ++b) lvl |= ((pl10[b] >> bpos) & 1u) << b;
+    for (int b = 0; b < PL; ++b) lvl |= ((pl10[b] >> bpos) & 1u) << b;
     if ((exw >> bpos) & 1u) return lvl ? epoch_base + lvl : 0u;  // relative code 0 == a seed
     return ((tkw >> bpos) & 1u) ? N_obst : N_unreach;
   };
@@ -775,25 +777,42 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-      if (holder) {
-        stage[myw * 4 + 0] = make_uint4(plane[0][k], plane[1][k], plane[2][k], plane[3][k]);
-        stage[myw * 4 + 1] = make_uint4(plane[4][k], plane[5][k], plane[6][k], plane[7][k]);
-        stage[myw * 4 + 2] = make_uint4(plane[8][k], plane[9][k], ex[k], blocked[k]);
-        stage[myw * 4 + 3] = make_uint4(lt[k], 0u, 0u, 0u);
+      if (holder) {  // record of one bitmap word: the planes, expanded, touched, late
+        if constexpr (PL == 10) {
+          stage[myw * 4 + 0] = make_uint4(plane[0][k], plane[1][k], plane[2][k], plane[3][k]);
+          stage[myw * 4 + 1] = make_uint4(plane[4][k], plane[5][k], plane[6][k], plane[7][k]);
+          stage[myw * 4 + 2] = make_uint4(plane[8][k], plane[9][k], ex[k], blocked[k]);
+          stage[myw * 4 + 3] = make_uint4(lt[k], 0u, 0u, 0u);
+        } else {
+          static_assert(PL == 10 || PL == 3, "record layout");
+          stage[myw * 4 + 0] = make_uint4(plane[0][k], plane[1][k], plane[2][k], ex[k]);
+          stage[myw * 4 + 1] = make_uint4(blocked[k], lt[k], 0u, 0u);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (rowj[j] + k < ny) {
           const uint32_t wj = 8u * j + (lane >> 3);
-          const uint4 a = stage[wj * 4 + 0], b4 = stage[wj * 4 + 1], c4 = stage[wj * 4 + 2], d4 = stage[wj * 4 + 3];
-          const uint32_t pl10[kPlanes] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w, c4.x, c4.y};
           uint32_t* out = dist + cellbase[j] + k * nx;
           uint4 v;
-          v.x = cellValue(pl10, c4.z, c4.w, c0);
-          v.y = cellValue(pl10, c4.z, c4.w, c0 + 1);
-          v.z = cellValue(pl10, c4.z, c4.w, c0 + 2);
-          v.w = cellValue(pl10, c4.z, c4.w, c0 + 3);
-          const uint32_t l4 = (d4.x >> c0) & 0xFu;  // cells already written when their epoch was flushed
+          uint32_t l4;  // cells already written when their epoch was flushed
+          if constexpr (PL == 10) {
+            const uint4 a = stage[wj * 4 + 0], b4 = stage[wj * 4 + 1], c4 = stage[wj * 4 + 2], d4 = stage[wj * 4 + 3];
+            const uint32_t pl10[PL] = {a.x, a.y, a.z, a.w, b4.x, b4.y, b4.z, b4.w, c4.x, c4.y};
+            v.x = cellValue(pl10, c4.z, c4.w, c0);
+            v.y = cellValue(pl10, c4.z, c4.w, c0 + 1);
+            v.z = cellValue(pl10, c4.z, c4.w, c0 + 2);
+            v.w = cellValue(pl10, c4.z, c4.w, c0 + 3);
+            l4 = (d4.x >> c0) & 0xFu;
+          } else {
+            const uint4 a = stage[wj * 4 + 0], b4 = stage[wj * 4 + 1];
+            const uint32_t pl3[PL] = {a.x, a.y, a.z};
+            v.x = cellValue(pl3, a.w, b4.x, c0);
+            v.y = cellValue(pl3, a.w, b4.x, c0 + 1);
+            v.z = cellValue(pl3, a.w, b4.x, c0 + 2);
+            v.w = cellValue(pl3, a.w, b4.x, c0 + 3);
+            l4 = (b4.y >> c0) & 0xFu;
+          }
           if (l4 == 0) {
             *reinterpret_cast<uint4*>(out) = v;
           } else {
@@ -809,8 +828,16 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       if (r0 + k >= ny) continue;
-      const uint32_t pl10[kPlanes] = {plane[0][k], plane[1][k], plane[2][k], plane[3][k], plane[4][k],
-                                      plane[5][k], plane[6][k], plane[7][k], plane[8][k], plane[9][k]};
+      uint32_t pl10[PL];
+      if constexpr (PL == 10) {
+        const uint32_t t10[PL] = {plane[0][k], plane[1][k], plane[2][k], plane[3][k], plane[4][k],
+                                  plane[5][k], plane[6][k], plane[7][k], plane[8][k], plane[9][k]};
+#pragma unroll
+        for (int b = 0; b < PL; ++b) pl10[b] = t10[b];
+      } else {
+#pragma unroll
+        for (int b = 0; b < PL; ++b) pl10[b] = plane[b][k];
+      }
       uint32_t* drow = dist + (r0 + k) * nx + wi * 32;
       const uint32_t nb = min(32u, nx - wi * 32);
       for (uint32_t bpos = 0; bpos < nb; ++bpos)
@@ -1007,19 +1034,24 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(k_bfs<R>, grid, dim3(1024), lds, s, pl, first);                                           \
   }
+    static const bool force_lds_kernel = getenv("NAVGPU_DEBUG_BFS_LDS") != nullptr;  // A/B timing only
+#define NAVGPU_BFS_WAVE(R, LEG, P)                                                                                            \
+  {                                                                                                                           \
+    const size_t lds_w = bfs_wave_lds(pl.nx, pl.ny, R);                                                                       \
+    if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<R, LEG, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); \
+    hipLaunchKernelGGL((k_bfs_wave<R, LEG, P>), grid, dim3(1024), lds_w, s, pl, first);                                       \
+    return;                                                                                                                   \
+  }
+    if (!force_lds_kernel && bfs_wave_fits(pl.nx, pl.ny, 7)) {
+      if (pl.bfs_grids == 2) NAVGPU_BFS_WAVE(7, true, 10)
+      else NAVGPU_BFS_WAVE(7, false, 10)
+    }
+    if (!force_lds_kernel && bfs_wave_fits(pl.nx, pl.ny, 13) && bfs_wave_lds(pl.nx, pl.ny, 13) <= 156u * 1024u) {
+      if (pl.bfs_grids == 2) NAVGPU_BFS_WAVE(13, true, 3)
+      else NAVGPU_BFS_WAVE(13, false, 3)
+    }
+#undef NAVGPU_BFS_WAVE
     if (rpt == 6) {
-      static const bool force_lds_kernel = getenv("NAVGPU_DEBUG_BFS_LDS") != nullptr;  // A/B timing only
-      if (bfs_wave_fits(pl.nx, pl.ny, 7) && !force_lds_kernel) {
-        const size_t lds_w = bfs_wave_lds(pl.nx, pl.ny, 7);
-        if (pl.bfs_grids == 2) {
-          if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
-          hipLaunchKernelGGL((k_bfs_wave<7, true>), grid, dim3(1024), lds_w, s, pl, first);
-        } else {
-          if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w);
-          hipLaunchKernelGGL((k_bfs_wave<7, false>), grid, dim3(1024), lds_w, s, pl, first);
-        }
-        return;
-      }
       NAVGPU_BFS(6)
     } else if (rpt == 12) NAVGPU_BFS(12)
     else NAVGPU_BFS(24)
