@@ -1364,7 +1364,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       const double sc_obs = pl.scale_obstacle, sc_gf = pl.scale_goal, sc_al = pl.align_on[inst] ? pl.scale_path : 0.0,
                    sc_path = pl.scale_path, sc_goal = pl.scale_goal;
       const bool en_obs = sc_obs != 0, en_gf = sc_gf != 0, en_al = sc_al != 0, en_path = sc_path != 0, en_goal = sc_goal != 0;
-      double code_obs = 0, code_gf = 0, code_al = 0, code_path = 0, code_goal = 0;
+      double fail_code = 0;  // code of critic `first_fail`: the only one scoreTrajectory's in-order sum can return
       double v_obs = 0, v_gf = 0, v_al = 0, v_path = 0, v_goal = 0;
       int first_fail = 6;  // order index of the earliest critic that failed (1..5), 6 = none
       const bool allow_unknown = c.allow_unknown != 0;
@@ -1372,7 +1372,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
 
       if (en_obs && nfp == 0) {  // "Footprint spec is empty" (obstacle_cost_function.cpp:78-82)
-        code_obs = -9.0;
+        fail_code = -9.0;
         first_fail = 1;
       }
       if (osc_fail) {
@@ -1526,7 +1526,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
               }
             }
             if (bad) {
-              code_obs = -6.0;
+              fail_code = -6.0;
               first_fail = 1;
             } else {
               // ok_c holds here, so the -7 branch (obstacle_cost_function.cpp:135-137) cannot fire
@@ -1537,10 +1537,10 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           if ((en_path && 4 < first_fail) || (en_goal && 5 < first_fail)) {
             if (!ok_c) {
               if (en_path && 4 < first_fail) {
-                code_path = -4.0;
+                fail_code = -4.0;
                 first_fail = 4;
               } else {
-                code_goal = -4.0;
+                fail_code = -4.0;
                 first_fail = 5;
               }
             } else {
@@ -1548,10 +1548,10 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
               if (en_path && 4 < first_fail) {
                 const uint32_t d = (pl.debug & 1u) ? 7u : dpath[cell];
                 if (d == N_obst) {
-                  code_path = -3.0;
+                  fail_code = -3.0;
                   first_fail = 4;
                 } else if (d == N_unreach) {
-                  code_path = -2.0;
+                  fail_code = -2.0;
                   first_fail = 4;
                 } else
                   v_path = d;
@@ -1559,10 +1559,10 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
               if (en_goal && 5 < first_fail) {
                 const uint32_t d = (pl.debug & 1u) ? 9u : dgoal[cell];
                 if (d == N_obst) {
-                  code_goal = -3.0;
+                  fail_code = -3.0;
                   first_fail = 5;
                 } else if (d == N_unreach) {
-                  code_goal = -2.0;
+                  fail_code = -2.0;
                   first_fail = 5;
                 } else
                   v_goal = d;
@@ -1578,10 +1578,10 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
             uint32_t ux, uy;
             if (!w2m(sx, sy, ux, uy)) {
               if (en_gf && 2 < first_fail) {
-                code_gf = -4.0;
+                fail_code = -4.0;
                 first_fail = 2;
               } else {
-                code_al = -4.0;
+                fail_code = -4.0;
                 first_fail = 3;
               }
             } else if (step == num_steps - 1) {  // aggregation Last: only the final point's value survives
@@ -1613,24 +1613,23 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           pth = ntp;
         }
         // ---- scoreTrajectory sum in critic order
+        // (the first failing critic in that order ends the sum with its code: simple_scored_sampling_planner.cpp:59-66)
         total = 0.0;
-        bool done = false;
-        auto add = [&](bool en, double code, double value, double scale) {
-          if (done || !en) return;
-          if (code < 0) {
-            total = code;
-            done = true;
-            return;
-          }
-          double cost = value;
-          if (cost != 0) cost *= scale;
-          total += cost;
-        };
-        add(en_obs, code_obs, v_obs, sc_obs);
-        add(en_gf, code_gf, v_gf, sc_gf);
-        add(en_al, code_al, v_al, sc_al);
-        add(en_path, code_path, v_path, sc_path);
-        add(en_goal, code_goal, v_goal, sc_goal);
+        if (first_fail < 6) {
+          total = fail_code;
+        } else {
+          auto add = [&](bool en, double value, double scale) {
+            if (!en) return;
+            double cost = value;
+            if (cost != 0) cost *= scale;
+            total += cost;
+          };
+          add(en_obs, v_obs, sc_obs);
+          add(en_gf, v_gf, sc_gf);
+          add(en_al, v_al, sc_al);
+          add(en_path, v_path, sc_path);
+          add(en_goal, v_goal, sc_goal);
+        }
       }
     }
     if (!EXPLICIT && pl.sample_cost) {
