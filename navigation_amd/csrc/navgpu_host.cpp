@@ -223,6 +223,10 @@ const char* navgpu_kernel_name(int32_t k) {
 
 int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   if (!d || !out || d->n_instances == 0 || d->size_x == 0 || d->size_y == 0 || !(d->resolution > 0)) return NAVGPU_ERR_INVALID;
+  if ((uint64_t)((d->size_x + 127) / 128) * ((d->size_y + 15) / 16) > 8192) {  // activity flags of k_bfs_global (kMaxTiles)
+    g_last_error = "navgpu_fleet_create: costmap larger than 16.7 M cells";
+    return NAVGPU_ERR_CAPACITY;
+  }
   if (d->max_footprint > (uint32_t)kMaxFootprint) return NAVGPU_ERR_CAPACITY;
   if ((uint64_t)d->size_x * d->size_y > (1ull << 30) || d->size_x > 65535 || d->size_y > 65535) return NAVGPU_ERR_CAPACITY;
   int ndev = 0;
