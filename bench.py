@@ -36,13 +36,14 @@ BYTES_PER_INFL_CELL = 2
 BYTES_PER_MERGE_CELL = 3
 
 
-def build_fleet(nav, n_inst, n_cells, seed0, device=0, vs=(32, 32, 16)):
+def build_fleet(nav, n_inst, n_cells, seed0, device=0, vs=(32, 32, 16), footprint="square"):
     from navigation_amd import _lib as N, synth
+    fp = synth.FOOTPRINT5 if footprint == "poly5" else synth.FOOTPRINT
     fl = nav.Fleet(n_inst, n_cells, n_cells, synth.RES, layers=N.LAYER_STATIC | N.LAYER_OBSTACLE | N.LAYER_INFLATION,
                    max_points=720, max_observations=1, max_plan=200, max_footprint=8, max_sim_steps=24, device=device)
     fl.configure_obstacle()
-    fl.set_footprint(synth.FOOTPRINT)
-    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, synth.inscribed_radius(synth.FOOTPRINT))
+    fl.set_footprint(fp)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, synth.inscribed_radius(fp))
     cfg = synth.fleet_config(*vs)
     fl.configure_planner(cfg)
     insts = [synth.make_instance(n_cells, seed0 + i) for i in range(n_inst)]
@@ -198,6 +199,8 @@ def main():
     ap.add_argument("--size", type=int, default=400, help="costmap cells per side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--vsamples", default="32,32,16", help="vx,vy,vtheta samples (exploration; the contract workload is 32,32,16)")
+    ap.add_argument("--footprint", default="square", choices=["square", "poly5"], help="poly5: costmap_params.yaml's 5-vertex polygon")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-process rehearsal on a box with ONE GPU: every rank uses device 0, collectives over gloo")
     args = ap.parse_args()
@@ -224,7 +227,8 @@ def main():
     nav.lib()  # fails loudly if the HIP extension is missing
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     n_inst, n_cells = args.instances, args.size
-    fl, insts, cfg = build_fleet(nav, n_inst, n_cells, seed0=rank * n_inst, device=local_rank)
+    vs = tuple(int(v) for v in args.vsamples.split(","))
+    fl, insts, cfg = build_fleet(nav, n_inst, n_cells, seed0=rank * n_inst, device=local_rank, vs=vs, footprint=args.footprint)
 
     def barrier():
         torch.cuda.synchronize()
@@ -282,7 +286,7 @@ def main():
             "config": {"workload": f"configs[2]: {n_inst} batched robot instances per MI355X, {n_cells}x{n_cells} costmaps "
                                    f"+ inflation, 32x32x16 velocity samples, 20 sim steps, LaserScan (720 beams) update "
                                    f"each cycle; N GPUs = N x {n_inst} instances (N=8 is configs[3])",
-                       "instances_per_gpu": n_inst, "costmap": f"{n_cells}x{n_cells}@0.05", "vsamples": "32x32x16",
+                       "instances_per_gpu": n_inst, "costmap": f"{n_cells}x{n_cells}@0.05", "vsamples": "x".join(str(v) for v in vs),
                        "sim_steps": T_STEPS, "critics": "oscillation+obstacle+goal_front+alignment+path+goal",
                        "parallelism": f"fleet-shard x{world}"},
             "per_instance_trajectories_per_s": traj_per_s / (n_inst * world),
