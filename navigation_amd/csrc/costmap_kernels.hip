@@ -390,6 +390,57 @@ __global__ __launch_bounds__(256) void k_obstacle(CostmapDev cm, uint32_t first,
       __syncthreads();
     }
     // ---------------- phase 2: marking observations
+    // VoxelGrid::markVoxelInMap reports "marked" from the column's bit count AT THAT POINT of the sequential loop
+    // (voxel_grid.h:100-117), so with mark_threshold > 0 which points touch the bounds depends on the point
+    // order.  Exact two-step form: (1) every point records its cell, z and the column bits before any marking;
+    // (2) a point is marked iff those bits, the bits of the EARLIER points of the same cell and its own exceed
+    // the threshold.  (mark_threshold == 0: every accepted point is marked, the one-pass form below is exact.)
+    if (VOXEL && mark_thr > 0) {
+      uint2* seq = cm.mark_seq + (size_t)inst * cm.max_points;
+      uint32_t n_seq = 0;
+      for (uint32_t o = ob; o < oe; ++o) n_seq = max(n_seq, cm.obs[o].first_point + cm.obs[o].n_points);
+      for (uint32_t s = tid; s < n_seq; s += blockDim.x) seq[s] = make_uint2(0u, 0u);
+      __syncthreads();
+      for (uint32_t o = ob; o < oe; ++o) {
+        const ObsCsr obs = cm.obs[o];
+        if (!(obs.flags & NAVGPU_OBS_MARKING)) continue;
+        const float* pts = inst_points + (size_t)obs.first_point * 3;
+        const double sq_obstacle_range = obs.obstacle_range * obs.obstacle_range;
+        for (uint32_t p = tid; p < obs.n_points; p += blockDim.x) {
+          const float fx = pts[3 * p], fy = pts[3 * p + 1], fz = pts[3 * p + 2];
+          double px = fx, py = fy, pz = fz;
+          if (pz > cm.max_obstacle_height) continue;
+          double sq_dist = (px - obs.ox) * (px - obs.ox) + (py - obs.oy) * (py - obs.oy) + (pz - obs.oz) * (pz - obs.oz);
+          if (sq_dist >= sq_obstacle_range) continue;
+          double wz = (pz < cm.origin_z) ? cm.origin_z : pz;
+          if (px < g.ox || py < g.oy || wz < cm.origin_z) continue;
+          double fxm = (px - g.ox) / g.res, fym = (py - g.oy) / g.res, fzm = (wz - cm.origin_z) / cm.z_resolution;
+          if (!(fxm < 2147483648.0) || !(fym < 2147483648.0) || !(fzm < 2147483648.0)) continue;
+          uint32_t mx = (uint32_t)(int)fxm, my = (uint32_t)(int)fym, mz = (uint32_t)(int)fzm;
+          if (!(mx < g.nx && my < g.ny && mz < (uint32_t)cm.z_voxels)) continue;
+          if (mz >= size_z) continue;
+          const uint32_t cell = my * g.nx + mx;
+          seq[obs.first_point + p] = make_uint2(cell, 0x80000000u | ((vox[cell] >> 16) << 8) | mz);
+        }
+      }
+      __syncthreads();
+      for (uint32_t s = tid; s < n_seq; s += blockDim.x) {
+        const uint2 e = seq[s];
+        if (!(e.y & 0x80000000u)) continue;
+        const uint32_t mz = e.y & 0xFFu;
+        uint32_t acc = ((e.y >> 8) & 0xFFFFu) | (1u << mz);
+        for (uint32_t q = 0; q < s; ++q) {
+          const uint2 f = seq[q];
+          if ((f.y & 0x80000000u) && f.x == e.x) acc |= 1u << (f.y & 0xFFu);
+        }
+        atomicOr(&vox[e.x], ((uint32_t)1 << mz << 16) | (1u << mz));
+        if (!bitsBelowThreshold(acc, mark_thr)) {
+          layer[e.x] = kLethal;
+          const float* pt = inst_points + (size_t)s * 3;  // touched with the point's own coordinates (voxel_layer.cpp:181)
+          b.touch((double)pt[0], (double)pt[1]);
+        }
+      }
+    } else
     for (uint32_t o = ob; o < oe; ++o) {
       const ObsCsr obs = cm.obs[o];
       if (!(obs.flags & NAVGPU_OBS_MARKING)) continue;

@@ -71,6 +71,7 @@ struct CostmapDev {
   int32_t* shift;      // [n][2] pending rolling-window shift in cells (cell_ox, cell_oy)
   uint8_t *master_alt, *obst_alt;  // ping-pong targets of the shift
   uint32_t* voxel_alt;
+  uint2* mark_seq;     // [n][max_points] voxel marking with mark_threshold > 0: (cell, valid | column bits before marking | z) in point order
 };
 
 struct PlannerDev {

@@ -299,6 +299,7 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
     if (cm.obst) A(cm.obst_alt, (size_t)n * cm.cells_padded);
     if (cm.voxel) A(cm.voxel_alt, (size_t)n * cm.cells_padded);
   }
+  if (cm.voxel) A(cm.mark_seq, (size_t)n * cm.max_points);
 #define AP(ptr, cnt)                              \
   if ((rc = f->allocPinned(&(ptr), (cnt))) != 0) { \
     navgpu_fleet_destroy(f);                       \

@@ -459,8 +459,9 @@ def test_full_size_properties(nav):
 # ----------------------------------------------------------------------------------------------
 # voxel layer: 3-D marking + 3-D raytrace clearing
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("track_unknown,z_voxels,unknown_thr", [(False, 10, 15), (True, 10, 15), (True, 16, 0), (True, 8, 5)])
-def test_voxel_layer_cycles(nav, orc, track_unknown, z_voxels, unknown_thr):
+@pytest.mark.parametrize("track_unknown,z_voxels,unknown_thr,mark_thr", [(False, 10, 15, 0), (True, 10, 15, 0), (True, 16, 0, 0), (True, 8, 5, 0),
+                                                                         (True, 10, 15, 1), (False, 16, 4, 2)])
+def test_voxel_layer_cycles(nav, orc, track_unknown, z_voxels, unknown_thr, mark_thr):
     from navigation_amd import synth
     N = L(nav)
     n, nI = 200, 2
@@ -468,7 +469,7 @@ def test_voxel_layer_cycles(nav, orc, track_unknown, z_voxels, unknown_thr):
     insc = synth.inscribed_radius(synth.FOOTPRINT5)
     fl = nav.Fleet(nI, n, n, synth.RES, layers=N.LAYER_VOXEL | N.LAYER_INFLATION, track_unknown=track_unknown,
                    max_points=1440, max_observations=2)
-    fl.configure_obstacle(z_voxels=z_voxels, origin_z=0.0, z_resolution=0.2, unknown_threshold=unknown_thr, mark_threshold=0,
+    fl.configure_obstacle(z_voxels=z_voxels, origin_z=0.0, z_resolution=0.2, unknown_threshold=unknown_thr, mark_threshold=mark_thr,
                           max_obstacle_height=2.0)
     fl.set_footprint(synth.FOOTPRINT5)
     fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, insc)
@@ -477,7 +478,7 @@ def test_voxel_layer_cycles(nav, orc, track_unknown, z_voxels, unknown_thr):
         o = orc.LayeredCostmap(track_unknown)
         o.resize(n, n, synth.RES, 0, 0)
         o.set_footprint(synth.FOOTPRINT5)
-        o.add_voxel(z_voxels=z_voxels, origin_z=0.0, z_resolution=0.2, unknown_threshold=unknown_thr, mark_threshold=0,
+        o.add_voxel(z_voxels=z_voxels, origin_z=0.0, z_resolution=0.2, unknown_threshold=unknown_thr, mark_threshold=mark_thr,
                     max_obstacle_height=2.0)
         o.add_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, exact=True)
         o.set_footprint(synth.FOOTPRINT5)
@@ -494,6 +495,12 @@ def test_voxel_layer_cycles(nav, orc, track_unknown, z_voxels, unknown_thr):
             poses.append([float(v) for v in ins["pos"]])
             oracles[i].clear_observations()
             oracles[i].add_observation(pts, origin=org, obstacle_range=2.5, raytrace_range=3.0)
+            if mark_thr:  # a second sensor hitting the same columns at other heights: the order across observations counts
+                pts2 = pts[::2].copy()
+                pts2[:, 2] = np.clip(pts2[:, 2] + 0.45, 0.0, 1.9)
+                org2 = (org[0] + 0.05, org[1] - 0.05, 0.9)
+                obs.append(dict(instance=i, points=pts2, origin=org2, obstacle_range=2.5, raytrace_range=3.0))
+                oracles[i].add_observation(pts2, origin=org2, obstacle_range=2.5, raytrace_range=3.0)
             oracles[i].update_map(*poses[-1])
         fl.stage_observations(poses, obs)
         fl.update_map()
