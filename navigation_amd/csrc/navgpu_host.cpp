@@ -3,197 +3,10 @@
 // scalar bookkeeping the reference also does once per cycle on the host (footprint transform,
 // nose goal, inflation cost table) — in fp64 with libm, like the reference.
 // There is no CPU fallback: every data-parallel step is a HIP kernel.
-#include <algorithm>
-#include <cfloat>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <ctime>
-#include <string>
-#include <vector>
+#include "navgpu_fleet.h"
 
-#include "navgpu_device.h"
-
-using namespace navgpu;
-
-namespace {
+namespace navgpu {
 thread_local std::string g_last_error;
-
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t e_ = (expr);                                                                        \
-    if (e_ != hipSuccess) {                                                                        \
-      g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                            \
-      return NAVGPU_ERR_HIP;                                                                       \
-    }                                                                                              \
-  } while (0)
-
-// hipStreamSynchronize also flushes the runtime's batched launches; a hipStreamQuery polling loop does
-// not (measured: the queue then only drains when the poll gives up), so no polling here.
-static hipError_t waitStream(hipStream_t s) { return hipStreamSynchronize(s); }
-
-struct EventPair {
-  int kernel;
-  hipEvent_t a, b;
-};
-}  // namespace
-
-struct navgpu_fleet {
-  navgpu_fleet_desc desc{};
-  hipStream_t stream = nullptr;
-  CostmapDev cm{};
-  PlannerDev pl{};
-  bool planner_configured = false, inflation_configured = false, planner_staged = false;
-  bool shift_pending = false;                   // rolling window: staged origins not yet applied to the grids
-  uint32_t shift_first = 0, shift_count = 0;
-  std::vector<void*> allocs;
-  // host mirrors
-  std::vector<double> h_origin;                 // [n][2]
-  std::vector<double> h_fp_spec;                // [n][kMaxFootprint][2]
-  std::vector<uint32_t> h_fp_n;                 // [n]
-  navgpu_inflation_params infl{};
-  navgpu_obstacle_params obsp{};
-  double fp_radius = 0.0;                       // largest vertex distance over all instances
-  // pinned host mirrors of the per-cycle staging arrays (full fleet size): H2D copies are truly
-  // asynchronous and no per-call allocation happens on the staging path
-  std::vector<void*> pinned;
-  ObsCsr* hp_obs = nullptr;
-  uint32_t *hp_cnt = nullptr, *hp_used = nullptr, *hp_plan_cnt = nullptr;
-  float* hp_pts = nullptr;
-  double *hp_fpw = nullptr, *hp_pose = nullptr, *hp_plan = nullptr, *hp_front = nullptr;
-  int32_t *hp_shift = nullptr, *hp_align = nullptr;
-  navgpu_robot_state* hp_state = nullptr;
-  navgpu_plan_result* hp_result = nullptr;
-  // DWAPlannerROS mirror (navgpu_local_planner_*): per-instance controller state, host only
-  struct LocalPlannerState {
-    std::vector<double> plan;      // stored global plan, (x, y, yaw) triples in the plan's frame (prunePlan shrinks it)
-    double T[3] = {0, 0, 0};       // planar plan -> global transform
-    bool has_T = false, have_plan = false;
-    bool xy_tolerance_latch = false, rotating_to_goal = false;  // LatchedStopRotateController members
-  };
-  std::vector<LocalPlannerState> lp;
-  navgpu_local_limits lp_limits{};
-  bool lp_configured = false;
-  // legacy TrajectoryPlanner (navgpu_tp_*)
-  struct TpHost {
-    std::vector<double> plan;  // global_plan_ as x, y pairs
-    double final_goal_x = 0, final_goal_y = 0;
-    bool final_goal_position_valid = false;
-    navgpu_tp_state st{};
-    std::vector<navgpu_tp_sample> made;  // the generateTrajectory calls of the last cycle, in call order
-    int n_points = 0;                    // of the winner
-  };
-  TpDev tp{};
-  bool tp_configured = false;
-  std::vector<TpHost> tph;
-  std::vector<double> tp_h_samples, tp_h_start;
-  std::vector<TpOut> tp_h_out;
-  std::vector<uint32_t> tp_h_nsamples, tp_h_within, tp_h_within_count;
-  std::vector<int32_t> tp_h_winner;
-  // scratch device buffers
-  double* d_bounds_tmp = nullptr;               // [n][4]
-  int32_t* d_boxes_tmp = nullptr;               // [n][4]
-  float* d_explicit = nullptr;                  // [3]
-  int8_t* d_occ = nullptr;
-  // profiling
-  bool profiling = false;
-  std::vector<EventPair> events;
-  std::vector<EventPair> free_events;
-  double prof_ms[NAVGPU_K_COUNT] = {0};
-  uint64_t prof_n[NAVGPU_K_COUNT] = {0};
-
-  template <class T>
-  int alloc(T** p, size_t count) {
-    void* q = nullptr;
-    size_t bytes = std::max<size_t>(count * sizeof(T), 16);
-    hipError_t e = hipMalloc(&q, bytes);
-    if (e != hipSuccess) {
-      g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
-      return NAVGPU_ERR_HIP;
-    }
-    e = hipMemsetAsync(q, 0, bytes, stream);
-    if (e != hipSuccess) {
-      g_last_error = std::string("hipMemsetAsync: ") + hipGetErrorString(e);
-      return NAVGPU_ERR_HIP;
-    }
-    allocs.push_back(q);
-    *p = static_cast<T*>(q);
-    return NAVGPU_OK;
-  }
-  template <class T>
-  int allocPinned(T** p, size_t count) {
-    void* q = nullptr;
-    hipError_t e = hipHostMalloc(&q, std::max<size_t>(count * sizeof(T), 16), hipHostMallocDefault);
-    if (e != hipSuccess) {
-      g_last_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
-      return NAVGPU_ERR_HIP;
-    }
-    memset(q, 0, std::max<size_t>(count * sizeof(T), 16));
-    pinned.push_back(q);
-    *p = static_cast<T*>(q);
-    return NAVGPU_OK;
-  }
-  void release(void* q) {
-    if (!q) return;
-    auto it = std::find(allocs.begin(), allocs.end(), q);
-    if (it != allocs.end()) allocs.erase(it);
-    hipFree(q);
-  }
-  bool rangeOk(uint32_t first, uint32_t count) const { return count > 0 && first < desc.n_instances && count <= desc.n_instances - first; }
-
-  int beginKernel(int k, EventPair* ep) {
-    if (!profiling) return NAVGPU_OK;
-    if (free_events.empty()) {
-      EventPair n{};
-      HIP_TRY(hipEventCreate(&n.a));
-      HIP_TRY(hipEventCreate(&n.b));
-      free_events.push_back(n);
-    }
-    *ep = free_events.back();
-    free_events.pop_back();
-    ep->kernel = k;
-    HIP_TRY(hipEventRecord(ep->a, stream));
-    return NAVGPU_OK;
-  }
-  int endKernel(EventPair* ep) {
-    if (!profiling) return NAVGPU_OK;
-    HIP_TRY(hipEventRecord(ep->b, stream));
-    events.push_back(*ep);
-    if (events.size() > 8192) return foldEvents();
-    return NAVGPU_OK;
-  }
-  int foldEvents() {
-    if (events.empty()) return NAVGPU_OK;
-    HIP_TRY(waitStream(stream));
-    for (auto& e : events) {
-      float ms = 0;
-      HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
-      prof_ms[e.kernel] += ms;
-      prof_n[e.kernel] += 1;
-      free_events.push_back(e);
-    }
-    events.clear();
-    return NAVGPU_OK;
-  }
-};
-
-#define PROFILED(fleet, kid, launch_expr)            \
-  do {                                               \
-    EventPair ep_{};                                 \
-    int rc_ = (fleet)->beginKernel((kid), &ep_);     \
-    if (rc_) return rc_;                             \
-    launch_expr;                                     \
-    rc_ = (fleet)->endKernel(&ep_);                  \
-    if (rc_) return rc_;                             \
-  } while (0)
-
-static int checkLaunch() {
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) {
-    g_last_error = std::string("kernel launch: ") + hipGetErrorString(e);
-    return NAVGPU_ERR_HIP;
-  }
-  return NAVGPU_OK;
 }
 
 extern "C" {
@@ -1019,865 +832,6 @@ int navgpu_planner_set_oscillation(navgpu_fleet* f, uint32_t first, uint32_t cou
   if (flags) HIP_TRY(hipMemcpyAsync(f->pl.osc_flags + first, flags, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
   if (prev) HIP_TRY(hipMemcpyAsync(f->pl.osc_prev + (size_t)first * 3, prev, sizeof(float) * 3 * count, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(waitStream(f->stream));
-  return NAVGPU_OK;
-}
-
-// ------------------------------------------------------------------------------------------------ DWAPlannerROS mirror
-// angles::normalize_angle_positive / normalize_angle / shortest_angular_distance (ros/angles, fmod form)
-static double normalizeAnglePositive(double a) { return fmod(fmod(a, 2.0 * M_PI) + 2.0 * M_PI, 2.0 * M_PI); }
-static double normalizeAngle(double a) {
-  double r = normalizeAnglePositive(a);
-  if (r > M_PI) r -= 2.0 * M_PI;
-  return r;
-}
-double navgpu_shortest_angular_distance(double from, double to) { return normalizeAngle(to - from); }
-static double signOf(double x) { return x < 0.0 ? -1.0 : 1.0; }  // base_local_planner sign()
-
-int navgpu_local_plan_window(const double* plan, uint32_t n, const double pose[3], const double* T, double dist_threshold,
-                             int32_t prune, double* out, uint32_t capacity, uint32_t* n_out, uint32_t* n_erased) {
-  if (!plan || !pose || !out || !n_out || !n_erased) return NAVGPU_ERR_INVALID;
-  *n_out = 0;
-  *n_erased = 0;
-  if (n == 0) return NAVGPU_ERR_INVALID;  // "Received plan with zero length" (goal_functions.cpp:98-101)
-  // the robot in the frame of the plan (tf.transformPose, :113-114)
-  double rx = pose[0], ry = pose[1];
-  double c = 1.0, sn = 0.0;
-  if (T) {
-    c = cos(T[2]);
-    sn = sin(T[2]);
-    const double dx = pose[0] - T[0], dy = pose[1] - T[1];
-    rx = c * dx + sn * dy;
-    ry = -sn * dx + c * dy;
-  }
-  const double sq_thr = dist_threshold * dist_threshold;
-  uint32_t i = 0;
-  double sq_dist = 0;
-  while (i < n) {  // :126-134: up to the first pose within reach
-    const double xd = rx - plan[3 * i], yd = ry - plan[3 * i + 1];
-    sq_dist = xd * xd + yd * yd;
-    if (sq_dist <= sq_thr) break;
-    ++i;
-  }
-  uint32_t m = 0;
-  while (i < n && sq_dist <= sq_thr) {  // :140-154: the pose that leaves the reach is still taken
-    if (m >= capacity) return NAVGPU_ERR_CAPACITY;
-    const double px = plan[3 * i], py = plan[3 * i + 1], pth = plan[3 * i + 2];
-    if (T) {
-      out[3 * m] = c * px - sn * py + T[0];
-      out[3 * m + 1] = sn * px + c * py + T[1];
-      out[3 * m + 2] = pth + T[2];
-    } else {
-      out[3 * m] = px;
-      out[3 * m + 1] = py;
-      out[3 * m + 2] = pth;
-    }
-    ++m;
-    const double xd = rx - px, yd = ry - py;
-    sq_dist = xd * xd + yd * yd;
-    ++i;
-  }
-  uint32_t erased = 0;
-  if (prune) {  // prunePlan (:69-86): drop leading poses until one is closer than 1 m
-    while (erased < m) {
-      const double xd = pose[0] - out[3 * erased], yd = pose[1] - out[3 * erased + 1];
-      if (xd * xd + yd * yd < 1) break;
-      ++erased;
-    }
-    if (erased) memmove(out, out + 3 * (size_t)erased, sizeof(double) * 3 * (m - erased));
-  }
-  *n_out = m - erased;
-  *n_erased = erased;
-  return NAVGPU_OK;
-}
-
-int navgpu_local_planner_configure(navgpu_fleet* f, const navgpu_local_limits* lim) {
-  if (!f || !lim) return NAVGPU_ERR_INVALID;
-  f->lp_limits = *lim;
-  f->lp_configured = true;
-  if (f->lp.size() != f->desc.n_instances) f->lp.assign(f->desc.n_instances, navgpu_fleet::LocalPlannerState());
-  return NAVGPU_OK;
-}
-
-int navgpu_local_planner_set_plan(navgpu_fleet* f, uint32_t instance, const double* plan, uint32_t n, const double* T) {
-  if (!f || instance >= f->desc.n_instances || (n && !plan)) return NAVGPU_ERR_INVALID;
-  if (!f->lp_configured || !f->planner_configured) return NAVGPU_ERR_STATE;
-  navgpu_fleet::LocalPlannerState& st = f->lp[instance];
-  st.xy_tolerance_latch = false;  // latchedStopRotateController_.resetLatching() (dwa_planner_ros.cpp:136)
-  st.plan.assign(plan, plan + 3 * (size_t)n);
-  st.have_plan = true;
-  st.has_T = T != nullptr;
-  if (T) memcpy(st.T, T, sizeof(st.T));
-  return navgpu_planner_set_plan(f, instance, 1);  // DWAPlanner::setPlan: resetOscillationFlags
-}
-
-int navgpu_local_planner_get_plan(navgpu_fleet* f, uint32_t instance, double* xyyaw, uint32_t capacity) {
-  if (!f || instance >= f->desc.n_instances || !f->lp_configured) return NAVGPU_ERR_INVALID;
-  const std::vector<double>& pl = f->lp[instance].plan;
-  const uint32_t n = (uint32_t)(pl.size() / 3);
-  if (xyyaw) {
-    if (capacity < n) return NAVGPU_ERR_CAPACITY;
-    memcpy(xyyaw, pl.data(), sizeof(double) * pl.size());
-  }
-  return (int)n;
-}
-
-// getGoalPose (goal_functions.cpp:175-214): the last pose of the stored plan in the global frame
-static bool goalPose(const navgpu_fleet::LocalPlannerState& st, double goal[3]) {
-  if (st.plan.empty()) return false;
-  const double* g = &st.plan[st.plan.size() - 3];
-  if (st.has_T) {
-    const double c = cos(st.T[2]), sn = sin(st.T[2]);
-    goal[0] = c * g[0] - sn * g[1] + st.T[0];
-    goal[1] = sn * g[0] + c * g[1] + st.T[1];
-    goal[2] = g[2] + st.T[2];
-  } else {
-    goal[0] = g[0];
-    goal[1] = g[1];
-    goal[2] = g[2];
-  }
-  return true;
-}
-static bool stoppedOdom(const double v[3], double rot_stopped, double trans_stopped) {  // goal_functions.cpp:248-253
-  return fabs(v[2]) <= rot_stopped && fabs(v[0]) <= trans_stopped && fabs(v[1]) <= trans_stopped;
-}
-
-int navgpu_local_planner_is_goal_reached(navgpu_fleet* f, uint32_t first, uint32_t count, const navgpu_robot_input* in, int32_t* reached) {
-  if (!f || !in || !reached || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
-  if (!f->lp_configured) return NAVGPU_ERR_STATE;
-  const navgpu_local_limits& lim = f->lp_limits;
-  for (uint32_t k = 0; k < count; ++k) {
-    navgpu_fleet::LocalPlannerState& st = f->lp[first + k];
-    reached[k] = 0;
-    double goal[3];
-    if (!in[k].have_pose || !goalPose(st, goal)) continue;
-    // LatchedStopRotateController::isGoalReached (:66-109)
-    const double dist = hypot(goal[0] - in[k].pose[0], goal[1] - in[k].pose[1]);
-    if ((lim.latch_xy_goal_tolerance && st.xy_tolerance_latch) || dist <= lim.xy_goal_tolerance) {
-      if (lim.latch_xy_goal_tolerance && !st.xy_tolerance_latch) st.xy_tolerance_latch = true;
-      const double angle = navgpu_shortest_angular_distance(in[k].pose[2], goal[2]);
-      if (fabs(angle) <= lim.yaw_goal_tolerance && stoppedOdom(in[k].odom_vel, lim.rot_stopped_vel, lim.trans_stopped_vel)) reached[k] = 1;
-    }
-  }
-  return NAVGPU_OK;
-}
-
-int navgpu_local_planner_compute_velocity_commands(navgpu_fleet* f, uint32_t first, uint32_t count, const navgpu_robot_input* in,
-                                                   navgpu_cmd_result* out) {
-  if (!f || !in || !out || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
-  if (!f->lp_configured || !f->planner_configured) return NAVGPU_ERR_STATE;
-  const navgpu_local_limits& lim = f->lp_limits;
-  const uint32_t max_plan = f->pl.max_plan;
-  const double dist_threshold = std::max(f->cm.nx * f->cm.res / 2.0, f->cm.ny * f->cm.res / 2.0);
-  std::vector<double> local((size_t)count * max_plan * 3), packed;
-  std::vector<navgpu_robot_state> states(count);
-  std::vector<uint8_t> valid(count, 0), dwa(count, 0);
-  packed.reserve((size_t)count * max_plan * 2);
-  // --- getLocalPlan per robot (computeVelocityCommands :254-271)
-  for (uint32_t k = 0; k < count; ++k) {
-    navgpu_fleet::LocalPlannerState& st = f->lp[first + k];
-    navgpu_cmd_result& o = out[k];
-    o = navgpu_cmd_result();
-    if (!in[k].have_pose) continue;                    // "Could not get robot pose"
-    if (!st.have_plan || st.plan.empty()) continue;    // transformGlobalPlan: "Received plan with zero length"
-    uint32_t n_loc = 0, n_er = 0;
-    int rc = navgpu_local_plan_window(st.plan.data(), (uint32_t)(st.plan.size() / 3), in[k].pose, st.has_T ? st.T : nullptr,
-                                      dist_threshold, lim.prune_plan, &local[(size_t)k * max_plan * 3], max_plan, &n_loc, &n_er);
-    if (rc == NAVGPU_ERR_CAPACITY) return rc;
-    if (rc != NAVGPU_OK) continue;
-    if (n_er) st.plan.erase(st.plan.begin(), st.plan.begin() + 3 * (size_t)std::min<size_t>(n_er, st.plan.size() / 3));
-    o.local_plan_points = (int32_t)n_loc;
-    if (n_loc == 0) continue;                          // "Received an empty transformed plan."
-    valid[k] = 1;
-    navgpu_robot_state& rs = states[k];
-    for (int a = 0; a < 3; ++a) {
-      rs.pos[a] = (float)in[k].pose[a];                // Eigen::Vector3f pos / vel (dwa_planner.cpp:303-304)
-      rs.vel[a] = (float)in[k].odom_vel[a];
-    }
-    rs.plan_first = (uint32_t)(packed.size() / 2);
-    rs.plan_count = n_loc;
-    for (uint32_t q = 0; q < n_loc; ++q) {
-      packed.push_back(local[((size_t)k * max_plan + q) * 3]);
-      packed.push_back(local[((size_t)k * max_plan + q) * 3 + 1]);
-    }
-  }
-  // --- updatePlanAndLocalCosts for every robot that has a local plan (:274), in contiguous runs
-  for (uint32_t k = 0; k < count;) {
-    if (!valid[k]) {
-      ++k;
-      continue;
-    }
-    uint32_t e = k;
-    while (e < count && valid[e]) ++e;
-    int rc = navgpu_planner_stage(f, first + k, e - k, &states[k], packed.data(), (uint32_t)(packed.size() / 2));
-    if (rc != NAVGPU_OK) return rc;
-    k = e;
-  }
-  // --- dispatch: isPositionReached (latched_stop_rotate_controller.cpp:37-58)
-  for (uint32_t k = 0; k < count; ++k) {
-    if (!valid[k]) continue;
-    navgpu_fleet::LocalPlannerState& st = f->lp[first + k];
-    double goal[3];
-    bool reached = false;
-    if (goalPose(st, goal)) {
-      const double dist = hypot(goal[0] - in[k].pose[0], goal[1] - in[k].pose[1]);
-      if ((lim.latch_xy_goal_tolerance && st.xy_tolerance_latch) || dist <= lim.xy_goal_tolerance) {
-        st.xy_tolerance_latch = true;
-        reached = true;
-      }
-    }
-    if (!reached) {
-      dwa[k] = 1;
-      out[k].branch = NAVGPU_BRANCH_DWA;
-      continue;
-    }
-    // computeVelocityCommandsStopRotate (:211-273)
-    navgpu_cmd_result& o = out[k];
-    if (!goalPose(st, goal)) continue;  // "Could not get goal pose"
-    if (lim.latch_xy_goal_tolerance && !st.xy_tolerance_latch) st.xy_tolerance_latch = true;
-    const double yaw = in[k].pose[2], vel_yaw = in[k].odom_vel[2];
-    const double angle = navgpu_shortest_angular_distance(yaw, goal[2]);
-    if (fabs(angle) <= lim.yaw_goal_tolerance) {
-      o.cmd_vel[0] = o.cmd_vel[1] = o.cmd_vel[2] = 0.0;
-      st.rotating_to_goal = false;
-      o.ok = 1;
-      o.branch = NAVGPU_BRANCH_AT_GOAL;
-      continue;
-    }
-    const double acc[3] = {lim.acc_lim_x, lim.acc_lim_y, lim.acc_lim_theta};
-    float vs[3];
-    int32_t okc = 0;
-    if (!st.rotating_to_goal && !stoppedOdom(in[k].odom_vel, lim.rot_stopped_vel, lim.trans_stopped_vel)) {
-      // stopWithAccLimits (:111-146); Eigen::Vector3f narrows the samples to float
-      const double vx = signOf(in[k].odom_vel[0]) * std::max(0.0, fabs(in[k].odom_vel[0]) - acc[0] * lim.sim_period);
-      const double vy = signOf(in[k].odom_vel[1]) * std::max(0.0, fabs(in[k].odom_vel[1]) - acc[1] * lim.sim_period);
-      const double vth = signOf(vel_yaw) * std::max(0.0, fabs(vel_yaw) - acc[2] * lim.sim_period);
-      vs[0] = (float)vx;
-      vs[1] = (float)vy;
-      vs[2] = (float)vth;
-      int rc = navgpu_planner_check_trajectory(f, first + k, vs, &okc);
-      if (rc != NAVGPU_OK) return rc;
-      o.branch = NAVGPU_BRANCH_STOP;
-      if (okc) {
-        o.cmd_vel[0] = vx;
-        o.cmd_vel[1] = vy;
-        o.cmd_vel[2] = vth;
-        o.ok = 1;
-      }  // else: zeros, "Error when stopping." -> false
-    } else {
-      // rotateToGoal (:148-209)
-      st.rotating_to_goal = true;
-      const double ang_diff = angle;
-      double v = std::min(lim.max_rot_vel, std::max(lim.min_rot_vel, fabs(ang_diff)));
-      const double max_acc_vel = fabs(vel_yaw) + acc[2] * lim.sim_period;
-      const double min_acc_vel = fabs(vel_yaw) - acc[2] * lim.sim_period;
-      v = std::min(std::max(fabs(v), min_acc_vel), max_acc_vel);
-      const double max_speed_to_stop = sqrt(2 * acc[2] * fabs(ang_diff));
-      v = std::min(max_speed_to_stop, fabs(v));
-      v = std::min(lim.max_rot_vel, std::max(lim.min_rot_vel, v));
-      if (ang_diff < 0) v = -v;
-      vs[0] = 0.f;
-      vs[1] = 0.f;
-      vs[2] = (float)v;
-      int rc = navgpu_planner_check_trajectory(f, first + k, vs, &okc);
-      if (rc != NAVGPU_OK) return rc;
-      o.branch = NAVGPU_BRANCH_ROTATE;
-      if (okc) {
-        o.cmd_vel[2] = v;
-        o.ok = 1;
-      }  // else: "Rotation cmd in collision" -> zeros, false
-    }
-  }
-  // --- dwaComputeVelocityCommands (:176-247) for the others, in contiguous runs
-  std::vector<navgpu_plan_result> res(count);
-  for (uint32_t k = 0; k < count;) {
-    if (!dwa[k]) {
-      ++k;
-      continue;
-    }
-    uint32_t e = k;
-    while (e < count && dwa[e]) ++e;
-    int rc = navgpu_planner_cycle(f, first + k, e - k);
-    if (rc != NAVGPU_OK) return rc;
-    rc = navgpu_planner_results(f, first + k, e - k, &res[k]);
-    if (rc != NAVGPU_OK) return rc;
-    for (uint32_t q = k; q < e; ++q) {
-      navgpu_cmd_result& o = out[q];
-      o.cmd_vel[0] = res[q].drive[0];
-      o.cmd_vel[1] = res[q].drive[1];
-      o.cmd_vel[2] = res[q].drive[2];
-      o.ok = res[q].cost >= 0 ? 1 : 0;  // path.cost_ < 0: "failed to find a valid plan"
-      o.trajectory_points = o.ok ? res[q].n_points : 0;
-    }
-    k = e;
-  }
-  return NAVGPU_OK;
-}
-
-// ------------------------------------------------------------------------------------------------ legacy TrajectoryPlanner
-namespace {
-struct TpCell {
-  int x, y;
-};
-// Costmap2D::worldToMap on the host (costmap_2d.cpp:208-220)
-bool hostWorldToMap(double ox, double oy, double res, uint32_t nx, uint32_t ny, double wx, double wy, uint32_t& mx, uint32_t& my) {
-  if (wx < ox || wy < oy) return false;
-  const double fx = (wx - ox) / res, fy = (wy - oy) / res;
-  if (!(fx < 2147483648.0) || !(fy < 2147483648.0)) return false;
-  mx = (uint32_t)(int)fx;
-  my = (uint32_t)(int)fy;
-  return mx < nx && my < ny;
-}
-// FootprintHelper::getLineCells (footprint_helper.cpp:51-124)
-void tpLineCells(int x0, int x1, int y0, int y1, std::vector<TpCell>& pts) {
-  int deltax = abs(x1 - x0), deltay = abs(y1 - y0);
-  int x = x0, y = y0;
-  int xinc1, xinc2, yinc1, yinc2, den, num, numadd, numpixels;
-  xinc1 = xinc2 = (x1 >= x0) ? 1 : -1;
-  yinc1 = yinc2 = (y1 >= y0) ? 1 : -1;
-  if (deltax >= deltay) {
-    xinc1 = 0;
-    yinc2 = 0;
-    den = deltax;
-    num = deltax / 2;
-    numadd = deltay;
-    numpixels = deltax;
-  } else {
-    xinc2 = 0;
-    yinc1 = 0;
-    den = deltay;
-    num = deltay / 2;
-    numadd = deltax;
-    numpixels = deltay;
-  }
-  for (int curpixel = 0; curpixel <= numpixels; curpixel++) {
-    pts.push_back(TpCell{x, y});
-    num += numadd;
-    if (num >= den) {
-      num -= den;
-      x += xinc1;
-      y += yinc1;
-    }
-    x += xinc2;
-    y += yinc2;
-  }
-}
-// FootprintHelper::getFillCells (:127-181)
-void tpFillCells(std::vector<TpCell>& fp) {
-  unsigned int i = 0;
-  while (i < fp.size() - 1) {
-    if (fp[i].x > fp[i + 1].x) {
-      std::swap(fp[i], fp[i + 1]);
-      if (i > 0) --i;
-    } else {
-      ++i;
-    }
-  }
-  i = 0;
-  TpCell min_pt, max_pt;
-  const unsigned int min_x = fp[0].x, max_x = fp[fp.size() - 1].x;
-  for (unsigned int x = min_x; x <= max_x; ++x) {
-    if (i >= fp.size() - 1) break;
-    if (fp[i].y < fp[i + 1].y) {
-      min_pt = fp[i];
-      max_pt = fp[i + 1];
-    } else {
-      min_pt = fp[i + 1];
-      max_pt = fp[i];
-    }
-    i += 2;
-    while (i < fp.size() && (unsigned int)fp[i].x == x) {
-      if (fp[i].y < min_pt.y)
-        min_pt = fp[i];
-      else if (fp[i].y > max_pt.y)
-        max_pt = fp[i];
-      ++i;
-    }
-    for (unsigned int y = min_pt.y; y < (unsigned int)max_pt.y; ++y) fp.push_back(TpCell{(int)x, (int)y});
-  }
-}
-// FootprintHelper::getFootprintCells(pos, spec, costmap, fill = true) (:186-258)
-void tpFootprintCells(const float pos[3], const double* spec, uint32_t nfp, double ox, double oy, double res, uint32_t nx, uint32_t ny,
-                      std::vector<TpCell>& cells) {
-  const double x_i = pos[0], y_i = pos[1], theta_i = pos[2];
-  cells.clear();
-  if (nfp <= 1) {
-    uint32_t mx, my;
-    if (hostWorldToMap(ox, oy, res, nx, ny, x_i, y_i, mx, my)) cells.push_back(TpCell{(int)mx, (int)my});
-    return;
-  }
-  const double cos_th = cos(theta_i), sin_th = sin(theta_i);
-  uint32_t x0, y0, x1, y1;
-  const uint32_t last = nfp - 1;
-  auto vertex = [&](uint32_t i, uint32_t& mx, uint32_t& my) {
-    const double wx = x_i + (spec[2 * i] * cos_th - spec[2 * i + 1] * sin_th);
-    const double wy = y_i + (spec[2 * i] * sin_th + spec[2 * i + 1] * cos_th);
-    return hostWorldToMap(ox, oy, res, nx, ny, wx, wy, mx, my);
-  };
-  for (uint32_t i = 0; i < last; ++i) {
-    if (!vertex(i, x0, y0)) return;
-    if (!vertex(i + 1, x1, y1)) return;
-    tpLineCells((int)x0, (int)x1, (int)y0, (int)y1, cells);
-  }
-  if (!vertex(last, x0, y0)) return;
-  if (!vertex(0, x1, y1)) return;
-  tpLineCells((int)x0, (int)x1, (int)y0, (int)y1, cells);
-  tpFillCells(cells);
-}
-// createTrajectories' sample enumeration (:537-665,777-780,871-874): every generateTrajectory call the
-// reference could make this cycle, with the stage it belongs to
-struct TpPlanned {
-  double vx, vy, vth;
-  double vth_unlimited;  // stage C: the loop variable before the min_in_place clamp
-  int stage;             // 0 forward grid, 1 holonomic pair, 2 in-place rotation, 3 y velocities, 4 backing up
-};
-}  // namespace
-
-static uint32_t tpMaxSamples(const navgpu_tp_config& c) {
-  return (uint32_t)(c.vx_samples * c.vtheta_samples + 2 + c.vtheta_samples + c.n_y_vels + 1);
-}
-
-int navgpu_tp_configure(navgpu_fleet* f, const navgpu_tp_config* cfg_in) {
-  if (!f || !cfg_in) return NAVGPU_ERR_INVALID;
-  navgpu_tp_config c = *cfg_in;
-  if (c.heading_scoring || c.simple_attractor) {
-    g_last_error = "navgpu_tp_configure: heading_scoring / simple_attractor are not supported";
-    return NAVGPU_ERR_INVALID;
-  }
-  if (c.n_y_vels < 0 || c.n_y_vels > 8 || !(c.sim_time > 0) || !(c.sim_granularity > 0) || !(c.angular_sim_granularity > 0))
-    return NAVGPU_ERR_INVALID;
-  if (c.vx_samples <= 0) c.vx_samples = 1;          // trajectory_planner.cpp:98-107
-  if (c.vtheta_samples <= 0) c.vtheta_samples = 1;
-  // step capacity: num_steps = int(max(vmag * sim_time / sim_granularity, |vtheta| / angular_sim_granularity) + 0.5)
-  double ymax = 0.1;
-  for (int i = 0; i < c.n_y_vels; ++i) ymax = std::max(ymax, fabs(c.y_vels[i]));
-  const double vxmax = std::max(std::max(fabs(c.max_vel_x), fabs(c.min_vel_x)), std::max(fabs(c.backup_vel), 0.1));
-  const double wmax = std::max(std::max(fabs(c.max_vel_th), fabs(c.min_vel_th)), fabs(c.min_in_place_vel_th));
-  const double steps = std::max(hypot(vxmax, ymax) * c.sim_time / c.sim_granularity, wmax / c.angular_sim_granularity) + 1.5;
-  if (steps > (double)f->pl.max_sim_steps) {
-    g_last_error = "navgpu_tp_configure: trajectories need more points than max_sim_steps";
-    return NAVGPU_ERR_CAPACITY;
-  }
-  HIP_TRY(waitStream(f->stream));
-  TpDev& tp = f->tp;
-  const uint32_t n = f->desc.n_instances;
-  const uint32_t ms = tpMaxSamples(c);
-  if (!f->tp_configured || ms > tp.max_samples) {
-    f->release(tp.samples);
-    f->release(tp.out);
-    tp.samples = nullptr;
-    tp.out = nullptr;
-    int rc = f->alloc(&tp.samples, (size_t)n * ms * 3);
-    if (rc) return rc;
-    rc = f->alloc(&tp.out, (size_t)n * ms);
-    if (rc) return rc;
-    tp.max_samples = ms;
-  }
-  if (!f->tp_configured) {
-    const uint32_t W = (f->cm.nx + 31) / 32;
-    int rc = f->alloc(&tp.n_samples, n);
-    if (!rc) rc = f->alloc(&tp.start, (size_t)n * 6);
-    if (!rc) rc = f->alloc(&tp.winner, n);
-    if (!rc) rc = f->alloc(&tp.points, (size_t)n * f->pl.max_sim_steps * 3);
-    if (!rc) rc = f->alloc(&tp.within_count, n);
-    if (!rc) rc = f->alloc(&tp.within_bits, (size_t)n * f->cm.ny * W);
-    if (rc) return rc;
-    f->tph.assign(n, navgpu_fleet::TpHost());
-  }
-  tp.cfg = c;
-  f->tp_h_samples.assign((size_t)n * tp.max_samples * 3, 0.0);
-  f->tp_h_out.assign((size_t)n * tp.max_samples, TpOut());
-  f->tp_h_start.assign((size_t)n * 6, 0.0);
-  f->tp_h_nsamples.assign(n, 0);
-  f->tp_h_within_count.assign(n, 0);
-  f->tp_h_winner.assign(n, -1);
-  f->tp_configured = true;
-  HIP_TRY(waitStream(f->stream));
-  return NAVGPU_OK;
-}
-
-// the wavefront launch of the legacy planner: two grids, path_map_ optionally with within_robot bits
-static int tpLaunchGrids(navgpu_fleet* f, uint32_t first, uint32_t count, bool with_within) {
-  PlannerDev pl = f->pl;
-  pl.bfs_grids = 2;
-  pl.within = with_within ? f->tp.within_bits : nullptr;
-  pl.cfg.allow_unknown = f->tp.cfg.allow_unknown;
-  PROFILED(f, NAVGPU_K_BFS, launch_bfs(pl, first, count, f->stream));
-  return NAVGPU_OK;
-}
-static int tpUploadPlans(navgpu_fleet* f, uint32_t first, uint32_t count) {
-  PlannerDev& pl = f->pl;
-  for (uint32_t i = first; i < first + count; ++i) {
-    const std::vector<double>& p = f->tph[i].plan;
-    const uint32_t np = (uint32_t)(p.size() / 2);
-    if (np > pl.max_plan) return NAVGPU_ERR_CAPACITY;
-    if (np) memcpy(&f->hp_plan[(size_t)i * pl.max_plan * 2], p.data(), sizeof(double) * p.size());
-    f->hp_plan_cnt[i] = np;
-  }
-  HIP_TRY(hipMemcpyAsync(pl.plan + (size_t)first * pl.max_plan * 2, f->hp_plan + (size_t)first * pl.max_plan * 2,
-                         sizeof(double) * 2 * (size_t)count * pl.max_plan, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(pl.plan_count + first, f->hp_plan_cnt + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
-  return NAVGPU_OK;
-}
-
-int navgpu_tp_update_plan(navgpu_fleet* f, uint32_t instance, const double* plan_xy, uint32_t n, int32_t compute_dists) {
-  if (!f || instance >= f->desc.n_instances || (n && !plan_xy)) return NAVGPU_ERR_INVALID;
-  if (!f->tp_configured) return NAVGPU_ERR_STATE;
-  if (n > f->pl.max_plan) return NAVGPU_ERR_CAPACITY;
-  navgpu_fleet::TpHost& h = f->tph[instance];
-  h.plan.assign(plan_xy, plan_xy + 2 * (size_t)n);
-  if (n) {  // :480-487
-    h.final_goal_x = plan_xy[2 * (size_t)(n - 1)];
-    h.final_goal_y = plan_xy[2 * (size_t)(n - 1) + 1];
-    h.final_goal_position_valid = true;
-  } else {
-    h.final_goal_position_valid = false;
-  }
-  if (compute_dists) {  // :489-499 (resetPathDist clears within_robot)
-    int rc = tpUploadPlans(f, instance, 1);
-    if (rc) return rc;
-    rc = tpLaunchGrids(f, instance, 1, false);
-    if (rc) return rc;
-    HIP_TRY(waitStream(f->stream));
-    return checkLaunch();
-  }
-  return NAVGPU_OK;
-}
-
-static inline bool tpFlag(const navgpu_tp_state& s, uint32_t bit) { return (s.flags & bit) != 0; }
-static inline void tpSet(navgpu_tp_state& s, uint32_t bit, bool v) { s.flags = v ? (s.flags | bit) : (s.flags & ~bit); }
-
-int navgpu_tp_find_best_path(navgpu_fleet* f, uint32_t first, uint32_t count, const navgpu_robot_state* states, navgpu_tp_result* results) {
-  if (!f || !states || !results || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
-  if (!f->tp_configured) return NAVGPU_ERR_STATE;
-  TpDev& tp = f->tp;
-  const navgpu_tp_config& c = tp.cfg;
-  const CostmapDev& cm = f->cm;
-  const uint32_t ms = tp.max_samples;
-  std::vector<std::vector<TpPlanned>> planned(count);
-  std::vector<double> dvth(count, 0.0);
-  std::vector<std::vector<TpCell>> cells(count);
-  size_t max_cells = 0;
-  // ---- host: footprint cells under the robot, velocity window, sample enumeration
-  for (uint32_t k = 0; k < count; ++k) {
-    const uint32_t inst = first + k;
-    navgpu_fleet::TpHost& h = f->tph[inst];
-    const float* pos = states[k].pos;
-    const float* vel = states[k].vel;
-    tpFootprintCells(pos, &f->h_fp_spec[(size_t)inst * kMaxFootprint * 2], f->h_fp_n[inst], f->h_origin[2 * inst],
-                     f->h_origin[2 * inst + 1], cm.res, cm.nx, cm.ny, cells[k]);
-    max_cells = std::max(max_cells, cells[k].size());
-    const double x = pos[0], y = pos[1], vx = vel[0], vtheta = vel[2];
-    const double acc_x = c.acc_lim_x, acc_theta = c.acc_lim_theta;
-    double* st = &f->tp_h_start[(size_t)inst * 6];
-    st[0] = x;
-    st[1] = y;
-    st[2] = pos[2];
-    st[3] = vx;
-    st[4] = vel[1];
-    st[5] = vtheta;
-    // :540-566
-    double max_vel_x = c.max_vel_x, max_vel_theta, min_vel_x, min_vel_theta;
-    if (h.final_goal_position_valid) {
-      const double final_goal_dist = hypot(h.final_goal_x - x, h.final_goal_y - y);
-      max_vel_x = std::min(max_vel_x, final_goal_dist / c.sim_time);
-    }
-    const double horizon = c.dwa ? c.sim_period : c.sim_time;
-    max_vel_x = std::max(std::min(max_vel_x, vx + acc_x * horizon), c.min_vel_x);
-    min_vel_x = std::max(c.min_vel_x, vx - acc_x * horizon);
-    max_vel_theta = std::min(c.max_vel_th, vtheta + acc_theta * horizon);
-    min_vel_theta = std::max(c.min_vel_th, vtheta - acc_theta * horizon);
-    const double dvx = (max_vel_x - min_vel_x) / (c.vx_samples - 1);
-    const double dvtheta = (max_vel_theta - min_vel_theta) / (c.vtheta_samples - 1);
-    dvth[k] = dvtheta;
-    std::vector<TpPlanned>& P = planned[k];
-    double vx_samp = min_vel_x, vtheta_samp = min_vel_theta, vy_samp = 0.0;
-    if (!tpFlag(h.st, NAVGPU_TP_ESCAPING)) {
-      for (int i = 0; i < c.vx_samples; ++i) {  // :584-611
-        vtheta_samp = 0;
-        P.push_back(TpPlanned{vx_samp, vy_samp, vtheta_samp, 0, 0});
-        vtheta_samp = min_vel_theta;
-        for (int j = 0; j < c.vtheta_samples - 1; ++j) {
-          P.push_back(TpPlanned{vx_samp, vy_samp, vtheta_samp, 0, 0});
-          vtheta_samp += dvtheta;
-        }
-        vx_samp += dvx;
-      }
-      if (c.holonomic_robot) {  // :614-644
-        P.push_back(TpPlanned{0.1, 0.1, 0.0, 0, 1});
-        P.push_back(TpPlanned{0.1, -0.1, 0.0, 0, 1});
-      }
-    }
-    vtheta_samp = min_vel_theta;  // :648-720
-    for (int i = 0; i < c.vtheta_samples; ++i) {
-      const double lim = vtheta_samp > 0 ? std::max(vtheta_samp, c.min_in_place_vel_th) : std::min(vtheta_samp, -1.0 * c.min_in_place_vel_th);
-      P.push_back(TpPlanned{0.0, 0.0, lim, vtheta_samp, 2});
-      vtheta_samp += dvtheta;
-    }
-    if (c.holonomic_robot)  // :771-817
-      for (int i = 0; i < c.n_y_vels; ++i) P.push_back(TpPlanned{0.0, c.y_vels[i], 0.0, 0, 3});
-    P.push_back(TpPlanned{c.backup_vel, 0.0, 0.0, 0, 4});  // :871-876
-    if (P.size() > ms) return NAVGPU_ERR_CAPACITY;
-    f->tp_h_nsamples[inst] = (uint32_t)P.size();
-    for (size_t q = 0; q < P.size(); ++q) {
-      double* d = &f->tp_h_samples[((size_t)inst * ms + q) * 3];
-      d[0] = P[q].vx;
-      d[1] = P[q].vy;
-      d[2] = P[q].vth;
-    }
-  }
-  // ---- within_robot cells (capacity grows with the footprint)
-  if (max_cells > tp.max_within || !tp.within_cells) {
-    HIP_TRY(waitStream(f->stream));
-    f->release(tp.within_cells);
-    tp.within_cells = nullptr;
-    tp.max_within = (uint32_t)std::max<size_t>(max_cells * 2, 256);
-    int rc = f->alloc(&tp.within_cells, (size_t)f->desc.n_instances * tp.max_within);
-    if (rc) return rc;
-    f->tp_h_within.assign((size_t)f->desc.n_instances * tp.max_within, 0);
-  }
-  for (uint32_t k = 0; k < count; ++k) {
-    const uint32_t inst = first + k;
-    f->tp_h_within_count[inst] = (uint32_t)cells[k].size();
-    for (size_t q = 0; q < cells[k].size(); ++q)
-      f->tp_h_within[(size_t)inst * tp.max_within + q] = (uint32_t)cells[k][q].y * cm.nx + (uint32_t)cells[k][q].x;
-  }
-  // ---- H2D + wavefronts + rollout of every planned sample
-  int rc = tpUploadPlans(f, first, count);
-  if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(tp.within_cells + (size_t)first * tp.max_within, &f->tp_h_within[(size_t)first * tp.max_within],
-                         sizeof(uint32_t) * (size_t)count * tp.max_within, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(tp.within_count + first, &f->tp_h_within_count[first], sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(tp.samples + (size_t)first * ms * 3, &f->tp_h_samples[(size_t)first * ms * 3], sizeof(double) * 3 * (size_t)count * ms,
-                         hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(tp.n_samples + first, &f->tp_h_nsamples[first], sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(tp.start + (size_t)first * 6, &f->tp_h_start[(size_t)first * 6], sizeof(double) * 6 * count, hipMemcpyHostToDevice, f->stream));
-  launch_tp_within(f->pl, tp, first, count, f->stream);
-  rc = tpLaunchGrids(f, first, count, true);
-  if (rc) return rc;
-  PROFILED(f, NAVGPU_K_SCORE, launch_tp_rollout(f->pl, tp, first, count, 0, f->stream));
-  HIP_TRY(hipMemcpyAsync(&f->tp_h_out[(size_t)first * ms], tp.out + (size_t)first * ms, sizeof(TpOut) * (size_t)count * ms, hipMemcpyDeviceToHost, f->stream));
-  HIP_TRY(waitStream(f->stream));
-  rc = checkLaunch();
-  if (rc) return rc;
-  // ---- host: the reference's sequential selection (createTrajectories :568-905) over the per-sample results
-  for (uint32_t k = 0; k < count; ++k) {
-    const uint32_t inst = first + k;
-    navgpu_fleet::TpHost& h = f->tph[inst];
-    navgpu_tp_state& S = h.st;
-    const std::vector<TpPlanned>& P = planned[k];
-    const TpOut* O = &f->tp_h_out[(size_t)inst * ms];
-    const double x = states[k].pos[0], y = states[k].pos[1], theta = states[k].pos[2];
-    const double dvtheta = dvth[k];
-    h.made.clear();
-    int best = -1;        // index into P of best_traj (-1: the initial best_traj with cost -1)
-    int best_made = -1;   // its position among the calls actually made
-    double best_cost = -1.0, best_xv = 0, best_yv = 0, best_thv = 0;
-    auto made = [&](size_t q) {
-      h.made.push_back(navgpu_tp_sample{P[q].vx, P[q].vy, P[q].vth, O[q].cost, O[q].n_points, 0});
-    };
-    auto take = [&](size_t q) {  // always called right after made(q)
-      best = (int)q;
-      best_made = (int)h.made.size() - 1;
-      best_cost = O[q].cost;
-      best_xv = P[q].vx;
-      best_yv = P[q].vy;
-      best_thv = P[q].vth;
-    };
-    size_t q = 0;
-    for (; q < P.size() && P[q].stage <= 1; ++q) {  // forward grid and the two holonomic samples: strict improvement
-      made(q);
-      if (O[q].cost >= 0 && (O[q].cost < best_cost || best_cost < 0)) take(q);
-    }
-    double heading_dist = DBL_MAX;
-    for (; q < P.size() && P[q].stage == 2; ++q) {  // in-place rotations :654-719
-      made(q);
-      const double vtheta_samp = P[q].vth_unlimited;
-      if (O[q].cost >= 0 && (O[q].cost <= best_cost || best_cost < 0 || best_yv != 0.0) &&
-          (vtheta_samp > dvtheta || vtheta_samp < -1 * dvtheta)) {
-        if (O[q].ahead_ok) {
-          const double ahead_gdist = O[q].ahead;
-          if (ahead_gdist < heading_dist) {
-            if (vtheta_samp < 0 && !tpFlag(S, NAVGPU_TP_STUCK_LEFT)) {
-              take(q);
-              heading_dist = ahead_gdist;
-            } else if (vtheta_samp > 0 && !tpFlag(S, NAVGPU_TP_STUCK_RIGHT)) {
-              take(q);
-              heading_dist = ahead_gdist;
-            }
-          }
-        }
-      }
-    }
-    auto resetOscillationIfMoved = [&]() {
-      const double dist = hypot(x - S.prev_x, y - S.prev_y);
-      if (dist > c.oscillation_reset_dist)
-        S.flags &= ~(NAVGPU_TP_ROTATING_LEFT | NAVGPU_TP_ROTATING_RIGHT | NAVGPU_TP_STRAFE_LEFT | NAVGPU_TP_STRAFE_RIGHT |
-                     NAVGPU_TP_STUCK_LEFT | NAVGPU_TP_STUCK_RIGHT | NAVGPU_TP_STUCK_LEFT_STRAFE | NAVGPU_TP_STUCK_RIGHT_STRAFE);
-    };
-    auto resetEscapeIfMoved = [&]() {
-      const double dist = hypot(x - S.escape_x, y - S.escape_y);
-      if (dist > c.escape_reset_dist || fabs(navgpu_shortest_angular_distance(S.escape_theta, theta)) > c.escape_reset_theta)
-        tpSet(S, NAVGPU_TP_ESCAPING, false);
-    };
-    bool finished = false;
-    if (best_cost >= 0) {  // :722-768
-      if (!(best_xv > 0)) {
-        if (best_thv < 0) {
-          if (tpFlag(S, NAVGPU_TP_ROTATING_RIGHT)) tpSet(S, NAVGPU_TP_STUCK_RIGHT, true);
-          tpSet(S, NAVGPU_TP_ROTATING_RIGHT, true);
-        } else if (best_thv > 0) {
-          if (tpFlag(S, NAVGPU_TP_ROTATING_LEFT)) tpSet(S, NAVGPU_TP_STUCK_LEFT, true);
-          tpSet(S, NAVGPU_TP_ROTATING_LEFT, true);
-        } else if (best_yv > 0) {
-          if (tpFlag(S, NAVGPU_TP_STRAFE_RIGHT)) tpSet(S, NAVGPU_TP_STUCK_RIGHT_STRAFE, true);
-          tpSet(S, NAVGPU_TP_STRAFE_RIGHT, true);
-        } else if (best_yv < 0) {
-          if (tpFlag(S, NAVGPU_TP_STRAFE_LEFT)) tpSet(S, NAVGPU_TP_STUCK_LEFT_STRAFE, true);
-          tpSet(S, NAVGPU_TP_STRAFE_LEFT, true);
-        }
-        S.prev_x = x;
-        S.prev_y = y;
-      }
-      resetOscillationIfMoved();
-      resetEscapeIfMoved();
-      finished = true;
-    }
-    if (!finished) {
-      for (; q < P.size() && P[q].stage == 3; ++q) {  // sideways :771-817
-        made(q);
-        const double vy_samp = P[q].vy;
-        if (O[q].cost >= 0 && (O[q].cost <= best_cost || best_cost < 0)) {
-          if (O[q].ahead_ok) {
-            const double ahead_gdist = O[q].ahead;
-            if (ahead_gdist < heading_dist) {
-              if (vy_samp > 0 && !tpFlag(S, NAVGPU_TP_STUCK_LEFT_STRAFE)) {
-                take(q);
-                heading_dist = ahead_gdist;
-              } else if (vy_samp < 0 && !tpFlag(S, NAVGPU_TP_STUCK_RIGHT_STRAFE)) {
-                take(q);
-                heading_dist = ahead_gdist;
-              }
-            }
-          }
-        }
-      }
-      if (best_cost >= 0) {  // :820-868 — the flags set here are not those of the block above
-        if (!(best_xv > 0)) {
-          if (best_thv < 0) {
-            if (tpFlag(S, NAVGPU_TP_ROTATING_RIGHT)) tpSet(S, NAVGPU_TP_STUCK_RIGHT, true);
-            tpSet(S, NAVGPU_TP_ROTATING_LEFT, true);
-          } else if (best_thv > 0) {
-            if (tpFlag(S, NAVGPU_TP_ROTATING_LEFT)) tpSet(S, NAVGPU_TP_STUCK_LEFT, true);
-            tpSet(S, NAVGPU_TP_ROTATING_RIGHT, true);
-          } else if (best_yv > 0) {
-            if (tpFlag(S, NAVGPU_TP_STRAFE_RIGHT)) tpSet(S, NAVGPU_TP_STUCK_RIGHT_STRAFE, true);
-            tpSet(S, NAVGPU_TP_STRAFE_LEFT, true);
-          } else if (best_yv < 0) {
-            if (tpFlag(S, NAVGPU_TP_STRAFE_LEFT)) tpSet(S, NAVGPU_TP_STUCK_LEFT_STRAFE, true);
-            tpSet(S, NAVGPU_TP_STRAFE_RIGHT, true);
-          }
-          S.prev_x = x;
-          S.prev_y = y;
-        }
-        resetOscillationIfMoved();
-        resetEscapeIfMoved();
-        finished = true;
-      }
-    }
-    if (!finished) {  // :871-905 back up slowly, whatever the footprint check says
-      while (q < P.size() && P[q].stage != 4) ++q;
-      made(q);
-      take(q);
-      resetOscillationIfMoved();
-      if (!tpFlag(S, NAVGPU_TP_ESCAPING) && best_cost > -2.0) {
-        S.escape_x = x;
-        S.escape_y = y;
-        S.escape_theta = theta;
-        tpSet(S, NAVGPU_TP_ESCAPING, true);
-      }
-      resetEscapeIfMoved();
-      if (best_cost == -1.0) best_cost = 1.0;
-    }
-    navgpu_tp_result& r = results[k];
-    r = navgpu_tp_result();
-    r.n_samples = (int32_t)h.made.size();
-    r.cost = best_cost;
-    if (best >= 0) {
-      r.xv = best_xv;
-      r.yv = best_yv;
-      r.thetav = best_thv;
-      r.n_points = O[best].n_points;
-      r.best_sample = best_made;
-    } else {  // the initial best_traj: Trajectory() with cost -1 and no points (cannot happen: backing up always takes)
-      r.best_sample = -1;
-    }
-    h.n_points = r.n_points;
-    if (r.cost >= 0) {  // findBestPath :969-978
-      r.drive[0] = r.xv;
-      r.drive[1] = r.yv;
-      r.drive[2] = r.thetav;
-    }
-    f->tp_h_winner[inst] = best;
-  }
-  // ---- second pass: the winner's points (published as the local plan)
-  HIP_TRY(hipMemcpyAsync(tp.winner + first, &f->tp_h_winner[first], sizeof(int32_t) * count, hipMemcpyHostToDevice, f->stream));
-  launch_tp_rollout(f->pl, tp, first, count, 1, f->stream);
-  HIP_TRY(waitStream(f->stream));
-  return checkLaunch();
-}
-
-int navgpu_tp_trajectory(navgpu_fleet* f, uint32_t instance, double* xyth, uint32_t cap) {
-  if (!f || !xyth || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
-  if (!f->tp_configured) return NAVGPU_ERR_STATE;
-  const int n = f->tph[instance].n_points;
-  if (n > (int)cap) return NAVGPU_ERR_CAPACITY;
-  if (n > 0) {
-    HIP_TRY(hipMemcpyAsync(xyth, f->tp.points + (size_t)instance * f->pl.max_sim_steps * 3, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, f->stream));
-    HIP_TRY(waitStream(f->stream));
-  }
-  return n;
-}
-
-int navgpu_tp_samples(navgpu_fleet* f, uint32_t instance, navgpu_tp_sample* samples, uint32_t cap) {
-  if (!f || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
-  if (!f->tp_configured) return NAVGPU_ERR_STATE;
-  const std::vector<navgpu_tp_sample>& m = f->tph[instance].made;
-  if (samples) {
-    if (m.size() > cap) return NAVGPU_ERR_CAPACITY;
-    if (!m.empty()) memcpy(samples, m.data(), sizeof(navgpu_tp_sample) * m.size());
-  }
-  return (int)m.size();
-}
-
-int navgpu_tp_score_trajectory(navgpu_fleet* f, uint32_t instance, const double pose[3], const double vel[3], const double vs[3], double* cost) {
-  if (!f || !pose || !vel || !vs || !cost || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
-  if (!f->tp_configured) return NAVGPU_ERR_STATE;
-  TpDev& tp = f->tp;
-  const uint32_t ms = tp.max_samples;
-  const double start[6] = {pose[0], pose[1], pose[2], vel[0], vel[1], vel[2]};
-  const uint32_t one = 1;
-  HIP_TRY(hipMemcpyAsync(tp.start + (size_t)instance * 6, start, sizeof(start), hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(tp.samples + (size_t)instance * ms * 3, vs, sizeof(double) * 3, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(tp.n_samples + instance, &one, sizeof(one), hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(waitStream(f->stream));  // the sources above live on this stack frame
-  launch_tp_rollout(f->pl, tp, instance, 1, 0, f->stream);
-  TpOut o;
-  HIP_TRY(hipMemcpyAsync(&o, tp.out + (size_t)instance * ms, sizeof(o), hipMemcpyDeviceToHost, f->stream));
-  HIP_TRY(waitStream(f->stream));
-  *cost = o.cost;
-  return checkLaunch();
-}
-
-int navgpu_tp_get_state(navgpu_fleet* f, uint32_t first, uint32_t count, navgpu_tp_state* states) {
-  if (!f || !states || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
-  if (!f->tp_configured) return NAVGPU_ERR_STATE;
-  for (uint32_t k = 0; k < count; ++k) states[k] = f->tph[first + k].st;
-  return NAVGPU_OK;
-}
-int navgpu_tp_set_state(navgpu_fleet* f, uint32_t first, uint32_t count, const navgpu_tp_state* states) {
-  if (!f || !states || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
-  if (!f->tp_configured) return NAVGPU_ERR_STATE;
-  for (uint32_t k = 0; k < count; ++k) f->tph[first + k].st = states[k];
   return NAVGPU_OK;
 }
 
