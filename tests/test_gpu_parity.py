@@ -1018,3 +1018,38 @@ def test_trajectory_planner_edge_cases(nav, orc):
             with pytest.raises(nav.NavgpuError):
                 fl.configure_trajectory_planner(N.TpConfig(heading_scoring=1))
         fl.close()
+
+
+def test_mapgrid_fleet_soak(nav, orc):
+    """Many wavefront workgroups in flight at once (384 per launch, more than the chip has CUs), several cycles with moving robots: every
+    grid against the oracle.  Guards the barrier-less neighbour-wave synchronisation of k_bfs_wave under load."""
+    from navigation_amd import synth
+    N = L(nav)
+    n, n_inst, cycles = 400, 128, 5
+    cfg = nav.DwaConfig(vx_samples=4, vy_samples=2, vth_samples=4, sim_time=1.0, sim_granularity=0.1, discretize_by_time=1)
+    ocfg = orc.DwaConfig(**cfg.as_dict())
+    insts = [_inflated_instance(orc, n, 200 + i, synth) for i in range(n_inst)]
+    fl = nav.Fleet(n_inst, n, n, synth.RES, layers=N.LAYER_OBSTACLE, max_sim_steps=32, max_plan=256)
+    fl.configure_planner(cfg)
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.upload(N.GRID_MASTER, np.stack([i["master"] for i in insts]))
+    fl.set_plan()
+    planners = [orc.DwaPlanner(i["master"], synth.RES, 0.0, 0.0, ocfg) for i in insts]
+    for p in planners:
+        p.set_plan()
+    rs = np.random.RandomState(12)
+    for cyc in range(cycles):
+        pos = np.stack([i["pos"] for i in insts]).astype(np.float32)
+        pos[:, :2] += rs.uniform(-0.4, 0.4, (n_inst, 2)).astype(np.float32)
+        pos[:, 2] += rs.uniform(-1.0, 1.0, n_inst).astype(np.float32)
+        vel = np.stack([i["vel"] for i in insts]).astype(np.float32)
+        cut = 200 - 30 * cyc  # shorter plans in later cycles: other seeds, other goals
+        plans = np.stack([i["plan"][:cut] for i in insts])
+        res = fl.find_best_path(pos, vel, plans)
+        for k in range(n_inst):
+            ores = planners[k].cycle(pos[k], vel[k], plans[k], synth.FOOTPRINT, want_samples=False)[0]
+            for gid, which in ((N.GRID_PATH, 0), (N.GRID_GOAL, 1), (N.GRID_GOAL_FRONT, 2)):
+                g = fl.download(gid, k, 1)[0]
+                assert np.array_equal(g.astype(np.float64), planners[k].grid(which)), f"MapGrid {which} differs (robot {k}, cycle {cyc})"
+            assert res[k].best_index == ores.best_index and abs(res[k].cost - ores.cost) <= 1e-5
+    fl.close()
