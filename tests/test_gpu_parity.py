@@ -1017,6 +1017,14 @@ def test_trajectory_planner_edge_cases(nav, orc):
             _tp_compare_cycle(fl, N, [o], edge, np.array([[0.3, 0.0, 0.0]], np.float32), 2)
             with pytest.raises(nav.NavgpuError):
                 fl.configure_trajectory_planner(N.TpConfig(heading_scoring=1))
+            # degenerate sample counts: dvx / dvtheta divide by zero exactly as the reference does (inf / nan steps)
+            for vxs, vths in ((1, 5), (4, 1), (1, 1), (0, 0)):
+                cfg1 = N.TpConfig(vx_samples=vxs, vtheta_samples=vths, sim_time=1.0, sim_granularity=0.05, angular_sim_granularity=0.05)
+                fl.configure_trajectory_planner(cfg1)
+                o1 = orc.TrajectoryPlanner(m, synth.RES, cfg1, fp)
+                o1.update_plan(ins["plan"])
+                o1.set_state(fl.tp_state(0, 1)[0])
+                _tp_compare_cycle(fl, N, [o1], pos, np.array([[0.1, 0.0, 0.2]], np.float32), 3)
         fl.close()
 
 
