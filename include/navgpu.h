@@ -206,6 +206,11 @@ int navgpu_fleet_get_origin(navgpu_fleet* fleet, uint32_t first, uint32_t count,
 int navgpu_grid_upload(navgpu_fleet* fleet, int grid, uint32_t first, uint32_t count, const void* host);
 int navgpu_grid_download(navgpu_fleet* fleet, int grid, uint32_t first, uint32_t count, void* host);
 int navgpu_grid_device(navgpu_fleet* fleet, int grid, void** device_ptr, size_t* instance_stride_bytes);
+/* replaces: Costmap2DPublisher::prepareGrid / the OccupancyGridUpdate window of publishCostmap
+ * (costmap_2d/src/costmap_2d_publisher.cpp:57-74,103-115,146-156): cells [x0, xn) x [y0, yn) of the master grid
+ * of one instance through the publisher's cost translation table (0, 1..98, 99, 100, -1), row-major into `out`
+ * ((xn - x0) * (yn - y0) int8).  The message origin is the costmap origin (navgpu_fleet_get_origin). */
+int navgpu_costmap_export(navgpu_fleet* fleet, uint32_t instance, uint32_t x0, uint32_t y0, uint32_t xn, uint32_t yn, int8_t* out);
 /* Costmap2D::resetMaps() on the given grid (default value of that grid) */
 int navgpu_grid_reset(navgpu_fleet* fleet, int grid, uint32_t first, uint32_t count);
 

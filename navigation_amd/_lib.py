@@ -219,6 +219,7 @@ SYMBOLS = [
     ("navgpu_tp_score_trajectory", C.c_int, [vp, u32, vp, vp, vp, C.POINTER(dbl)]),
     ("navgpu_tp_get_state", C.c_int, [vp, u32, u32, vp]),
     ("navgpu_tp_set_state", C.c_int, [vp, u32, u32, vp]),
+    ("navgpu_costmap_export", C.c_int, [vp, u32, u32, u32, u32, u32, vp]),
     ("navgpu_profile_enable", C.c_int, [vp, i32]),
     ("navgpu_profile_reset", C.c_int, [vp]),
     ("navgpu_profile_read", C.c_int, [vp, i32, C.POINTER(dbl), C.POINTER(C.c_uint64)]),

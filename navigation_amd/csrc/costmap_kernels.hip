@@ -71,6 +71,28 @@ void launch_static_interpret(uint8_t* dst, const int8_t* occ, uint32_t cells, ui
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_export_window: Costmap2DPublisher's occupancy view of a window of the master grid
+// (costmap_2d_publisher.cpp:57-74 table, :103-115 full grid, :146-156 update window): 0 -> 0, 253 -> 99,
+// 254 -> 100, 255 -> -1, 1..252 -> 1 + 97 (v - 1) / 251.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_export_window(const uint8_t* master, uint32_t nx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, int8_t* out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w * h) return;
+  const uint32_t y = i / w, x = i - y * w;
+  const uint32_t v = master[(size_t)(y0 + y) * nx + x0 + x];
+  int8_t o;
+  if (v == 0) o = 0;
+  else if (v == 253) o = 99;
+  else if (v == 254) o = 100;
+  else if (v == 255) o = -1;
+  else o = (int8_t)(1 + (97 * ((int)v - 1)) / 251);
+  out[i] = o;
+}
+void launch_export_window(const uint8_t* master, uint32_t nx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, int8_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_export_window, dim3((w * h + 255) / 256), dim3(256), 0, s, master, nx, x0, y0, w, h, out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Costmap2D::updateOrigin (costmap_2d.cpp:264-313) / VoxelLayer::updateOrigin (voxel_layer.cpp:385-440):
 // the overlap of the old and the new window keeps its contents, everything else becomes the default
 // value.  dst(x, y) = src(x + cell_ox, y + cell_oy) when that lies in the grid.  Ping-pong buffers,

@@ -149,6 +149,7 @@ void launch_merge(const CostmapDev& cm, uint32_t first, uint32_t count, const in
 void launch_inflate(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s);
 void launch_static_interpret(uint8_t* dst, const int8_t* occ, uint32_t cells, uint32_t cells_padded, uint32_t count,
                              int track_unknown_space, int trinary, int lethal_threshold, int unknown_cost_value, hipStream_t s);
+void launch_export_window(const uint8_t* master, uint32_t nx, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, int8_t* out, hipStream_t s);
 void launch_fill_u8(uint8_t* dst, uint8_t v, size_t n, hipStream_t s);
 void launch_fill_u32(uint32_t* dst, uint32_t v, size_t n, hipStream_t s);
 void launch_shift_u8(const uint8_t* src, uint8_t* dst, const CostmapDev& cm, uint32_t first, uint32_t count, uint8_t fill, hipStream_t s);

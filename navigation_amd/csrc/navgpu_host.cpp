@@ -299,6 +299,22 @@ int navgpu_grid_reset(navgpu_fleet* f, int grid, uint32_t first, uint32_t count)
   return checkLaunch();
 }
 
+/* Costmap2DPublisher view of a window of the master grid */
+int navgpu_costmap_export(navgpu_fleet* f, uint32_t instance, uint32_t x0, uint32_t y0, uint32_t xn, uint32_t yn, int8_t* out) {
+  if (!f || !out || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
+  const CostmapDev& cm = f->cm;
+  if (x0 >= xn || y0 >= yn || xn > cm.nx || yn > cm.ny) return NAVGPU_ERR_INVALID;
+  if (!f->d_occ) {
+    int rc = f->alloc(&f->d_occ, cm.cells);
+    if (rc) return rc;
+  }
+  const uint32_t w = xn - x0, h = yn - y0;
+  launch_export_window(cm.master + (size_t)instance * cm.cells_padded, cm.nx, x0, y0, w, h, f->d_occ, f->stream);
+  HIP_TRY(hipMemcpyAsync(out, f->d_occ, (size_t)w * h, hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(waitStream(f->stream));
+  return checkLaunch();
+}
+
 // ------------------------------------------------------------------------------------------------ layers
 int navgpu_static_set_map(navgpu_fleet* f, uint32_t first, uint32_t count, const int8_t* occ, int32_t track_unknown_space,
                           int32_t use_maximum, int32_t trinary, int32_t lethal_cost_threshold, int32_t unknown_cost_value) {

@@ -83,6 +83,14 @@ class Fleet:
     def master(self, first=0, count=None):
         return self.download(N.GRID_MASTER, first, count)
 
+    def export_occupancy(self, instance, x0=0, y0=0, xn=None, yn=None):
+        """Costmap2DPublisher's int8 occupancy view of a window of the master grid."""
+        xn = self.desc.size_x if xn is None else xn
+        yn = self.desc.size_y if yn is None else yn
+        out = np.zeros((yn - y0, xn - x0), np.int8)
+        check(self.L.navgpu_costmap_export(self.h, instance, x0, y0, xn, yn, _ptr(out)), "costmap_export")
+        return out
+
     def reset(self, grid, first=0, count=None):
         first, count = self._range(first, count)
         check(self.L.navgpu_grid_reset(self.h, grid, first, count), "grid_reset")

@@ -674,6 +674,30 @@ def test_planner_edge_cases(nav, orc):
     fl.close()
 
 
+def test_costmap_publisher_export(nav):
+    """Costmap2DPublisher's occupancy view (costmap_2d_publisher.cpp:57-74 table; :103-115 full grid; :146-156 window)."""
+    N = L(nav)
+    n = 96
+    rs = np.random.RandomState(2)
+    m = rs.randint(0, 256, (2, n, n)).astype(np.uint8)
+    m[0, :4, :4] = [[0, 1, 2, 126], [127, 128, 251, 252], [253, 254, 255, 0], [1, 252, 253, 255]]
+    table = np.zeros(256, np.int8)  # the reference's table, rebuilt from its text
+    table[0], table[253], table[254], table[255] = 0, 99, 100, -1
+    for i in range(1, 253):
+        table[i] = 1 + (97 * (i - 1)) // 251
+    fl = nav.Fleet(2, n, n, 0.05, layers=N.LAYER_OBSTACLE)
+    fl.upload(N.GRID_MASTER, m)
+    for k in range(2):
+        assert np.array_equal(fl.export_occupancy(k), table[m[k]])
+        assert np.array_equal(fl.export_occupancy(k, 5, 7, 61, 40), table[m[k][7:40, 5:61]])
+        assert np.array_equal(fl.export_occupancy(k, n - 1, n - 1, n, n), table[m[k][n - 1:, n - 1:]])
+    with pytest.raises(nav.NavgpuError):
+        fl.export_occupancy(0, 10, 10, 10, 20)  # empty window
+    with pytest.raises(nav.NavgpuError):
+        fl.export_occupancy(0, 0, 0, n + 1, n)
+    fl.close()
+
+
 def test_costmap_edge_cases(nav, orc):
     from navigation_amd import synth
     N = L(nav)
