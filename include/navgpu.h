@@ -230,6 +230,12 @@ int navgpu_obstacle_configure(navgpu_fleet* fleet, const navgpu_obstacle_params*
  * (plugins/inflation_layer.cpp:160-170,295-328,362-376).  The (R+2)^2 distance/cost tables are
  * built on the host in fp64 with libm exactly as the reference does, then uploaded. */
 int navgpu_inflation_configure(navgpu_fleet* fleet, const navgpu_inflation_params* params);
+/* footprint helpers, pure host functions (no fleet, no GPU).  xy = n x {x, y} in the robot frame.
+ * replaces: costmap_2d::calculateMinAndMaxDistances (costmap_2d/src/footprint.cpp:41-67; DBL_MAX / 0 for n <= 2),
+ * padFootprint (:138-147, in place), makeFootprintFromRadius (:150-167, 16 vertices). */
+int navgpu_footprint_radii(const double* xy, uint32_t n, double* inscribed_radius, double* circumscribed_radius);
+int navgpu_footprint_pad(double* xy, uint32_t n, double padding);
+int navgpu_footprint_from_radius(double radius, double* xy16);
 /* replaces: LayeredCostmap::setFootprint (layered_costmap.cpp:164-174) for [first,first+count).
  * footprint_xy = n_vertices x {x,y} in the robot frame.  Does NOT change inscribed_radius of the
  * inflation layer (pass it through navgpu_inflation_configure, as the adapter does). */

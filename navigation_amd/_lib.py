@@ -219,6 +219,9 @@ SYMBOLS = [
     ("navgpu_tp_score_trajectory", C.c_int, [vp, u32, vp, vp, vp, C.POINTER(dbl)]),
     ("navgpu_tp_get_state", C.c_int, [vp, u32, u32, vp]),
     ("navgpu_tp_set_state", C.c_int, [vp, u32, u32, vp]),
+    ("navgpu_footprint_radii", C.c_int, [vp, u32, C.POINTER(dbl), C.POINTER(dbl)]),
+    ("navgpu_footprint_pad", C.c_int, [vp, u32, dbl]),
+    ("navgpu_footprint_from_radius", C.c_int, [dbl, vp]),
     ("navgpu_costmap_export", C.c_int, [vp, u32, u32, u32, u32, u32, vp]),
     ("navgpu_profile_enable", C.c_int, [vp, i32]),
     ("navgpu_profile_reset", C.c_int, [vp]),

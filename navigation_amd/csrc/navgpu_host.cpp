@@ -299,6 +299,58 @@ int navgpu_grid_reset(navgpu_fleet* f, int grid, uint32_t first, uint32_t count)
   return checkLaunch();
 }
 
+// ---- footprint helpers (costmap_2d/src/footprint.cpp, costmap_math.{h,cpp}); pure host functions
+static double fpDistance(double x0, double y0, double x1, double y1) { return hypot(x1 - x0, y1 - y0); }  // costmap_math.h:58-61
+static double fpDistanceToLine(double pX, double pY, double x0, double y0, double x1, double y1) {  // costmap_math.cpp:32-67
+  const double A = pX - x0, B = pY - y0, C = x1 - x0, D = y1 - y0;
+  const double dot = A * C + B * D, len_sq = C * C + D * D;
+  const double param = dot / len_sq;
+  double xx, yy;
+  if (param < 0) {
+    xx = x0;
+    yy = y0;
+  } else if (param > 1) {
+    xx = x1;
+    yy = y1;
+  } else {
+    xx = x0 + param * C;
+    yy = y0 + param * D;
+  }
+  return fpDistance(pX, pY, xx, yy);
+}
+int navgpu_footprint_radii(const double* xy, uint32_t n, double* inscribed, double* circumscribed) {
+  if ((n && !xy) || !inscribed || !circumscribed) return NAVGPU_ERR_INVALID;
+  double min_dist = DBL_MAX, max_dist = 0.0;  // footprint.cpp:41-67
+  if (n > 2) {
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint32_t j = (i + 1 == n) ? 0 : i + 1;  // the last edge closes the polygon (:60-65)
+      const double vertex_dist = fpDistance(0.0, 0.0, xy[2 * i], xy[2 * i + 1]);
+      const double edge_dist = fpDistanceToLine(0.0, 0.0, xy[2 * i], xy[2 * i + 1], xy[2 * j], xy[2 * j + 1]);
+      min_dist = std::min(min_dist, std::min(vertex_dist, edge_dist));
+      max_dist = std::max(max_dist, std::max(vertex_dist, edge_dist));
+    }
+  }
+  *inscribed = min_dist;
+  *circumscribed = max_dist;
+  return NAVGPU_OK;
+}
+int navgpu_footprint_pad(double* xy, uint32_t n, double padding) {  // footprint.cpp:138-147
+  if (n && !xy) return NAVGPU_ERR_INVALID;
+  auto sign0 = [](double x) { return x < 0.0 ? -1.0 : (x > 0.0 ? 1.0 : 0.0); };
+  for (uint32_t i = 0; i < 2 * n; ++i) xy[i] += sign0(xy[i]) * padding;
+  return NAVGPU_OK;
+}
+int navgpu_footprint_from_radius(double radius, double* xy16) {  // footprint.cpp:150-167
+  if (!xy16) return NAVGPU_ERR_INVALID;
+  const int N = 16;
+  for (int i = 0; i < N; ++i) {
+    const double angle = i * 2 * M_PI / N;
+    xy16[2 * i] = cos(angle) * radius;
+    xy16[2 * i + 1] = sin(angle) * radius;
+  }
+  return NAVGPU_OK;
+}
+
 /* Costmap2DPublisher view of a window of the master grid */
 int navgpu_costmap_export(navgpu_fleet* f, uint32_t instance, uint32_t x0, uint32_t y0, uint32_t xn, uint32_t yn, int8_t* out) {
   if (!f || !out || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;

@@ -496,3 +496,12 @@ def footprint_cells(size_x, size_y, res, pos, footprint, fill=True, ox=0.0, oy=0
     out = np.zeros((cap, 2), np.int32)
     n = L.orc_tp_footprint_cells(size_x, size_y, res, ox, oy, _f32(pos), fp, len(fp), int(fill), out.ctypes.data, cap)
     return [tuple(int(v) for v in c) for c in out[:n]]
+
+
+def min_max_distances(footprint):
+    """costmap_2d::calculateMinAndMaxDistances (footprint.cpp:41-67) -> (inscribed, circumscribed)."""
+    L = lib()
+    fp = _f64(footprint).reshape(-1, 2)
+    mn, mx = C.c_double(), C.c_double()
+    L.orc_min_max_distances(fp, len(fp), C.byref(mn), C.byref(mx))
+    return mn.value, mx.value
