@@ -293,6 +293,12 @@ int navgpu_planner_samples(navgpu_fleet* fleet, uint32_t instance, double* costs
 /* replaces: DWAPlanner::checkTrajectory (dwa_planner.cpp:213-237) for one instance; uses the
  * staged state of that instance.  *ok = 1 when the single sample scores >= 0. */
 int navgpu_planner_check_trajectory(navgpu_fleet* fleet, uint32_t instance, const float vel_samples[3], int32_t* ok);
+/* replaces: DWAPlanner::getCellCosts (dwa_planner.cpp:185-202) over the whole map + MapGridVisualizer::publishCostCloud
+ * (base_local_planner/src/map_grid_visualizer.cpp:55-83): the cost cloud of one instance from the grids of its last
+ * cycle.  points = up to `capacity` x {x, y, z, path_cost, goal_cost, occ_cost, total_cost} (MapGridCostPoint), in the
+ * reference's order (cx outer, cy inner, cells for which getCellCosts returns false skipped).  Returns the
+ * number of points of the full cloud. */
+int navgpu_planner_cost_cloud(navgpu_fleet* fleet, uint32_t instance, float* points, uint32_t capacity);
 /* OscillationCostFunction state access (persists across cycles per instance) */
 int navgpu_planner_get_oscillation(navgpu_fleet* fleet, uint32_t first, uint32_t count, uint32_t* flags,
                                    float* prev_stationary_pos_xyz);

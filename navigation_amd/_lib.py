@@ -202,6 +202,7 @@ SYMBOLS = [
     ("navgpu_planner_trajectory", C.c_int, [vp, u32, vp, u32]),
     ("navgpu_planner_samples", C.c_int, [vp, u32, vp, vp, vp, u32]),
     ("navgpu_planner_check_trajectory", C.c_int, [vp, u32, vp, C.POINTER(i32)]),
+    ("navgpu_planner_cost_cloud", C.c_int, [vp, u32, vp, u32]),
     ("navgpu_planner_get_oscillation", C.c_int, [vp, u32, u32, vp, vp]),
     ("navgpu_planner_set_oscillation", C.c_int, [vp, u32, u32, vp, vp]),
     ("navgpu_local_plan_window", C.c_int, [vp, u32, vp, vp, dbl, i32, vp, u32, C.POINTER(u32), C.POINTER(u32)]),

@@ -155,6 +155,7 @@ void launch_fill_u32(uint32_t* dst, uint32_t v, size_t n, hipStream_t s);
 void launch_shift_u8(const uint8_t* src, uint8_t* dst, const CostmapDev& cm, uint32_t first, uint32_t count, uint8_t fill, hipStream_t s);
 void launch_shift_u32(const uint32_t* src, uint32_t* dst, const CostmapDev& cm, uint32_t first, uint32_t count, uint32_t fill, hipStream_t s);
 
+void launch_cell_costs(const PlannerDev& pl, uint32_t inst, float4* out, hipStream_t s);
 void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
 void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
 uint32_t launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s);  // returns blocks per instance

@@ -94,6 +94,7 @@ struct navgpu_fleet {
   int32_t* d_boxes_tmp = nullptr;               // [n][4]
   float* d_explicit = nullptr;                  // [3]
   int8_t* d_occ = nullptr;
+  float4* d_cell_costs = nullptr;                // [cells] navgpu_planner_cost_cloud
   // profiling
   bool profiling = false;
   std::vector<EventPair> events;

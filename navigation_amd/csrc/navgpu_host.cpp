@@ -888,6 +888,42 @@ int navgpu_planner_check_trajectory(navgpu_fleet* f, uint32_t instance, const fl
   return checkLaunch();
 }
 
+int navgpu_planner_cost_cloud(navgpu_fleet* f, uint32_t instance, float* points, uint32_t capacity) {
+  if (!f || instance >= f->desc.n_instances || (capacity && !points)) return NAVGPU_ERR_INVALID;
+  if (!f->planner_configured) return NAVGPU_ERR_STATE;
+  const PlannerDev& pl = f->pl;
+  if (!f->d_cell_costs) {
+    int rc = f->alloc(&f->d_cell_costs, (size_t)pl.cells);
+    if (rc) return rc;
+  }
+  launch_cell_costs(pl, instance, f->d_cell_costs, f->stream);
+  std::vector<float4> h(pl.cells);
+  HIP_TRY(hipMemcpyAsync(h.data(), f->d_cell_costs, sizeof(float4) * pl.cells, hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(waitStream(f->stream));
+  int rc = checkLaunch();
+  if (rc) return rc;
+  // MapGridVisualizer::publishCostCloud (map_grid_visualizer.cpp:55-83): cx outer, cy inner, mapToWorld per cell
+  const double ox = f->h_origin[2 * instance], oy = f->h_origin[2 * instance + 1], res = pl.res;
+  uint32_t n = 0;
+  for (uint32_t cx = 0; cx < pl.nx; ++cx)
+    for (uint32_t cy = 0; cy < pl.ny; ++cy) {
+      const float4& c = h[(size_t)cy * pl.nx + cx];
+      if (c.w != c.w) continue;  // NaN: getCellCosts returned false
+      if (n < capacity) {
+        float* p = points + (size_t)7 * n;
+        p[0] = (float)(ox + (cx + 0.5) * res);
+        p[1] = (float)(oy + (cy + 0.5) * res);
+        p[2] = 0.0f;
+        p[3] = c.x;
+        p[4] = c.y;
+        p[5] = c.z;
+        p[6] = c.w;
+      }
+      ++n;
+    }
+  return (int)n;  // points of the cloud (may exceed capacity: call again with a larger buffer)
+}
+
 int navgpu_planner_get_oscillation(navgpu_fleet* f, uint32_t first, uint32_t count, uint32_t* flags, float* prev) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
   if (flags) HIP_TRY(hipMemcpyAsync(flags, f->pl.osc_flags + first, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, f->stream));

@@ -1820,6 +1820,29 @@ uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_cell_costs: DWAPlanner::getCellCosts (dwa_planner.cpp:185-202) for every cell — what MapGridVisualizer's
+// cost cloud shows.  out[cell] = {path_cost, goal_cost, occ_cost, total_cost} as floats, total = NaN where the
+// reference returns false (path cost obstacle / unreachable, or an inscribed-or-worse cell).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_cell_costs(PlannerDev pl, uint32_t inst, float4* out) {
+  const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cell >= pl.cells) return;
+  const float path_cost = (float)(double)pl.path[(size_t)inst * pl.cells + cell];
+  const float goal_cost = (float)(double)pl.goal[(size_t)inst * pl.cells + cell];
+  const float occ_cost = (float)pl.master[(size_t)inst * pl.cells_padded + cell];
+  float total = __builtin_nanf("");
+  if (!(path_cost == (double)pl.cells || path_cost == (double)(pl.cells + 1) || occ_cost >= (float)kInscribed)) {
+    const double resolution = pl.res;
+    total = (float)(pl.cfg.path_distance_bias * resolution * path_cost + pl.cfg.goal_distance_bias * resolution * goal_cost +
+                    pl.cfg.occdist_scale * occ_cost);
+  }
+  out[cell] = make_float4(path_cost, goal_cost, occ_cost, total);
+}
+void launch_cell_costs(const PlannerDev& pl, uint32_t inst, float4* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_cell_costs, dim3((pl.cells + 255) / 256), dim3(256), 0, s, pl, inst, out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_select: the tail of SimpleScoredSamplingPlanner::findBestTrajectory (:111-135) and of
 // DWAPlanner::findBestPath (dwa_planner.cpp:316,357-368): pick the first strict minimum, rebuild
 // the winner's points, run OscillationCostFunction::updateOscillationFlags

@@ -262,6 +262,13 @@ class Fleet:
         check(self.L.navgpu_planner_check_trajectory(self.h, instance, _ptr(v), C.byref(ok)), "check_trajectory")
         return bool(ok.value)
 
+    def cost_cloud(self, instance):
+        """MapGridVisualizer's cost cloud of one robot: (n, 7) float32 x, y, z, path, goal, occ, total."""
+        cap = self.desc.size_x * self.desc.size_y
+        buf = np.zeros((cap, 7), np.float32)
+        n = check(self.L.navgpu_planner_cost_cloud(self.h, instance, _ptr(buf), cap), "cost_cloud")
+        return buf[:n].copy()
+
     def oscillation(self, first=0, count=None):
         first, count = self._range(first, count)
         flags = np.zeros(count, np.uint32)
