@@ -102,6 +102,7 @@ struct PlannerDev {
   const uint32_t* within;     // [n][ny][W] MapCell::within_robot bits of path_map_ (legacy planner), else null
   uint32_t win;               // edge (cells) of the costmap window staged in LDS by k_score
   uint32_t fp_rcells;         // Chebyshev radius (cells) that contains every footprint cell around the centre cell
+  uint32_t fp_chunk;          // cells of the longest footprint edge (+1): picks the k_score<CHUNK> instantiation
   uint32_t use_tables, tab_steps, tab_nfp, tab_nth;
   uint8_t* prep;              // [n][prep_stride] LDS image of k_score (window, reach bitmaps, heading tables), built per cycle by k_score_prep*
   uint32_t prep_stride, prep_bytes;

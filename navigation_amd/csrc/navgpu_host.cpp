@@ -505,6 +505,19 @@ static void updateWindow(navgpu_fleet* f) {
   uint32_t win = (uint32_t)std::min(cells * 2 + 1, 240.0);
   f->pl.win = win;
   f->pl.fp_rcells = (uint32_t)ceil(f->fp_radius / f->pl.res) + 1;  // vertex cells lie within this Chebyshev radius of the centre cell
+  {  // longest footprint edge in cells (both end cells included) over all instances
+    double max_edge = 0.0;
+    for (uint32_t i = 0; i < f->desc.n_instances; ++i) {
+      const uint32_t nv = f->h_fp_n[i];
+      const double* q = &f->h_fp_spec[(size_t)i * kMaxFootprint * 2];
+      for (uint32_t a = 0; a < nv; ++a) {
+        const uint32_t b = (a + 1) % nv;
+        max_edge = std::max(max_edge, std::max(fabs(q[2 * a] - q[2 * b]), fabs(q[2 * a + 1] - q[2 * b + 1])));
+        max_edge = std::max(max_edge, hypot(q[2 * a] - q[2 * b], q[2 * a + 1] - q[2 * b + 1]));
+      }
+    }
+    f->pl.fp_chunk = (uint32_t)ceil(max_edge / f->pl.res) + 1;
+  }
   // shared heading tables (k_score<TABLES>): constant velocity + fixed step count only
   uint32_t max_nfp = 0;
   for (uint32_t v : f->h_fp_n) max_nfp = std::max(max_nfp, v);

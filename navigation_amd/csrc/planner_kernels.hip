@@ -1178,7 +1178,9 @@ __host__ __device__ inline size_t score_bits_bytes(int win) {  // 2 x [win][nw][
 // PREP: 0 = build the LDS image (window, bitmaps, tables) in this workgroup; 1 = build it and store it to
 // pl.prep (k_score_prep*, one workgroup per robot); 2 = load the stored image (the scoring workgroups of
 // a robot all use the same one: 74 of them in the 32x32x16 configuration)
-template <bool EXPLICIT, bool TABLES, int THREADS, int PREP = 0>
+// CHUNK: cells of a footprint edge fetched per LDS round trip; the launcher picks the smallest of 6 / 9 / 12 / 16 that
+// covers the longest edge (a 0.4 m square at 0.05 m: 9), longer edges take several chunks
+template <bool EXPLICIT, bool TABLES, int THREADS, int PREP = 0, int CHUNK = 12>
 __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first, const float* explicit_sample) {
   extern __shared__ __align__(16) uint8_t s_dyn[];
   uint8_t* s_win = s_dyn;
@@ -1561,7 +1563,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
                     // kChunk at a time with all ds_reads in flight together (one wait per chunk instead
                     // of one dependent LDS round trip per cell); cells past the end re-read the first
                     // cell, cells past a lethal cell cannot change the outcome (-1 either way).
-                    constexpr int kChunk = 12;
+                    constexpr int kChunk = CHUNK;
                     int idx = (pyc - wy0) * win + (pxc - wx0);
                     const int idx_first = idx;
                     const int inc1 = yinc1 * win + xinc1, inc2 = yinc2 * win + xinc2;
@@ -1758,11 +1760,13 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
 // three entry points over the same body: the table variant is compiled for 6 waves/SIMD (80 VGPRs)
 // in 512-thread workgroups (3 per CU by LDS => 24 waves/CU; measured 2.39 vs 2.59 ms at 256 threads)
 constexpr int kScoreThreadsTab = 512;
+template <int CHUNK>
 __global__ __launch_bounds__(kScoreThreadsTab, 6) void k_score_tab(PlannerDev pl, uint32_t first, const float* explicit_sample) {
-  score_body<false, true, kScoreThreadsTab, 2>(pl, first, explicit_sample);
+  score_body<false, true, kScoreThreadsTab, 2, CHUNK>(pl, first, explicit_sample);
 }
+template <int CHUNK>
 __global__ __launch_bounds__(kScoreThreads) void k_score_gen(PlannerDev pl, uint32_t first, const float* explicit_sample) {
-  score_body<false, false, kScoreThreads, 2>(pl, first, explicit_sample);
+  score_body<false, false, kScoreThreads, 2, CHUNK>(pl, first, explicit_sample);
 }
 __global__ __launch_bounds__(kScoreThreadsTab) void k_score_prep_tab(PlannerDev pl, uint32_t first) {
   score_body<false, true, kScoreThreadsTab, 1>(pl, first, nullptr);
@@ -1802,20 +1806,32 @@ uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, c
   if (pl.use_tables) {
     const size_t lds = win_bytes + score_table_bytes(pl);
     const uint32_t blocks = (pl.max_samples + kScoreThreadsTab - 1) / kScoreThreadsTab;
-    if (lds > 48 * 1024) {
-      hipFuncSetAttribute((const void*)k_score_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipFuncSetAttribute((const void*)k_score_prep_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_score_prep_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_score_prep_tab, dim3(1, count), dim3(kScoreThreadsTab), lds, s, pl, first);
-    hipLaunchKernelGGL(k_score_tab, dim3(blocks, count), dim3(kScoreThreadsTab), lds, s, pl, first, explicit_sample);
+#define NAVGPU_SCORE_TAB(C)                                                                                              \
+  {                                                                                                                      \
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_score_tab<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(k_score_tab<C>, dim3(blocks, count), dim3(kScoreThreadsTab), lds, s, pl, first, explicit_sample);  \
+  }
+    if (pl.fp_chunk <= 6) NAVGPU_SCORE_TAB(6)
+    else if (pl.fp_chunk <= 9) NAVGPU_SCORE_TAB(9)
+    else if (pl.fp_chunk <= 12) NAVGPU_SCORE_TAB(12)
+    else NAVGPU_SCORE_TAB(16)
+#undef NAVGPU_SCORE_TAB
     return blocks;
   }
-  if (win_bytes > 48 * 1024) {
-    hipFuncSetAttribute((const void*)k_score_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes);
-    hipFuncSetAttribute((const void*)k_score_prep_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes);
-  }
+  if (win_bytes > 48 * 1024) hipFuncSetAttribute((const void*)k_score_prep_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes);
   hipLaunchKernelGGL(k_score_prep_gen, dim3(1, count), dim3(kScoreThreads), win_bytes, s, pl, first);
-  hipLaunchKernelGGL(k_score_gen, dim3(pl.score_blocks, count), dim3(kScoreThreads), win_bytes, s, pl, first, explicit_sample);
+#define NAVGPU_SCORE_GEN(C)                                                                                                    \
+  {                                                                                                                            \
+    if (win_bytes > 48 * 1024) hipFuncSetAttribute((const void*)k_score_gen<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes); \
+    hipLaunchKernelGGL(k_score_gen<C>, dim3(pl.score_blocks, count), dim3(kScoreThreads), win_bytes, s, pl, first, explicit_sample);          \
+  }
+  if (pl.fp_chunk <= 6) NAVGPU_SCORE_GEN(6)
+  else if (pl.fp_chunk <= 9) NAVGPU_SCORE_GEN(9)
+  else if (pl.fp_chunk <= 12) NAVGPU_SCORE_GEN(12)
+  else NAVGPU_SCORE_GEN(16)
+#undef NAVGPU_SCORE_GEN
   return pl.score_blocks;
 }
 
