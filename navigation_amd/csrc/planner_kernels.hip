@@ -1284,6 +1284,18 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     s_fb[it] = m;
   }
   }
+  // The LDS window is kept in "walk order": with allow_unknown the bytes 254 (LETHAL) and 255 (NO_INFORMATION)
+  // are swapped, so that in both modes a footprint cell fails pointCost iff its stored byte >= walk_fail and the
+  // polygon walk needs nothing but a running maximum per cell (cellCost() undoes the swap).
+  const bool walk_swap = pl.cfg.allow_unknown != 0;
+  const uint32_t walk_fail = walk_swap ? 255u : 254u;
+  if (PREP != 2 && walk_swap) {
+    __syncthreads();
+    for (int i = tid; i < win * win; i += blockDim.x) {
+      const uint8_t cc = s_win[i];
+      if (cc >= 254) s_win[i] = cc ^ 1u;
+    }
+  }
   // ---- TABLES: per-(v_theta sample, step) heading, trig, rotated footprint, forward-point offset
   const int K = TABLES ? (int)pl.tab_steps : 0;
   const int tnfp = TABLES ? (int)pl.tab_nfp : 0;
@@ -1339,6 +1351,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     const bool in = inWin(x, y);
     uint32_t v = s_win[in ? (y - wy0) * win + (x - wx0) : 0];
     asm volatile("" : "+v"(v));  // pin the ds_read here so it cannot be re-merged with the global load below
+    if (walk_swap && v >= 254u) v ^= 1u;  // back from walk order
     if (__builtin_expect(!in, 0)) v = master[y * g.nx + x];
     return (uint8_t)v;
   };
@@ -1503,7 +1516,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
                   f_cost = cc;
               } else {
                 int fx0 = 0, fy0 = 0, pxc = 0, pyc = 0;
-                uint8_t mx_cost = 0;
+                uint32_t mx_cost = 0;  // maximum over the perimeter cells, in walk order
                 for (uint32_t v = 0; v <= nfp && !bad; ++v) {
                   int vx, vy;
                   if (v < nfp) {
@@ -1580,11 +1593,8 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
                         idx += inc2;
                       }
 #pragma unroll
-                      for (int u = 0; u < kChunk; ++u) {
-                        const uint8_t cc = (uint8_t)cellv[u];
-                        bad |= (uint8_t)(cc - kLethal) <= fail_span;
-                        mx_cost = cc > mx_cost ? cc : mx_cost;
-                      }
+                      for (int u = 0; u < kChunk; ++u) mx_cost = max(mx_cost, cellv[u]);
+                      bad = mx_cost >= walk_fail;
                     }
                   } else {
                     for (int cp = 0; cp <= numpixels; ++cp) {
@@ -1593,7 +1603,8 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
                         bad = true;
                         break;
                       }
-                      mx_cost = cc > mx_cost ? cc : mx_cost;
+                      const uint32_t ct = (walk_swap && cc >= 254) ? (cc ^ 1u) : cc;  // walk order, like the LDS bytes
+                      mx_cost = ct > mx_cost ? ct : mx_cost;
                       num += numadd;
                       if (num >= den) {
                         num -= den;
@@ -1607,7 +1618,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
                   pxc = vx;
                   pyc = vy;
                 }
-                f_cost = mx_cost;
+                f_cost = (walk_swap && mx_cost == 254u) ? 255.0 : (double)mx_cost;  // an allowed NO_INFORMATION cell costs 255
               }
             }
             if (bad) {
