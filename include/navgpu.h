@@ -283,6 +283,18 @@ int navgpu_planner_stage(navgpu_fleet* fleet, uint32_t first, uint32_t count, co
  * (4 x MapGridCostFunction::prepare, rollout + six critics per sample, first-strict-minimum) +
  * OscillationCostFunction::updateOscillationFlags. */
 int navgpu_planner_cycle(navgpu_fleet* fleet, uint32_t first, uint32_t count);
+/* Bounded MapGrid wavefronts (no counterpart in the reference, which always runs computeTargetDistance over the whole
+ * costmap, map_grid.cpp:262-310).  The critics read a MapGrid only at trajectory and forward points
+ * (map_grid_cost_function.cpp:75-129), all inside a box around the robot of half edge
+ * hypot(max |v_x|, max |v_y|) * sim_time + forward_point_distance; a level-synchronous wavefront has every cell it has
+ * reached final, so the search of a cycle may stop once that box is settled.  enable = 1 (the default): it does, and the
+ * grids of that cycle are exact inside the box and completed on demand before anything else reads them
+ * (navgpu_grid_download / _device of the three MapGrids, navgpu_planner_cost_cloud, a checked trajectory that leaves
+ * the box) — a request that comes after the costmap or the plan of that cycle has changed fails with
+ * NAVGPU_ERR_STATE.  Robots within two such half edges of the end of their plan always get whole grids (the
+ * stop-and-rotate controller keeps using them across cycles).  enable = 0: every cycle searches the whole grid, as
+ * the reference does.  Planner results are identical either way. */
+int navgpu_planner_set_bounded_map_grids(navgpu_fleet* fleet, int32_t enable);
 int navgpu_planner_results(navgpu_fleet* fleet, uint32_t first, uint32_t count, navgpu_plan_result* results);
 /* winning trajectory of one instance: xyth = n_points x {x,y,theta}; returns n_points or <0 */
 int navgpu_planner_trajectory(navgpu_fleet* fleet, uint32_t instance, double* xyth, uint32_t capacity_points);

@@ -98,6 +98,13 @@ struct PlannerDev {
   int32_t* axis_count;        // [n][4]  (nx, ny, nth, total)
   uint32_t *path, *goal, *goal_front;  // [n][cells] each
   uint32_t* bfs_scratch;      // k_bfs_global bitmaps (only for grids too large for LDS)
+  int32_t* bfs_box;           // [n][4] x0, x1, y0, y1 (cells, inclusive) every MapGrid look-up of this cycle's samples falls in; x1 < x0 = none (k_samples)
+  uint32_t* bfs_reach;        // [n] staged half edge of that box in cells, 0 = search the whole grid
+  uint32_t bfs_bounded;       // launch switch: stop a wavefront once its robot's box is settled
+  unsigned long long* bfs_trace;  // TEMP debug
+  uint32_t* bfs_next_item;    // work counter of the persistent k_bfs_wave launch
+  uint32_t* bfs_levels;       // [n][3] levels the last wavefront of (robot, grid) ran: predicts the next one's length
+  uint32_t* bfs_order;        // [n * 3] items of a launch sorted longest first, stored at first * 3 (k_samples)
   uint32_t bfs_grids;         // wavefronts per robot: 3 (DWA: path, goal, goal_front) or 2 (legacy TrajectoryPlanner)
   const uint32_t* within;     // [n][ny][W] MapCell::within_robot bits of path_map_ (legacy planner), else null
   uint32_t win;               // edge (cells) of the costmap window staged in LDS by k_score
@@ -158,10 +165,11 @@ void launch_shift_u32(const uint32_t* src, uint32_t* dst, const CostmapDev& cm, 
 
 void launch_cell_costs(const PlannerDev& pl, uint32_t inst, float4* out, hipStream_t s);
 void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
-void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
+void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order = nullptr);
 uint32_t launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s);  // returns blocks per instance
 void launch_select(const PlannerDev& pl, uint32_t first, uint32_t count, uint32_t n_blocks, hipStream_t s);
 size_t bfs_lds_bytes(uint32_t nx, uint32_t ny);
+bool bfs_bounded_applies(const PlannerDev& pl);  // the wavefront kernel launch_bfs picks for this map can stop at the robot's box
 size_t score_table_bytes(const PlannerDev& pl);
 size_t score_window_bytes(uint32_t win);
 size_t score_prep_bytes(const PlannerDev& pl);

@@ -35,6 +35,7 @@ struct EventPair {
   int kernel;
   hipEvent_t a, b;
 };
+int ensureCompleteGrids(navgpu_fleet* f, uint32_t first, uint32_t count);
 }  // namespace navgpu
 
 struct navgpu_fleet {
@@ -61,6 +62,16 @@ struct navgpu_fleet {
   float* hp_pts = nullptr;
   double *hp_fpw = nullptr, *hp_pose = nullptr, *hp_plan = nullptr, *hp_front = nullptr;
   int32_t *hp_shift = nullptr, *hp_align = nullptr;
+  uint32_t* hp_reach = nullptr;
+  // bounded MapGrid wavefronts (navgpu_planner_set_bounded_map_grids): which robots hold grids that are exact inside
+  // their box only, that box, and whether the inputs of the cycle that made them are still the staged ones
+  bool bounded_grids = true;
+  std::vector<uint8_t> grid_partial;            // [n]
+  std::vector<int32_t> h_box;                   // [n][4] x0, x1, y0, y1 of the last bounded cycle
+  std::vector<uint64_t> inputs_gen, cycle_gen;  // [n] bumped by whatever a wavefront reads / value at the last cycle
+  void touchInputs(uint32_t first, uint32_t count) {
+    for (uint32_t i = first; i < first + count && i < inputs_gen.size(); ++i) ++inputs_gen[i];
+  }
   navgpu_robot_state* hp_state = nullptr;
   navgpu_plan_result* hp_result = nullptr;
   // DWAPlannerROS mirror (navgpu_local_planner_*): per-instance controller state, host only

@@ -130,6 +130,7 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   AP(f->hp_plan_cnt, n);
   AP(f->hp_front, (size_t)n * 2);
   AP(f->hp_align, n);
+  AP(f->hp_reach, n);
   AP(f->hp_result, n);
   f->pl.result = f->hp_result;  // k_select writes results straight into pinned host memory (72 B per robot)
 #undef AP
@@ -161,6 +162,12 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   if (bfs_scratch_words(cm.nx, cm.ny)) A(pl.bfs_scratch, (size_t)n * bfs_scratch_words(cm.nx, cm.ny));
   pl.bfs_grids = 3;
   pl.within = nullptr;
+  A(pl.bfs_box, (size_t)n * 4);
+  A(pl.bfs_reach, n);
+  A(pl.bfs_next_item, 4);
+  A(pl.bfs_levels, (size_t)n * 3);
+  A(pl.bfs_order, (size_t)n * 3);
+  pl.bfs_bounded = 0;
   A(pl.counters, (size_t)n * 2);
   A(pl.osc_flags, n);
   A(pl.osc_prev, (size_t)n * 3);
@@ -169,6 +176,11 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   f->h_origin.assign((size_t)n * 2, 0.0);
   f->h_fp_spec.assign((size_t)n * kMaxFootprint * 2, 0.0);
   f->h_fp_n.assign(n, 0);
+  f->grid_partial.assign(n, 0);
+  f->bounded_grids = getenv("NAVGPU_DEBUG_COMPLETE_GRIDS") == nullptr;  // A/B timing only; the API switch is navgpu_planner_set_bounded_map_grids
+  f->h_box.assign((size_t)n * 4, 0);
+  f->inputs_gen.assign(n, 0);
+  f->cycle_gen.assign(n, 0);
   // grids start at their default values (Costmap2D ctor -> resetMaps)
   launch_fill_u8(cm.master, cm.master_default, (size_t)n * cm.cells_padded, f->stream);
   if (cm.obst) launch_fill_u8(cm.obst, cm.obstacle_default, (size_t)n * cm.cells_padded, f->stream);
@@ -183,6 +195,8 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
     s.last_max_y = FLT_MAX;
   }
   hipError_t e = hipMemcpyAsync(cm.state, st.data(), sizeof(InstCostmapState) * n, hipMemcpyHostToDevice, f->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(pl.bfs_reach, 0, sizeof(uint32_t) * n, f->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(pl.bfs_levels, 0, sizeof(uint32_t) * 3 * n, f->stream);
   if (e == hipSuccess) e = waitStream(f->stream);
   if (e != hipSuccess || checkLaunch() != NAVGPU_OK) {
     if (e != hipSuccess) g_last_error = std::string("fleet init: ") + hipGetErrorString(e);
@@ -219,6 +233,7 @@ void* navgpu_stream(navgpu_fleet* f) { return f ? (void*)f->stream : nullptr; }
 
 int navgpu_fleet_set_origin(navgpu_fleet* f, uint32_t first, uint32_t count, const double* xy) {
   if (!f || !xy || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  f->touchInputs(first, count);
   memcpy(&f->h_origin[(size_t)first * 2], xy, sizeof(double) * 2 * count);
   HIP_TRY(hipMemcpyAsync(f->cm.origin + (size_t)first * 2, xy, sizeof(double) * 2 * count, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(waitStream(f->stream));
@@ -250,10 +265,13 @@ static int gridInfo(navgpu_fleet* f, int grid, void** base, size_t* elem, size_t
 }
 int navgpu_grid_upload(navgpu_fleet* f, int grid, uint32_t first, uint32_t count, const void* host) {
   if (!f || !host || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  f->touchInputs(first, count);
   void* base;
   size_t elem, stride, used;
   int rc = gridInfo(f, grid, &base, &elem, &stride, &used);
   if (rc) return rc;
+  if (grid >= NAVGPU_GRID_PATH)  // caller-supplied MapGrids are whatever the caller says they are
+    for (uint32_t i = first; i < first + count; ++i) f->grid_partial[i] = 0;
   HIP_TRY(hipMemcpy2DAsync((char*)base + (size_t)first * stride * elem, stride * elem, host, used * elem, used * elem, count,
                            hipMemcpyHostToDevice, f->stream));
   HIP_TRY(waitStream(f->stream));
@@ -265,6 +283,7 @@ int navgpu_grid_download(navgpu_fleet* f, int grid, uint32_t first, uint32_t cou
   size_t elem, stride, used;
   int rc = gridInfo(f, grid, &base, &elem, &stride, &used);
   if (rc) return rc;
+  if (grid >= NAVGPU_GRID_PATH && (rc = ensureCompleteGrids(f, first, count))) return rc;
   HIP_TRY(hipMemcpy2DAsync(host, used * elem, (char*)base + (size_t)first * stride * elem, stride * elem, used * elem, count,
                            hipMemcpyDeviceToHost, f->stream));
   HIP_TRY(waitStream(f->stream));
@@ -276,12 +295,14 @@ int navgpu_grid_device(navgpu_fleet* f, int grid, void** ptr, size_t* stride_byt
   size_t elem, stride, used;
   int rc = gridInfo(f, grid, &base, &elem, &stride, &used);
   if (rc) return rc;
+  if (grid >= NAVGPU_GRID_PATH && (rc = ensureCompleteGrids(f, 0, f->desc.n_instances))) return rc;
   *ptr = base;
   if (stride_bytes) *stride_bytes = stride * elem;
   return NAVGPU_OK;
 }
 int navgpu_grid_reset(navgpu_fleet* f, int grid, uint32_t first, uint32_t count) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  f->touchInputs(first, count);
   CostmapDev& cm = f->cm;
   switch (grid) {
     case NAVGPU_GRID_MASTER: launch_fill_u8(cm.master + (size_t)first * cm.cells_padded, cm.master_default, (size_t)count * cm.cells_padded, f->stream); break;
@@ -572,6 +593,7 @@ int navgpu_costmap_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
   if (!f || !poses || !f->rangeOk(first, count) || (n_obs && (!obs || (!points && n_points_total)))) return NAVGPU_ERR_INVALID;
   CostmapDev& cm = f->cm;
   if (f->desc.rolling_window && f->shift_pending) return NAVGPU_ERR_STATE;  // previous stage not consumed by an update yet
+  if (f->desc.rolling_window) f->touchInputs(first, count);  // the origins move now
   HIP_TRY(waitStream(f->stream));  // the pinned mirrors may still feed an earlier copy
   for (uint32_t li = 0; li < count; ++li) f->hp_cnt[first + li] = f->hp_used[first + li] = 0;
   for (uint32_t k = 0; k < n_obs; ++k) {
@@ -639,6 +661,7 @@ int navgpu_costmap_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
 
 int navgpu_costmap_update(navgpu_fleet* f, uint32_t first, uint32_t count) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  f->touchInputs(first, count);
   CostmapDev& cm = f->cm;
   if ((cm.layers & NAVGPU_LAYER_INFLATION) && !f->inflation_configured) return NAVGPU_ERR_STATE;
   if (f->desc.rolling_window && f->shift_pending) {
@@ -676,6 +699,7 @@ int navgpu_costmap_bounds(navgpu_fleet* f, uint32_t first, uint32_t count, int32
 
 int navgpu_inflate(navgpu_fleet* f, uint32_t first, uint32_t count, const int32_t* boxes) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  f->touchInputs(first, count);
   if (!f->inflation_configured) return NAVGPU_ERR_STATE;
   const int32_t* d_boxes = nullptr;
   if (boxes) {
@@ -699,6 +723,7 @@ int navgpu_obstacle_update_bounds(navgpu_fleet* f, uint32_t first, uint32_t coun
 
 int navgpu_obstacle_update_costs(navgpu_fleet* f, uint32_t first, uint32_t count, const int32_t* boxes) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  f->touchInputs(first, count);
   const int32_t* d_boxes = nullptr;
   if (boxes) {
     HIP_TRY(hipMemcpyAsync(f->d_boxes_tmp, boxes, sizeof(int32_t) * 4 * count, hipMemcpyHostToDevice, f->stream));
@@ -710,6 +735,80 @@ int navgpu_obstacle_update_costs(navgpu_fleet* f, uint32_t first, uint32_t count
 }
 
 // ------------------------------------------------------------------------------------------------ planner
+
+// ---- bounded MapGrid wavefronts ------------------------------------------------------------------------------------
+// The critics read a MapGrid at trajectory points and at the forward point only (map_grid_cost_function.cpp:75-129),
+// all within `reach` of the robot: speed bound x sim_time + forward_point_distance.  Every axis velocity a sample can
+// take lies between the robot's velocity and the limits (simple_trajectory_generator.cpp:77-110, velocity_iterator.h;
+// computeNewVelocities moves from the one towards the other), so |v_axis| <= max(|min|, |max|, |v|).  k_samples turns
+// the reach into the robot's box and a wavefront stops once that box is settled (k_bfs_wave); what it leaves open is
+// completed by ensureCompleteGrids before anybody else reads the grid.
+static const int kBoxMarginCells = 4;  // cell rounding of pose and points, the touched-obstacle ring, slack
+static double reachMetres(const navgpu_dwa_config& c, const float vel[3], const float* sample) {
+  auto axis = [&](double lo, double hi, int a) {
+    double b = std::max(std::max(fabs(lo), fabs(hi)), fabs((double)vel[a]));
+    if (sample) b = std::max(fabs((double)sample[a]), fabs((double)vel[a]));
+    return b;
+  };
+  const double bx = axis(c.min_vel_x, c.max_vel_x, 0), by = axis(c.min_vel_y, c.max_vel_y, 1);
+  return hypot(bx, by) * c.sim_time * 1.001 + fabs(c.forward_point_distance);
+}
+static uint32_t bfsReachCells(const navgpu_fleet* f, const navgpu_robot_state& s, double goal_x, double goal_y) {
+  if (!f->bounded_grids || !bfs_bounded_applies(f->pl)) return 0;
+  const double reach = reachMetres(f->pl.cfg, s.vel, nullptr);
+  const double cells = ceil(reach / f->pl.res) + kBoxMarginCells;
+  if (!(cells < 32768.0)) return 0;
+  // close to the goal the stop-and-rotate controller may take over and keep checking trajectories against these
+  // grids for many cycles (latched_stop_rotate_controller.cpp:188-269): give it complete ones
+  if (!(hypot(goal_x - s.pos[0], goal_y - s.pos[1]) > 2.0 * reach)) return 0;
+  return (uint32_t)cells;
+}
+// the cell box k_samples derives from a reach (same arithmetic, fp64); false = robot not on the map = whole grid
+static bool robotBox(const navgpu_fleet* f, uint32_t i, const float pos[3], uint32_t reach, int32_t box[4]) {
+  const double ox = f->h_origin[2 * i], oy = f->h_origin[2 * i + 1], res = f->pl.res;
+  const double wx = pos[0], wy = pos[1];
+  if (!reach || !(wx >= ox) || !(wy >= oy)) return false;
+  const double fx = (wx - ox) / res, fy = (wy - oy) / res;
+  if (!(fx < 2147483648.0) || !(fy < 2147483648.0)) return false;
+  const int64_t mx = (int)fx, my = (int)fy;
+  if (mx >= (int64_t)f->pl.nx || my >= (int64_t)f->pl.ny) return false;
+  box[0] = (int32_t)std::max<int64_t>(mx - reach, 0);
+  box[1] = (int32_t)std::min<int64_t>(mx + reach, f->pl.nx - 1);
+  box[2] = (int32_t)std::max<int64_t>(my - reach, 0);
+  box[3] = (int32_t)std::min<int64_t>(my + reach, f->pl.ny - 1);
+  return true;
+}
+// finish the grids of robots whose last wavefronts stopped early; fails when their inputs have changed since
+extern "C++" int navgpu::ensureCompleteGrids(navgpu_fleet* f, uint32_t first, uint32_t count) {
+  static const bool raw = getenv("NAVGPU_DEBUG_RAW_GRIDS") != nullptr;  // tools/probe_levels.py: look at what a bounded search left
+  if (raw) return NAVGPU_OK;
+  for (uint32_t i = first; i < first + count; ++i)
+    if (f->grid_partial[i] && f->cycle_gen[i] != f->inputs_gen[i]) {
+      g_last_error = "MapGrids of instance " + std::to_string(i) + " were searched inside the robot's box only and the costmap / plan they came from has changed; "
+                     "read them before the next update or call navgpu_planner_set_bounded_map_grids(f, 0)";
+      return NAVGPU_ERR_STATE;
+    }
+  PlannerDev pl = f->pl;
+  pl.bfs_bounded = 0;
+  for (uint32_t i = first; i < first + count;) {
+    if (!f->grid_partial[i]) {
+      ++i;
+      continue;
+    }
+    uint32_t j = i;
+    while (j < first + count && f->grid_partial[j]) f->grid_partial[j++] = 0;
+    launch_bfs(pl, i, j - i, f->stream);
+    i = j;
+  }
+  return checkLaunch();
+}
+
+int navgpu_planner_set_bounded_map_grids(navgpu_fleet* f, int32_t enable) {
+  if (!f) return NAVGPU_ERR_INVALID;
+  f->bounded_grids = enable != 0;
+  return NAVGPU_OK;
+}
+
 int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
   if (!f || !c) return NAVGPU_ERR_INVALID;
   if (!(c->sim_time > 0) || !(c->sim_granularity > 0) || !(c->angular_sim_granularity > 0)) return NAVGPU_ERR_INVALID;
@@ -763,6 +862,7 @@ int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
     pl.score_blocks = score_blocks;
   }
   pl.cfg = cfg;
+  f->touchInputs(0, nI);  // allow_unknown decides which cells a wavefront may enter
   // DWAPlanner::reconfigure scales (dwa_planner.cpp:64-75)
   pl.scale_path = pl.res * cfg.path_distance_bias * 0.5;
   pl.scale_goal = pl.res * cfg.goal_distance_bias * 0.5;
@@ -809,12 +909,15 @@ int navgpu_planner_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
     f->hp_front[2 * i] = gx + c.forward_point_distance * cos(angle_to_goal);
     f->hp_front[2 * i + 1] = gy + c.forward_point_distance * sin(angle_to_goal);
     f->hp_align[i] = sq_dist > c.forward_point_distance * c.forward_point_distance * c.cheat_factor ? 1 : 0;
+    f->hp_reach[i] = bfsReachCells(f, s, gx, gy);
   }
+  f->touchInputs(first, count);
   HIP_TRY(hipMemcpyAsync(pl.state + first, f->hp_state + first, sizeof(navgpu_robot_state) * count, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(hipMemcpyAsync(pl.plan + (size_t)first * pl.max_plan * 2, f->hp_plan + (size_t)first * pl.max_plan * 2, sizeof(double) * 2 * (size_t)count * pl.max_plan, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(hipMemcpyAsync(pl.plan_count + first, f->hp_plan_cnt + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(hipMemcpyAsync(pl.front_last + (size_t)first * 2, f->hp_front + (size_t)first * 2, sizeof(double) * 2 * count, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(hipMemcpyAsync(pl.align_on + first, f->hp_align + first, sizeof(int32_t) * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(pl.bfs_reach + first, f->hp_reach + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
   f->planner_staged = true;
   return NAVGPU_OK;
 }
@@ -823,8 +926,38 @@ int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
   if (!f->planner_configured || !f->planner_staged) return NAVGPU_ERR_STATE;
   PlannerDev& pl = f->pl;
+  pl.bfs_bounded = getenv("NAVGPU_DEBUG_BFS_STOP") ? atoi(getenv("NAVGPU_DEBUG_BFS_STOP")) : 1;  // per robot: bfs_reach (0 = whole grid)
+  for (uint32_t i = first; i < first + count; ++i) {
+    f->grid_partial[i] = robotBox(f, i, f->hp_state[i].pos, f->hp_reach[i], &f->h_box[(size_t)4 * i]) ? 1 : 0;
+    f->cycle_gen[i] = f->inputs_gen[i];
+  }
   launch_samples(pl, first, count, f->stream);
-  PROFILED(f, NAVGPU_K_BFS, launch_bfs(pl, first, count, f->stream));
+  if (getenv("NAVGPU_DEBUG_BOX")) {
+    std::vector<int32_t> hb((size_t)4 * count);
+    std::vector<uint32_t> hr(count);
+    hipMemcpyAsync(hb.data(), pl.bfs_box + (size_t)4 * first, sizeof(int32_t) * 4 * count, hipMemcpyDeviceToHost, f->stream);
+    hipMemcpyAsync(hr.data(), pl.bfs_reach + first, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, f->stream);
+    waitStream(f->stream);
+    uint32_t nvalid = 0, npart = 0, nreach = 0, ndr = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+      nvalid += hb[4 * i + 1] >= hb[4 * i];
+      npart += f->grid_partial[first + i];
+      nreach += f->hp_reach[first + i] != 0;
+      ndr += hr[i] != 0;
+    }
+    fprintf(stderr, "bounded=%u: %u robots, host reach %u, device reach %u, device boxes %u, host partial %u; box0 = %d %d %d %d\n", pl.bfs_bounded, count, nreach, ndr, nvalid, npart, hb[0], hb[1], hb[2], hb[3]);
+  }
+  if (getenv("NAVGPU_DEBUG_BFS_TRACE") && !pl.bfs_trace) f->alloc(&pl.bfs_trace, (size_t)f->desc.n_instances * 3 * 4);
+  PROFILED(f, NAVGPU_K_BFS, launch_bfs(pl, first, count, f->stream, pl.bfs_order + (size_t)first * 3));
+  if (pl.bfs_trace) {
+    std::vector<unsigned long long> h((size_t)count * 12);
+    hipMemcpyAsync(h.data(), pl.bfs_trace, h.size() * 8, hipMemcpyDeviceToHost, f->stream);
+    waitStream(f->stream);
+    FILE* fp = fopen(getenv("NAVGPU_DEBUG_BFS_TRACE"), "w");
+    for (size_t i = 0; i < (size_t)count * 3; ++i)
+      fprintf(fp, "%zu %llu %llu %llu %llu %llu\n", i, h[4 * i], h[4 * i + 1] & 0xFFFFFFFFFFFFull, h[4 * i + 1] >> 48, h[4 * i + 2], h[4 * i + 3]);
+    fclose(fp);
+  }
   uint32_t n_blocks = 0;
   PROFILED(f, NAVGPU_K_SCORE, n_blocks = launch_score(pl, first, count, nullptr, f->stream));
   PROFILED(f, NAVGPU_K_SELECT, launch_select(pl, first, count, n_blocks, f->stream));
@@ -888,6 +1021,17 @@ int navgpu_planner_check_trajectory(navgpu_fleet* f, uint32_t instance, const fl
   if (!f || !vs || !ok || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
   if (!f->planner_configured || !f->planner_staged) return NAVGPU_ERR_STATE;
   PlannerDev& pl = f->pl;
+  if (f->grid_partial[instance]) {  // the sample must stay inside the box the last wavefronts settled
+    const navgpu_robot_state& st = f->hp_state[instance];
+    const uint32_t need = (uint32_t)std::min(ceil(reachMetres(pl.cfg, st.vel, vs) / pl.res) + 3.0, 32768.0);
+    int32_t nb[4];
+    const int32_t* hb = &f->h_box[(size_t)4 * instance];
+    const bool inside = robotBox(f, instance, st.pos, need, nb) && nb[0] >= hb[0] && nb[1] <= hb[1] && nb[2] >= hb[2] && nb[3] <= hb[3];
+    if (!inside) {
+      int rc = ensureCompleteGrids(f, instance, 1);
+      if (rc) return rc;
+    }
+  }
   // checkTrajectory resets the oscillation flags first (dwa_planner.cpp:217)
   HIP_TRY(hipMemsetAsync(pl.osc_flags + instance, 0, sizeof(uint32_t), f->stream));
   HIP_TRY(hipMemcpyAsync(f->d_explicit, vs, sizeof(float) * 3, hipMemcpyHostToDevice, f->stream));
@@ -904,6 +1048,10 @@ int navgpu_planner_check_trajectory(navgpu_fleet* f, uint32_t instance, const fl
 int navgpu_planner_cost_cloud(navgpu_fleet* f, uint32_t instance, float* points, uint32_t capacity) {
   if (!f || instance >= f->desc.n_instances || (capacity && !points)) return NAVGPU_ERR_INVALID;
   if (!f->planner_configured) return NAVGPU_ERR_STATE;
+  {
+    int rc = ensureCompleteGrids(f, instance, 1);
+    if (rc) return rc;
+  }
   const PlannerDev& pl = f->pl;
   if (!f->d_cell_costs) {
     int rc = f->alloc(&f->d_cell_costs, (size_t)pl.cells);

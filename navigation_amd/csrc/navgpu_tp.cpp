@@ -193,6 +193,8 @@ static int tpLaunchGrids(navgpu_fleet* f, uint32_t first, uint32_t count, bool w
   pl.bfs_grids = 2;
   pl.within = with_within ? f->tp.within_bits : nullptr;
   pl.cfg.allow_unknown = f->tp.cfg.allow_unknown;
+  pl.bfs_bounded = 0;  // the legacy planner's look-ups are not confined to a box around the robot
+  for (uint32_t i = first; i < first + count; ++i) f->grid_partial[i] = 0;
   PROFILED(f, NAVGPU_K_BFS, launch_bfs(pl, first, count, f->stream));
   return NAVGPU_OK;
 }

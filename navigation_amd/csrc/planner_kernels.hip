@@ -81,6 +81,37 @@ __global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first) {
     cnt[3] = prod > 0 ? cnt[0] * cnt[1] * cnt[2] : 0;
     pl.counters[2 * inst] = 0;
     pl.counters[2 * inst + 1] = 0;
+    // the cells every MapGrid look-up of this robot's samples falls in (bounded wavefronts, k_bfs_wave): the staged
+    // reach around the robot's cell, clipped to the map; empty = search the whole grid
+    int4 box = make_int4(0, -1, 0, -1);
+    const uint32_t reach = pl.bfs_reach[inst];
+    const Geom g = geomOf(pl, inst);
+    uint32_t mx, my;
+    if (reach && worldToMap(g, (double)st.pos[0], (double)st.pos[1], mx, my)) {
+      box.x = max((int)mx - (int)reach, 0);
+      box.y = min((int)mx + (int)reach, (int)pl.nx - 1);
+      box.z = max((int)my - (int)reach, 0);
+      box.w = min((int)my + (int)reach, (int)pl.ny - 1);
+    }
+    reinterpret_cast<int4*>(pl.bfs_box)[inst] = box;
+  }
+  // dispatch order of this launch's wavefronts (k_bfs_wave takes items off a counter): longest first, predicted by
+  // the level count of the robot's previous cycle.  item = g * count + robot, g = 0 goal_front, 1 goal, 2 path;
+  // every robot ranks its three items among all of them (count * 3 keys: a few dozen loads per lane)
+  {
+    const uint32_t count = gridDim.x, total = 3 * count;
+    for (uint32_t g = 0; g < 3; ++g) {
+      const uint32_t i = g * count + blockIdx.x;
+      const uint32_t key = pl.bfs_levels[(size_t)inst * 3 + (2 - g)];
+      uint32_t before = 0;
+      for (uint32_t j = tid; j < total; j += 64) {
+        const uint32_t gj = j / count, rj = j - gj * count;
+        const uint32_t kj = pl.bfs_levels[(size_t)(first + rj) * 3 + (2 - gj)];
+        before += (kj > key || (kj == key && j < i)) ? 1u : 0u;
+      }
+      for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+      if (tid == 0) pl.bfs_order[(size_t)first * 3 + before] = i;
+    }
   }
 }
 void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
@@ -471,16 +502,25 @@ __device__ __forceinline__ uint32_t fromLaneAbove(uint32_t v) {
 // PL = level planes kept in registers: 10 (epochs of 1023 levels) for RPT 7; 3 (epochs of 7 levels, the cells written out
 // at every epoch end) for RPT 13, which extends the kernel to maps of up to 640 x 624 cells
 template <int RPT, bool LEGACY, int PL>
-__global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first) {
+__device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t inst, const int which, const uint32_t item) {
   extern __shared__ __align__(16) uint32_t sm[];
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_flag[3];
+  __shared__ uint32_t s_open[3];   // bounded search: some cell of the robot's box is still neither reached nor blocked
   __shared__ uint32_t s_prog[18];  // levels published by wave w at [w + 1]; [0] and [17] are sentinels
-  const int which = (LEGACY ? 1 : 2) - (int)blockIdx.y;  // longest searches (goal grids) are dispatched first
-  const uint32_t inst = first + blockIdx.x;
-  const uint32_t tid = threadIdx.x;
+  // opaque per item: otherwise everything below that depends only on the thread index and the map size is hoisted
+  // out of the item loop of k_bfs_wave and kept in registers across the whole search (measured: 400 B of spills)
+  uint32_t tid_ = threadIdx.x, nx_ = pl.nx, ny_ = pl.ny;
+  asm volatile("" : "+v"(tid_), "+s"(nx_), "+s"(ny_));
+  const uint32_t tid = tid_;
+  if (pl.bfs_trace && tid == 0) {
+    unsigned long long* t = pl.bfs_trace + (size_t)item * 4;
+    t[0] = wall_clock64();
+    t[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+    t[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+  }
   const Geom g = geomOf(pl, inst);
-  const uint32_t nx = pl.nx, ny = pl.ny, W = (nx + 31) >> 5;
+  const uint32_t nx = nx_, ny = ny_, W = (nx + 31) >> 5;
   const uint32_t strips = (ny + RPT - 1) / RPT;
   const uint32_t L = W + 1, spw = 64u / L;  // lanes per strip (one separator), strips per wave
   const uint32_t lane = tid & 63u, slot = lane / L;
@@ -504,7 +544,7 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
   const bool aligned4 = (nx & 3) == 0;
 
   for (uint32_t i = tid; i < 2 * rows_p * W + 2 * edge_words; i += blockDim.x) sm[i] = 0;
-  if (tid < 3) s_flag[tid] = 0;
+  if (tid < 3) s_flag[tid] = s_open[tid] = 0;
   __syncthreads();
 
   // --- seeds from the plan (as k_bfs)
@@ -622,6 +662,20 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
   const uint32_t wave_id = tid >> 6;
   uint32_t group = 0, any_grp = 0;  // termination is checked once per block of 2^kLow levels
   uint32_t had = 0;                 // OR of this lane's frontier words
+  // Bounded search (pl.bfs_bounded): the critics read a MapGrid only at cells the robot's samples can reach, a box
+  // around the robot (k_samples).  A level-synchronous wavefront has every reached cell final, so the sweep may stop
+  // once no cell of that box is left open (neither reached nor an obstacle); cells it has not reached by then read
+  // unreachableCellCosts() and the host completes the grid before anybody reads it outside the box.
+  int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1;
+  if (!LEGACY && pl.bfs_bounded) {
+    const int4 bb = reinterpret_cast<const int4*>(pl.bfs_box)[inst];
+    bx0 = __builtin_amdgcn_readfirstlane(bb.x);
+    bx1 = __builtin_amdgcn_readfirstlane(bb.y);
+    by0 = __builtin_amdgcn_readfirstlane(bb.z);
+    by1 = __builtin_amdgcn_readfirstlane(bb.w);
+  }
+  const bool bounded = !LEGACY && bx1 >= bx0 && by1 >= by0;
+  const bool wave_in_box = bounded && (int)(wave_id * spw * RPT) <= by1 && (int)((wave_id + 1) * spw * RPT) > by0;
 #pragma unroll
   for (int k = 0; k < RPT; ++k) had |= fr[k];
   while (true) {
@@ -677,7 +731,20 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
       if (group_end) {
         closeBlock(code >> kLow);
         if (any_grp) s_flag[group % 3] = 1;
-        if (tid == 0) s_flag[(group + 1) % 3] = 0;
+        if (wave_in_box) {  // wave-uniform; recomputed from scratch so that nothing of it lives across the levels
+          uint32_t wi_v = wi, r0_v = r0;
+          asm volatile("" : "+v"(wi_v), "+v"(r0_v));
+          const int c_lo = max(bx0 - (int)(wi_v * 32), 0), c_hi = min(bx1 - (int)(wi_v * 32), 31);
+          uint32_t open = 0;
+#pragma unroll
+          for (int k = 0; k < RPT; ++k)
+            if ((uint32_t)((int)(r0_v + k) - by0) <= (uint32_t)(by1 - by0)) open |= ~blocked[k];
+          if (c_hi >= c_lo && (open & (0xFFFFFFFFu >> (31 - c_hi)) & (0xFFFFFFFFu << c_lo)) != 0) s_open[group % 3] = 1;
+        }
+        if (tid == 0) {
+          s_flag[(group + 1) % 3] = 0;
+          s_open[(group + 1) % 3] = 0;
+        }
         __syncthreads();
       }
       uint32_t* t = ecur;
@@ -685,7 +752,7 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
       enxt = t;
       ++level;
       if (group_end) {
-        done = !s_flag[group % 3];  // nothing new in a whole block of levels: the search is over
+        done = !s_flag[group % 3] || (bounded && (!s_open[group % 3] || (pl.bfs_bounded >= 2 && level >= pl.bfs_bounded)));  // nothing new in a whole block of levels (or nothing open in the box): the search is over
         ++group;
         any_grp = 0;
         if (done || code == kEpoch) break;
@@ -843,6 +910,28 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
       for (uint32_t bpos = 0; bpos < nb; ++bpos)
         if (!((lt[k] >> bpos) & 1u)) drow[bpos] = cellValue(pl10, ex[k], blocked[k], bpos);
     }
+  }
+  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 4 + 1] = wall_clock64() | ((unsigned long long)level << 48);
+  if (!LEGACY && tid == 0) pl.bfs_levels[(size_t)inst * 3 + which] = level;  // next cycle's dispatch order
+}
+// Persistent launch: one workgroup per CU takes (grid, robot) items off a counter until none is left.  The hardware
+// hands the workgroups of a plain launch to XCDs and shader engines round-robin and IN ORDER, so with searches of
+// very different length (bounded ones end after 60..600 levels) a CU that is done early waits for the head of its
+// engine's queue: measured 0.71 ms of work per CU spread over 1.21 ms.  Items are ordered longest first (goal_front,
+// goal, path).  Every workgroup leaves the loop as soon as the counter has passed the last item.
+template <int RPT, bool LEGACY, int PL>
+__global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first, uint32_t count, uint32_t* next_item, const uint32_t* order) {
+  __shared__ uint32_t s_item;
+  const uint32_t total = count * (LEGACY ? 2u : 3u);
+  for (;;) {
+    if (threadIdx.x == 0) s_item = atomicAdd(next_item, 1u);
+    __syncthreads();
+    const uint32_t slot = s_item;
+    if (slot >= total) break;
+    const uint32_t item = order ? order[slot] : slot;  // longest searches first: by the level count of the previous cycle (k_samples)
+    const uint32_t g = item / count;
+    bfsWaveGrid<RPT, LEGACY, PL>(pl, first + (item - g * count), (LEGACY ? 1 : 2) - (int)g, item);
+    __syncthreads();  // s_item and the LDS staging of the decode are reused by the next item
   }
 }
 // k_bfs_wave applies when all strips fit the 16 waves of one workgroup
@@ -1107,7 +1196,20 @@ size_t bfs_scratch_words(uint32_t nx, uint32_t ny) {  // per instance, for k_bfs
   return bfs_lds_resident(nx, ny) ? 0 : (size_t)3 * 4 * ny * ((nx + 31) / 32);
 }
 
-void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
+static uint32_t bfs_cu_count() {
+  static const uint32_t n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return (uint32_t)cus;
+  }();
+  return n;
+}
+bool bfs_bounded_applies(const PlannerDev& pl) {
+  static const bool force_lds_kernel = getenv("NAVGPU_DEBUG_BFS_LDS") != nullptr;
+  if (force_lds_kernel || !bfs_lds_resident(pl.nx, pl.ny)) return false;
+  return bfs_wave_fits(pl.nx, pl.ny, 7) || (bfs_wave_fits(pl.nx, pl.ny, 13) && bfs_wave_lds(pl.nx, pl.ny, 13) <= 156u * 1024u);
+}
+void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order) {
   dim3 grid(count, pl.bfs_grids);
   const size_t lds = bfs_lds_bytes(pl.nx, pl.ny);  // dense bit-parallel sweep (no LDS atomics in the loop)
   const int rpt = bfs_rows_per_thread(pl.nx, pl.ny);
@@ -1122,7 +1224,8 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
   {                                                                                                                           \
     const size_t lds_w = bfs_wave_lds(pl.nx, pl.ny, R);                                                                       \
     if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<R, LEG, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); \
-    hipLaunchKernelGGL((k_bfs_wave<R, LEG, P>), grid, dim3(1024), lds_w, s, pl, first);                                       \
+    hipMemsetAsync(pl.bfs_next_item, 0, sizeof(uint32_t), s);                                                                 \
+    hipLaunchKernelGGL((k_bfs_wave<R, LEG, P>), dim3(std::min(count * pl.bfs_grids, bfs_cu_count())), dim3(1024), lds_w, s, pl, first, count, pl.bfs_next_item, order); \
     return;                                                                                                                   \
   }
     if (!force_lds_kernel && bfs_wave_fits(pl.nx, pl.ny, 7)) {

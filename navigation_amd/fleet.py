@@ -217,6 +217,10 @@ class Fleet:
         check(self.L.navgpu_planner_stage(self.h, first, n, C.cast(states, C.c_void_p), _ptr(packed_plans),
                                           len(packed_plans)), "planner_stage")
 
+    def set_bounded_map_grids(self, enable):
+        """navgpu_planner_set_bounded_map_grids: wavefronts stop once the robot's box is settled (default on)."""
+        check(self.L.navgpu_planner_set_bounded_map_grids(self.h, 1 if enable else 0), "set_bounded_map_grids")
+
     def planner_cycle(self, first=0, count=None):
         first, count = self._range(first, count)
         check(self.L.navgpu_planner_cycle(self.h, first, count), "planner_cycle")

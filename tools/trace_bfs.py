@@ -1,0 +1,31 @@
+"""TEMP: per-workgroup start/end of k_bfs_wave in the bench fleet"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["NAVGPU_DEBUG_BFS_TRACE"] = os.path.join(ROOT, "gpurun_out", "bfs_trace.txt")
+import navigation_amd as nav
+import bench
+fl, insts, cfg = bench.build_fleet(nav, 256, 400, 0)
+for _ in range(4):
+    bench.step(fl)
+fl.sync()
+a = np.loadtxt(os.environ["NAVGPU_DEBUG_BFS_TRACE"], dtype=np.float64)
+t0 = a[:, 1].min()
+st = (a[:, 1] - t0) / 100.0  # us (100 MHz)
+en = (a[:, 2] - t0) / 100.0
+lv = a[:, 3]
+print("makespan us", en.max(), "sum of durations / 256 us", (en - st).sum() / 256)
+for y in range(3):
+    s = slice(256 * y, 256 * y + 256)
+    print("grid", y, "start min/mean/max", st[s].min(), st[s].mean(), st[s].max(), "dur mean/max", (en - st)[s].mean(), (en - st)[s].max(), "levels mean", lv[s].mean())
+d = en - st
+# duration vs levels fit
+A = np.vstack([np.ones_like(lv), lv]).T
+coef = np.linalg.lstsq(A, d, rcond=None)[0]
+print("duration ~ %.1f us + %.3f us/level" % (coef[0], coef[1]))
+xcc = a[:, 5].astype(int) & 0xF
+print("WGs per XCC", np.bincount(xcc, minlength=8))
+for x in range(8):
+    m = xcc == x
+    print("xcc", x, "busy sum us", d[m].sum(), "last end", en[m].max())
