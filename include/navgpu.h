@@ -295,6 +295,9 @@ int navgpu_planner_cycle(navgpu_fleet* fleet, uint32_t first, uint32_t count);
  * stop-and-rotate controller keeps using them across cycles).  enable = 0: every cycle searches the whole grid, as
  * the reference does.  Planner results are identical either way. */
 int navgpu_planner_set_bounded_map_grids(navgpu_fleet* fleet, int32_t enable);
+/* introspection: the number of wavefront levels the last cycle ran for the path / goal / goal_front grid of each instance
+ * (levels = count x 3).  A whole-grid search runs until nothing new is reached, a bounded one stops earlier. */
+int navgpu_planner_wavefront_levels(navgpu_fleet* fleet, uint32_t first, uint32_t count, uint32_t* levels);
 int navgpu_planner_results(navgpu_fleet* fleet, uint32_t first, uint32_t count, navgpu_plan_result* results);
 /* winning trajectory of one instance: xyth = n_points x {x,y,theta}; returns n_points or <0 */
 int navgpu_planner_trajectory(navgpu_fleet* fleet, uint32_t instance, double* xyth, uint32_t capacity_points);

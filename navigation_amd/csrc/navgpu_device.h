@@ -16,6 +16,7 @@ namespace navgpu {
 
 constexpr uint8_t kNoInfo = 255, kLethal = 254, kInscribed = 253, kFree = 0;
 constexpr int kMaxFootprint = 32;
+constexpr int kCareRows = 128, kCareWords = 4;  // bounded wavefronts: extent of the per-robot pocket mask (k_samples)
 #ifndef NAVGPU_SCORE_THREADS
 #define NAVGPU_SCORE_THREADS 256
 #endif
@@ -98,7 +99,8 @@ struct PlannerDev {
   int32_t* axis_count;        // [n][4]  (nx, ny, nth, total)
   uint32_t *path, *goal, *goal_front;  // [n][cells] each
   uint32_t* bfs_scratch;      // k_bfs_global bitmaps (only for grids too large for LDS)
-  int32_t* bfs_box;           // [n][4] x0, x1, y0, y1 (cells, inclusive) every MapGrid look-up of this cycle's samples falls in; x1 < x0 = none (k_samples)
+  int32_t* bfs_box;           // [n][8] x0, x1, y0, y1 (cells, inclusive) of the robot's region = box of its MapGrid look-ups + 2 cells; x1 < x0 = none; [4] = bfs_care valid (k_samples)
+  uint32_t* bfs_care;         // [n][kCareRows][kCareWords] box cells outside pockets, by region row and word from the region's first
   uint32_t* bfs_reach;        // [n] staged half edge of that box in cells, 0 = search the whole grid
   uint32_t bfs_bounded;       // launch switch: stop a wavefront once its robot's box is settled
   unsigned long long* bfs_trace;  // TEMP debug

@@ -162,7 +162,8 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   if (bfs_scratch_words(cm.nx, cm.ny)) A(pl.bfs_scratch, (size_t)n * bfs_scratch_words(cm.nx, cm.ny));
   pl.bfs_grids = 3;
   pl.within = nullptr;
-  A(pl.bfs_box, (size_t)n * 4);
+  A(pl.bfs_box, (size_t)n * 8);
+  A(pl.bfs_care, (size_t)n * kCareRows * kCareWords);
   A(pl.bfs_reach, n);
   A(pl.bfs_next_item, 4);
   A(pl.bfs_levels, (size_t)n * 3);
@@ -808,6 +809,12 @@ int navgpu_planner_set_bounded_map_grids(navgpu_fleet* f, int32_t enable) {
   f->bounded_grids = enable != 0;
   return NAVGPU_OK;
 }
+int navgpu_planner_wavefront_levels(navgpu_fleet* f, uint32_t first, uint32_t count, uint32_t* levels) {
+  if (!f || !levels || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  HIP_TRY(hipMemcpyAsync(levels, f->pl.bfs_levels + (size_t)first * 3, sizeof(uint32_t) * 3 * count, hipMemcpyDeviceToHost, f->stream));
+  HIP_TRY(waitStream(f->stream));
+  return NAVGPU_OK;
+}
 
 int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
   if (!f || !c) return NAVGPU_ERR_INVALID;
@@ -932,21 +939,6 @@ int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
     f->cycle_gen[i] = f->inputs_gen[i];
   }
   launch_samples(pl, first, count, f->stream);
-  if (getenv("NAVGPU_DEBUG_BOX")) {
-    std::vector<int32_t> hb((size_t)4 * count);
-    std::vector<uint32_t> hr(count);
-    hipMemcpyAsync(hb.data(), pl.bfs_box + (size_t)4 * first, sizeof(int32_t) * 4 * count, hipMemcpyDeviceToHost, f->stream);
-    hipMemcpyAsync(hr.data(), pl.bfs_reach + first, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, f->stream);
-    waitStream(f->stream);
-    uint32_t nvalid = 0, npart = 0, nreach = 0, ndr = 0;
-    for (uint32_t i = 0; i < count; ++i) {
-      nvalid += hb[4 * i + 1] >= hb[4 * i];
-      npart += f->grid_partial[first + i];
-      nreach += f->hp_reach[first + i] != 0;
-      ndr += hr[i] != 0;
-    }
-    fprintf(stderr, "bounded=%u: %u robots, host reach %u, device reach %u, device boxes %u, host partial %u; box0 = %d %d %d %d\n", pl.bfs_bounded, count, nreach, ndr, nvalid, npart, hb[0], hb[1], hb[2], hb[3]);
-  }
   if (getenv("NAVGPU_DEBUG_BFS_TRACE") && !pl.bfs_trace) f->alloc(&pl.bfs_trace, (size_t)f->desc.n_instances * 3 * 4);
   PROFILED(f, NAVGPU_K_BFS, launch_bfs(pl, first, count, f->stream, pl.bfs_order + (size_t)first * 3));
   if (pl.bfs_trace) {

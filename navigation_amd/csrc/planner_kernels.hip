@@ -22,6 +22,7 @@ __device__ __forceinline__ Geom geomOf(const PlannerDev& pl, uint32_t inst) {
 // SimpleTrajectoryGenerator::initialise (src/simple_trajectory_generator.cpp:60-135).
 // One lane per axis: `next += step_size` is a sequential fp64 accumulation and must stay one.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bfsFreeWord(const uint8_t* master, uint32_t row, uint32_t nx, uint32_t wi, uint32_t unknown_is_obstacle);
 __global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first) {
   const uint32_t inst = first + blockIdx.x;
   const uint32_t tid = threadIdx.x;
@@ -81,19 +82,107 @@ __global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first) {
     cnt[3] = prod > 0 ? cnt[0] * cnt[1] * cnt[2] : 0;
     pl.counters[2 * inst] = 0;
     pl.counters[2 * inst + 1] = 0;
-    // the cells every MapGrid look-up of this robot's samples falls in (bounded wavefronts, k_bfs_wave): the staged
-    // reach around the robot's cell, clipped to the map; empty = search the whole grid
-    int4 box = make_int4(0, -1, 0, -1);
+  }
+  // Bounded wavefronts (k_bfs_wave).  The box = every cell a MapGrid look-up of this robot's samples can fall in: the
+  // staged reach around the robot's cell.  The region = the box grown by two cells, clipped to the map.  A search may
+  // stop when (a) no cell of the box that it could still reach is open and (b) no frontier cell is inside the region.
+  // "Could still reach" leaves out the POCKETS: free cells of the region that no 4-connected chain of free cells joins
+  // to the region's rim (one cell enclosed by inflated obstacles is enough to keep a search going over the whole map
+  // otherwise).  A wavefront gets into a pocket only from a seed next to it, which (b) waits for.  The pockets are
+  // found here, once per robot for its three grids, by a bit-parallel flood from the rim: two region rows per lane,
+  // whole words filled along a row with an add-carry, neighbours rows by lane shuffles.
+  {
+    int4 region = make_int4(0, -1, 0, -1);
+    int care_ok = 0;
     const uint32_t reach = pl.bfs_reach[inst];
     const Geom g = geomOf(pl, inst);
-    uint32_t mx, my;
+    uint32_t mx = 0, my = 0;
     if (reach && worldToMap(g, (double)st.pos[0], (double)st.pos[1], mx, my)) {
-      box.x = max((int)mx - (int)reach, 0);
-      box.y = min((int)mx + (int)reach, (int)pl.nx - 1);
-      box.z = max((int)my - (int)reach, 0);
-      box.w = min((int)my + (int)reach, (int)pl.ny - 1);
+      const int R = (int)reach + 2;
+      region.x = max((int)mx - R, 0);
+      region.y = min((int)mx + R, (int)pl.nx - 1);
+      region.z = max((int)my - R, 0);
+      region.w = min((int)my + R, (int)pl.ny - 1);
+      const int rows = region.w - region.z + 1, wx0 = region.x >> 5, nw = (region.y >> 5) - wx0 + 1;
+      if (rows <= kCareRows && nw <= kCareWords) {
+        const uint8_t* master = pl.master + (size_t)inst * pl.cells_padded;
+        const uint32_t unknown_is_obstacle = pl.cfg.allow_unknown != 0 ? 0u : 1u;
+        const int bx0 = max((int)mx - (int)reach, 0), bx1 = min((int)mx + (int)reach, (int)pl.nx - 1);
+        const int by0 = max((int)my - (int)reach, 0), by1 = min((int)my + (int)reach, (int)pl.ny - 1);
+        auto colMask = [&](int w, int x0, int x1) -> uint32_t {  // bits of word wx0 + w inside [x0, x1]
+          const int lo = max(x0 - (wx0 + w) * 32, 0), hi = min(x1 - (wx0 + w) * 32, 31);
+          return hi >= lo ? ((0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo)) : 0u;
+        };
+        uint32_t fm[2][kCareWords], F[2][kCareWords];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int rr = 2 * (int)tid + h, row = region.z + rr;
+#pragma unroll
+          for (int w = 0; w < kCareWords; ++w) {
+            fm[h][w] = 0;
+            F[h][w] = 0;
+            if (rr < rows && w < nw) {
+              const uint32_t cm = colMask(w, region.x, region.y);
+              fm[h][w] = bfsFreeWord(master, (uint32_t)row, pl.nx, (uint32_t)(wx0 + w), unknown_is_obstacle) & cm;
+              const uint32_t rim = (rr == 0 || rr == rows - 1) ? cm : (colMask(w, region.x, region.x) | colMask(w, region.y, region.y));
+              F[h][w] = fm[h][w] & rim;
+            }
+          }
+        }
+        bool settled = false;
+        for (int it = 0; it < 256 && !settled; ++it) {
+          uint32_t changed = 0;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int w = 0; w < kCareWords; ++w) {
+              uint32_t up, dn;
+              if (h == 0) {
+                up = __shfl_up(F[1][w], 1);
+                if (tid == 0) up = 0;
+                dn = F[1][w];
+              } else {
+                up = F[0][w];
+                dn = __shfl_down(F[0][w], 1);
+                if (tid == 63) dn = 0;
+              }
+              const uint32_t cur = F[h][w], f = fm[h][w];
+              uint32_t n = cur | up | dn | (cur << 1) | (cur >> 1);
+              if (w > 0) n |= F[h][w - 1] >> 31;
+              if (w + 1 < kCareWords) n |= F[h][w + 1] << 31;
+              n &= f;
+              // fill the runs of free cells the set bits lie in: towards bit 31 with an add-carry, towards bit 0 mirrored
+              n |= f & ~(f + n);
+              const uint32_t fr_ = __brev(f), nr = __brev(n);
+              n |= __brev(fr_ & ~(fr_ + nr));
+              changed |= n ^ cur;
+              F[h][w] = n;
+            }
+          }
+          settled = __builtin_amdgcn_ballot_w64(changed != 0) == 0;
+        }
+        care_ok = settled ? 1 : 0;  // not settled within the bound: no pocket is left out (the search is exact either way)
+        uint32_t* care = pl.bfs_care + (size_t)inst * kCareRows * kCareWords;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int rr = 2 * (int)tid + h, row = region.z + rr;
+#pragma unroll
+          for (int w = 0; w < kCareWords; ++w) {
+            uint32_t cw = 0;
+            if (rr < rows && w < nw && row >= by0 && row <= by1) cw = colMask(w, bx0, bx1) & ~(fm[h][w] & ~F[h][w]);
+            care[rr * kCareWords + w] = cw;
+          }
+        }
+      }
     }
-    reinterpret_cast<int4*>(pl.bfs_box)[inst] = box;
+    if (tid == 0) {
+      int* b = pl.bfs_box + (size_t)inst * 8;
+      b[0] = region.x;
+      b[1] = region.y;
+      b[2] = region.z;
+      b[3] = region.w;
+      b[4] = care_ok;
+    }
   }
   // dispatch order of this launch's wavefronts (k_bfs_wave takes items off a counter): longest first, predicted by
   // the level count of the robot's previous cycle.  item = g * count + robot, g = 0 goal_front, 1 goal, 2 path;
@@ -516,8 +605,6 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
   if (pl.bfs_trace && tid == 0) {
     unsigned long long* t = pl.bfs_trace + (size_t)item * 4;
     t[0] = wall_clock64();
-    t[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
-    t[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
   }
   const Geom g = geomOf(pl, inst);
   const uint32_t nx = nx_, ny = ny_, W = (nx + 31) >> 5;
@@ -666,18 +753,20 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
   // around the robot (k_samples).  A level-synchronous wavefront has every reached cell final, so the sweep may stop
   // once no cell of that box is left open (neither reached nor an obstacle); cells it has not reached by then read
   // unreachableCellCosts() and the host completes the grid before anybody reads it outside the box.
-  int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1;
+  int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, care_ok = 0;  // the robot's region (box + 2 cells) and whether its pockets are known
   if (!LEGACY && pl.bfs_bounded) {
-    const int4 bb = reinterpret_cast<const int4*>(pl.bfs_box)[inst];
+    const int4 bb = reinterpret_cast<const int4*>(pl.bfs_box)[2 * inst];
     bx0 = __builtin_amdgcn_readfirstlane(bb.x);
     bx1 = __builtin_amdgcn_readfirstlane(bb.y);
     by0 = __builtin_amdgcn_readfirstlane(bb.z);
     by1 = __builtin_amdgcn_readfirstlane(bb.w);
+    care_ok = __builtin_amdgcn_readfirstlane(pl.bfs_box[8 * inst + 4]);
   }
   const bool bounded = !LEGACY && bx1 >= bx0 && by1 >= by0;
   const bool wave_in_box = bounded && (int)(wave_id * spw * RPT) <= by1 && (int)((wave_id + 1) * spw * RPT) > by0;
 #pragma unroll
   for (int k = 0; k < RPT; ++k) had |= fr[k];
+  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 4 + 2] = wall_clock64();
   while (true) {
     bool done = false;
     uint32_t code = 0;
@@ -735,10 +824,16 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
           uint32_t wi_v = wi, r0_v = r0;
           asm volatile("" : "+v"(wi_v), "+v"(r0_v));
           const int c_lo = max(bx0 - (int)(wi_v * 32), 0), c_hi = min(bx1 - (int)(wi_v * 32), 31);
-          uint32_t open = 0;
+          // care words (k_samples): the box cells that are not in a pocket; stored per region row, four words from the region's first
+          const uint32_t cw_i = wi_v - (uint32_t)(bx0 >> 5);
+          const uint32_t* care = pl.bfs_care + (size_t)inst * kCareRows * kCareWords + cw_i;
+          const bool has_care = care_ok != 0 && cw_i < (uint32_t)kCareWords;
+          uint32_t open = 0;  // open cells of the box that still count + frontier cells inside the region
 #pragma unroll
-          for (int k = 0; k < RPT; ++k)
-            if ((uint32_t)((int)(r0_v + k) - by0) <= (uint32_t)(by1 - by0)) open |= ~blocked[k];
+          for (int k = 0; k < RPT; ++k) {
+            const uint32_t rr = (uint32_t)((int)(r0_v + k) - by0);
+            if (rr <= (uint32_t)(by1 - by0)) open |= (~blocked[k] & (has_care ? care[rr * kCareWords] : (care_ok ? 0u : 0xFFFFFFFFu))) | fr[k];
+          }
           if (c_hi >= c_lo && (open & (0xFFFFFFFFu >> (31 - c_hi)) & (0xFFFFFFFFu << c_lo)) != 0) s_open[group % 3] = 1;
         }
         if (tid == 0) {
@@ -783,6 +878,7 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
     }
   }
 
+  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 4 + 3] = wall_clock64();
   // --- expanded set = reached free cells + seeds; its obstacle neighbours were touched
   uint32_t ex[RPT], freeb[RPT];
 #pragma unroll
@@ -827,8 +923,14 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
   // covers 8 whole words = 1 KB of contiguous distances.
   const uint32_t nwords = spw * W;
   const bool coalesced = aligned4 && (size_t)16 * nwords * 16 <= (size_t)2 * rows_p * W + 2 * edge_words;
+  // A bounded search is only ever read inside the robot's region (the host completes the grid before anything else
+  // looks at it), so only those rows and words are written: 65 x 96 cells instead of 400 x 400.
+  const uint32_t dec_y0 = bounded ? (uint32_t)by0 : 0u, dec_rows = bounded ? (uint32_t)(by1 - by0 + 1) : ny;
+  const uint32_t dec_w0 = bounded ? (uint32_t)(bx0 >> 5) : 0u, dec_w1 = bounded ? (uint32_t)(bx1 >> 5) : W - 1;
   __syncthreads();  // everyone is done with seedm / late / the edge buffers
-  if (coalesced) {
+  if (bounded && !wave_in_box) {
+    // none of this wave's rows is in the region
+  } else if (coalesced) {
     uint4* stage = reinterpret_cast<uint4*>(sm) + (size_t)wave_id * nwords * 4;
     const bool holder = slot < spw && lane - slot * L < W;
     const uint32_t myw = holder ? slot * W + (lane - slot * L) : 0u;
@@ -838,7 +940,7 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
     for (int j = 0; j < 8; ++j) {
       const uint32_t wj = 8u * j + (lane >> 3);
       const uint32_t sj = wj / W, wij = wj - sj * W, strip_j = wave_id * spw + sj;
-      const bool ok = wj < nwords && strip_j < strips && wij * 32 + c0 < nx;
+      const bool ok = wj < nwords && strip_j < strips && wij * 32 + c0 < nx && wij >= dec_w0 && wij <= dec_w1;
       rowj[j] = ok ? strip_j * RPT : 0xFFFFFF00u;  // rows of a word that does not exist are never < ny
       cellbase[j] = strip_j * RPT * nx + wij * 32 + c0;
     }
@@ -858,7 +960,7 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (rowj[j] + k < ny) {
+        if (rowj[j] + k - dec_y0 < dec_rows) {
           const uint32_t wj = 8u * j + (lane >> 3);
           uint32_t* out = dist + cellbase[j] + k * nx;
           uint4 v;
@@ -894,7 +996,7 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
   } else if (owner) {
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-      if (r0 + k >= ny) continue;
+      if (r0 + k >= ny || r0 + k - dec_y0 >= dec_rows || wi < dec_w0 || wi > dec_w1) continue;
       uint32_t pl10[PL];
       if constexpr (PL == 10) {
         const uint32_t t10[PL] = {plane[0][k], plane[1][k], plane[2][k], plane[3][k], plane[4][k],

@@ -221,6 +221,13 @@ class Fleet:
         """navgpu_planner_set_bounded_map_grids: wavefronts stop once the robot's box is settled (default on)."""
         check(self.L.navgpu_planner_set_bounded_map_grids(self.h, 1 if enable else 0), "set_bounded_map_grids")
 
+    def wavefront_levels(self, first=0, count=None):
+        """Levels the last cycle's path / goal / goal_front wavefronts ran, [count, 3]."""
+        first, count = self._range(first, count)
+        out = np.zeros((count, 3), np.uint32)
+        check(self.L.navgpu_planner_wavefront_levels(self.h, first, count, _ptr(out)), "wavefront_levels")
+        return out
+
     def planner_cycle(self, first=0, count=None):
         first, count = self._range(first, count)
         check(self.L.navgpu_planner_cycle(self.h, first, count), "planner_cycle")

@@ -1120,3 +1120,93 @@ def test_mapgrid_fleet_soak(nav, orc):
                 assert np.array_equal(g.astype(np.float64), planners[k].grid(which)), f"MapGrid {which} differs (robot {k}, cycle {cyc})"
             assert res[k].best_index == ores.best_index and abs(res[k].cost - ores.cost) <= 1e-5
     fl.close()
+
+
+# ---- bounded MapGrid wavefronts (navgpu_planner_set_bounded_map_grids): same planner results, grids completed on demand
+def test_bounded_map_grids_equal_complete(nav, orc):
+    from navigation_amd import synth
+    from navigation_amd._lib import NavgpuError
+    N = L(nav)
+    n, n_inst = 400, 6
+    cfg = nav.DwaConfig(vx_samples=8, vy_samples=5, vth_samples=9, sim_time=1.7, sim_granularity=0.085, discretize_by_time=1)
+    insts = [_inflated_instance(orc, n, 40 + i, synth) for i in range(n_inst)]
+    masters = np.stack([i["master"] for i in insts])
+    pos = np.stack([i["pos"] for i in insts])
+    vel = np.stack([i["vel"] for i in insts])
+    plans = np.stack([i["plan"] for i in insts])
+    out = {}
+    for bounded in (1, 0):
+        fl = nav.Fleet(n_inst, n, n, synth.RES, layers=N.LAYER_OBSTACLE, keep_sample_costs=True, max_sim_steps=32, max_plan=256)
+        fl.configure_planner(cfg)
+        fl.set_footprint(synth.FOOTPRINT)
+        fl.set_bounded_map_grids(bounded)
+        fl.upload(N.GRID_MASTER, masters)
+        fl.set_plan()
+        res = fl.find_best_path(pos, vel, plans)
+        lv = fl.wavefront_levels()
+        samples = [fl.samples(k) for k in range(n_inst)]
+        grids = [fl.download(g) for g in (N.GRID_PATH, N.GRID_GOAL, N.GRID_GOAL_FRONT)]  # completes the bounded ones
+        out[bounded] = (res, lv, samples, grids)
+        if bounded:
+            # a second cycle leaves bounded grids again; once the costmap they came from is replaced they cannot be completed
+            fl.find_best_path(pos, vel, plans)
+            fl.upload(N.GRID_MASTER, masters)
+            with pytest.raises(NavgpuError):
+                fl.download(N.GRID_PATH)
+            fl.set_bounded_map_grids(0)
+            fl.find_best_path(pos, vel, plans)
+            fl.upload(N.GRID_MASTER, masters)
+            assert np.array_equal(fl.download(N.GRID_PATH), grids[0])
+        fl.close()
+    (rb, lb, sb, gb), (rc, lc, sc, gc) = out[1], out[0]
+    assert (lb < lc).sum() >= 2 * n_inst, (lb, lc)  # the bounded searches did stop early (goal ~160 cells away, reach ~30)
+    assert (lb <= lc).all()
+    for k in range(n_inst):
+        assert (rb[k].best_index, rb[k].n_valid, rb[k].n_scored, rb[k].cost) == (rc[k].best_index, rc[k].n_valid, rc[k].n_scored, rc[k].cost)
+        assert np.array_equal(sb[k][0], sc[k][0]) and np.array_equal(sb[k][1], sc[k][1])  # every sample's cost and status
+    for a, b in zip(gb, gc):
+        assert np.array_equal(a, b)
+    # and both equal the oracle (costs of robot 0)
+    p = orc.DwaPlanner(masters[0], synth.RES, 0.0, 0.0, orc.DwaConfig(**cfg.as_dict()))
+    p.set_plan()
+    o, _, _, cfull, ost = p.cycle(pos[0], vel[0], plans[0], synth.FOOTPRINT)
+    scored = ost == 1
+    assert np.array_equal(sb[0][1], ost)
+    assert np.allclose(sb[0][0][scored], cfull[scored], rtol=0, atol=1e-5)
+    assert np.array_equal(gb[0][0].astype(np.float64), p.grid(0))
+
+
+def test_bounded_map_grids_pockets(nav, orc):
+    """Enclosed free cells inside the robot's box: left alone when nothing feeds them, filled when a plan pose lies on
+    their wall (seeds expand whatever their cost, map_grid.cpp:160-187) - the bounded search has to wait for that."""
+    from navigation_amd import synth
+    N = L(nav)
+    n = 240
+    res = synth.RES
+    cfg_kw = dict(vx_samples=9, vy_samples=7, vth_samples=9, sim_time=1.7, sim_granularity=0.085, discretize_by_time=1, max_vel_y=0.3, min_vel_y=-0.3)
+    rx, ry = 60, 120  # robot cell
+    for variant in range(3):
+        m = np.zeros((n, n), np.uint8)
+        # ring of lethal cells around a free 5 x 5 interior, 12 cells ahead of the robot; variant 1 puts the plan through it
+        cx, cy = rx + 12, ry + (0 if variant == 1 else 9)
+        m[cy - 4:cy + 5, cx - 4:cx + 5] = LETHAL
+        m[cy - 2:cy + 3, cx - 2:cx + 3] = 0
+        if variant == 2:  # a one-cell pocket next to the robot and a long wall that forces a detour of the goal wavefront
+            m[ry - 3:ry, rx + 3:rx + 6] = INSCRIBED
+            m[ry - 2, rx + 4] = 0
+            m[20:200, 150] = LETHAL
+        plan = np.stack([(rx + 0.5) * res + 0.04 * np.arange(200), np.full(200, (ry + 0.5) * res)], 1)
+        fl, p = _planner_pair(nav, orc, n, m, cfg_kw, synth.FOOTPRINT)
+        fl.set_plan()
+        p.set_plan()
+        pos, vel = [(rx + 0.5) * res, (ry + 0.5) * res, 0.2], [0.3, 0.0, 0.1]
+        _compare_cycle(fl, p, pos, vel, plan, synth.FOOTPRINT)
+        lv = fl.wavefront_levels()[0]
+        # none of them ran over the whole 240 x 240 map (path > 230 levels, goal > 330, behind the wall of variant 2 > 500)
+        assert lv[0] < 120 and lv[1] < (320 if variant < 2 else 450) and lv[2] < (320 if variant < 2 else 450), (variant, lv)
+        for gid, which in ((N.GRID_PATH, 0), (N.GRID_GOAL, 1), (N.GRID_GOAL_FRONT, 2)):
+            assert np.array_equal(fl.download(gid, 0, 1)[0].astype(np.float64), p.grid(which)), (variant, which)
+        # a checked trajectory far faster than the limits leaves the box: the grids are completed first
+        for vs in ([3.0, 0.0, 0.0], [2.0, 0.3, 0.1], [0.2, 0.0, 0.0]):
+            assert fl.check_trajectory(0, vs) == p.check_trajectory(np.asarray(pos, np.float32), np.asarray(vel, np.float32), vs), (variant, vs)
+        fl.close()

@@ -24,8 +24,6 @@ d = en - st
 A = np.vstack([np.ones_like(lv), lv]).T
 coef = np.linalg.lstsq(A, d, rcond=None)[0]
 print("duration ~ %.1f us + %.3f us/level" % (coef[0], coef[1]))
-xcc = a[:, 5].astype(int) & 0xF
-print("WGs per XCC", np.bincount(xcc, minlength=8))
-for x in range(8):
-    m = xcc == x
-    print("xcc", x, "busy sum us", d[m].sum(), "last end", en[m].max())
+p1 = (a[:, 4] - t0) / 100.0
+p2 = (a[:, 5] - t0) / 100.0
+print("prologue mean us", (p1 - st).mean(), "levels mean us", (p2 - p1).mean(), "post+decode mean us", (en - p2).mean())
