@@ -103,8 +103,9 @@ struct PlannerDev {
   uint32_t* bfs_care;         // [n][kCareRows][kCareWords] box cells outside pockets, by region row and word from the region's first
   uint32_t* bfs_reach;        // [n] staged half edge of that box in cells, 0 = search the whole grid
   uint32_t bfs_bounded;       // launch switch: stop a wavefront once its robot's box is settled
-  unsigned long long* bfs_trace;  // TEMP debug
+  unsigned long long* bfs_trace;  // [items][8] wall-clock stamps of the phases of every wavefront (NAVGPU_DEBUG_BFS_TRACE=<file>, tools/trace_bfs.py), else null
   uint32_t* bfs_next_item;    // work counter of the persistent k_bfs_wave launch
+  uint32_t* bfs_free;         // [n][ny][W] traversable-cell bitmap of the costmaps (k_free_bits, per launch_bfs)
   uint32_t* bfs_levels;       // [n][3] levels the last wavefront of (robot, grid) ran: predicts the next one's length
   uint32_t* bfs_order;        // [n * 3] items of a launch sorted longest first, stored at first * 3 (k_samples)
   uint32_t bfs_grids;         // wavefronts per robot: 3 (DWA: path, goal, goal_front) or 2 (legacy TrajectoryPlanner)

@@ -166,6 +166,7 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   A(pl.bfs_care, (size_t)n * kCareRows * kCareWords);
   A(pl.bfs_reach, n);
   A(pl.bfs_next_item, 4);
+  A(pl.bfs_free, (size_t)n * cm.ny * ((cm.nx + 31) / 32));
   A(pl.bfs_levels, (size_t)n * 3);
   A(pl.bfs_order, (size_t)n * 3);
   pl.bfs_bounded = 0;
@@ -933,21 +934,21 @@ int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
   if (!f->planner_configured || !f->planner_staged) return NAVGPU_ERR_STATE;
   PlannerDev& pl = f->pl;
-  pl.bfs_bounded = getenv("NAVGPU_DEBUG_BFS_STOP") ? atoi(getenv("NAVGPU_DEBUG_BFS_STOP")) : 1;  // per robot: bfs_reach (0 = whole grid)
+  pl.bfs_bounded = 1;  // per robot: bfs_reach (0 = whole grid)
   for (uint32_t i = first; i < first + count; ++i) {
     f->grid_partial[i] = robotBox(f, i, f->hp_state[i].pos, f->hp_reach[i], &f->h_box[(size_t)4 * i]) ? 1 : 0;
     f->cycle_gen[i] = f->inputs_gen[i];
   }
   launch_samples(pl, first, count, f->stream);
-  if (getenv("NAVGPU_DEBUG_BFS_TRACE") && !pl.bfs_trace) f->alloc(&pl.bfs_trace, (size_t)f->desc.n_instances * 3 * 4);
+  if (getenv("NAVGPU_DEBUG_BFS_TRACE") && !pl.bfs_trace) f->alloc(&pl.bfs_trace, (size_t)f->desc.n_instances * 3 * 8);
   PROFILED(f, NAVGPU_K_BFS, launch_bfs(pl, first, count, f->stream, pl.bfs_order + (size_t)first * 3));
   if (pl.bfs_trace) {
-    std::vector<unsigned long long> h((size_t)count * 12);
+    std::vector<unsigned long long> h((size_t)count * 24);
     hipMemcpyAsync(h.data(), pl.bfs_trace, h.size() * 8, hipMemcpyDeviceToHost, f->stream);
     waitStream(f->stream);
     FILE* fp = fopen(getenv("NAVGPU_DEBUG_BFS_TRACE"), "w");
     for (size_t i = 0; i < (size_t)count * 3; ++i)
-      fprintf(fp, "%zu %llu %llu %llu %llu %llu\n", i, h[4 * i], h[4 * i + 1] & 0xFFFFFFFFFFFFull, h[4 * i + 1] >> 48, h[4 * i + 2], h[4 * i + 3]);
+      fprintf(fp, "%zu %llu %llu %llu %llu %llu %llu %llu %llu\n", i, h[8 * i], h[8 * i + 1] & 0xFFFFFFFFFFFFull, h[8 * i + 1] >> 48, h[8 * i + 2], h[8 * i + 3], h[8 * i + 4], h[8 * i + 5], h[8 * i + 6]);
     fclose(fp);
   }
   uint32_t n_blocks = 0;

@@ -28,60 +28,28 @@ __global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first) {
   const uint32_t tid = threadIdx.x;
   const navgpu_dwa_config& c = pl.cfg;
   const navgpu_robot_state st = pl.state[inst];
-  int32_t* cnt = pl.axis_count + 4 * inst;
-  if (tid < 3) {
-    const int a = tid;
-    const float vsamp = a == 0 ? (float)c.vx_samples : (a == 1 ? (float)c.vy_samples : (float)c.vth_samples);
-    const double max_vel_th = c.max_rot_vel, min_vel_th = -1.0 * max_vel_th;
-    double lim_min = a == 0 ? c.min_vel_x : (a == 1 ? c.min_vel_y : min_vel_th);
-    double lim_max = a == 0 ? c.max_vel_x : (a == 1 ? c.max_vel_y : max_vel_th);
-    const float acc = a == 0 ? (float)c.acc_lim_x : (a == 1 ? (float)c.acc_lim_y : (float)c.acc_lim_theta);
-    const float v = st.vel[a];
-    float maxv, minv;
-    if (!c.use_dwa) {
-      // goal = last pose of the plan narrowed to float (dwa_planner.cpp:305-306)
-      const double* P = pl.plan + (size_t)inst * pl.max_plan * 2;
-      const uint32_t np = pl.plan_count[inst];
-      const float gx = (float)P[2 * (np - 1)], gy = (float)P[2 * (np - 1) + 1];
-      double dist = hyp2((double)(gx - st.pos[0]), (double)(gy - st.pos[1]));
-      if (a < 2) lim_max = fmax(fmin(lim_max, dist / c.sim_time), lim_min);
-      maxv = (float)fmin(lim_max, v + acc * c.sim_time);
-      minv = (float)fmax(lim_min, v - acc * c.sim_time);
-    } else {
-      maxv = (float)fmin(lim_max, v + acc * c.sim_period);
-      minv = (float)fmax(lim_min, v - acc * c.sim_period);
+  // dispatch order of this launch's wavefronts (k_bfs_wave takes items off a counter): longest first, predicted by
+  // the level count of the robot's previous cycle.  item = g * count + robot, g = 0 goal_front, 1 goal, 2 path;
+  // every robot ranks its three items among all of them (count * 3 keys: a dozen loads per lane, issued before anything
+  // is stored so that they overlap the other loads of this kernel - its time is all memory latency)
+  uint32_t rank[3];
+  {
+    const uint32_t count = gridDim.x, total = 3 * count;
+    uint32_t key[3], before[3] = {0, 0, 0};
+#pragma unroll
+    for (uint32_t g = 0; g < 3; ++g) key[g] = pl.bfs_levels[(size_t)inst * 3 + (2 - g)];
+#pragma unroll 4
+    for (uint32_t j = tid; j < total; j += 64) {
+      const uint32_t gj = j / count, rj = j - gj * count;
+      const uint32_t kj = pl.bfs_levels[(size_t)(first + rj) * 3 + (2 - gj)];
+#pragma unroll
+      for (uint32_t g = 0; g < 3; ++g) before[g] += (kj > key[g] || (kj == key[g] && j < g * count + blockIdx.x)) ? 1u : 0u;
     }
-    float* out = pl.axis_samples + ((size_t)inst * 3 + a) * pl.max_axis;
-    const double mn = minv, mx = maxv;
-    int n = 0;
-    if (mn == mx) {
-      out[n++] = (float)mn;
-    } else {
-      int num_samples = (int)vsamp;
-      num_samples = num_samples > 2 ? num_samples : 2;
-      double step_size = (mx - mn) / double(num_samples - 1 > 1 ? num_samples - 1 : 1);
-      double current, next = mn;
-      for (int j = 0; j < num_samples - 1; ++j) {
-        current = next;
-        next += step_size;
-        if (n < (int)pl.max_axis) out[n] = (float)current;
-        ++n;
-        if ((current < 0) && (next > 0)) {
-          if (n < (int)pl.max_axis) out[n] = 0.0f;
-          ++n;
-        }
-      }
-      if (n < (int)pl.max_axis) out[n] = (float)mx;
-      ++n;
+#pragma unroll
+    for (uint32_t g = 0; g < 3; ++g) {
+      for (int o = 32; o > 0; o >>= 1) before[g] += __shfl_xor(before[g], o);
+      rank[g] = before[g];
     }
-    cnt[a] = n < (int)pl.max_axis ? n : (int)pl.max_axis;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float prod = (float)c.vx_samples * (float)c.vy_samples * (float)c.vth_samples;
-    cnt[3] = prod > 0 ? cnt[0] * cnt[1] * cnt[2] : 0;
-    pl.counters[2 * inst] = 0;
-    pl.counters[2 * inst + 1] = 0;
   }
   // Bounded wavefronts (k_bfs_wave).  The box = every cell a MapGrid look-up of this robot's samples can fall in: the
   // staged reach around the robot's cell.  The region = the box grown by two cells, clipped to the map.  A search may
@@ -184,24 +152,62 @@ __global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first) {
       b[4] = care_ok;
     }
   }
-  // dispatch order of this launch's wavefronts (k_bfs_wave takes items off a counter): longest first, predicted by
-  // the level count of the robot's previous cycle.  item = g * count + robot, g = 0 goal_front, 1 goal, 2 path;
-  // every robot ranks its three items among all of them (count * 3 keys: a few dozen loads per lane)
-  {
-    const uint32_t count = gridDim.x, total = 3 * count;
-    for (uint32_t g = 0; g < 3; ++g) {
-      const uint32_t i = g * count + blockIdx.x;
-      const uint32_t key = pl.bfs_levels[(size_t)inst * 3 + (2 - g)];
-      uint32_t before = 0;
-      for (uint32_t j = tid; j < total; j += 64) {
-        const uint32_t gj = j / count, rj = j - gj * count;
-        const uint32_t kj = pl.bfs_levels[(size_t)(first + rj) * 3 + (2 - gj)];
-        before += (kj > key || (kj == key && j < i)) ? 1u : 0u;
-      }
-      for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
-      if (tid == 0) pl.bfs_order[(size_t)first * 3 + before] = i;
+  int32_t* cnt = pl.axis_count + 4 * inst;
+  if (tid < 3) {
+    const int a = tid;
+    const float vsamp = a == 0 ? (float)c.vx_samples : (a == 1 ? (float)c.vy_samples : (float)c.vth_samples);
+    const double max_vel_th = c.max_rot_vel, min_vel_th = -1.0 * max_vel_th;
+    double lim_min = a == 0 ? c.min_vel_x : (a == 1 ? c.min_vel_y : min_vel_th);
+    double lim_max = a == 0 ? c.max_vel_x : (a == 1 ? c.max_vel_y : max_vel_th);
+    const float acc = a == 0 ? (float)c.acc_lim_x : (a == 1 ? (float)c.acc_lim_y : (float)c.acc_lim_theta);
+    const float v = st.vel[a];
+    float maxv, minv;
+    if (!c.use_dwa) {
+      // goal = last pose of the plan narrowed to float (dwa_planner.cpp:305-306)
+      const double* P = pl.plan + (size_t)inst * pl.max_plan * 2;
+      const uint32_t np = pl.plan_count[inst];
+      const float gx = (float)P[2 * (np - 1)], gy = (float)P[2 * (np - 1) + 1];
+      double dist = hyp2((double)(gx - st.pos[0]), (double)(gy - st.pos[1]));
+      if (a < 2) lim_max = fmax(fmin(lim_max, dist / c.sim_time), lim_min);
+      maxv = (float)fmin(lim_max, v + acc * c.sim_time);
+      minv = (float)fmax(lim_min, v - acc * c.sim_time);
+    } else {
+      maxv = (float)fmin(lim_max, v + acc * c.sim_period);
+      minv = (float)fmax(lim_min, v - acc * c.sim_period);
     }
+    float* out = pl.axis_samples + ((size_t)inst * 3 + a) * pl.max_axis;
+    const double mn = minv, mx = maxv;
+    int n = 0;
+    if (mn == mx) {
+      out[n++] = (float)mn;
+    } else {
+      int num_samples = (int)vsamp;
+      num_samples = num_samples > 2 ? num_samples : 2;
+      double step_size = (mx - mn) / double(num_samples - 1 > 1 ? num_samples - 1 : 1);
+      double current, next = mn;
+      for (int j = 0; j < num_samples - 1; ++j) {
+        current = next;
+        next += step_size;
+        if (n < (int)pl.max_axis) out[n] = (float)current;
+        ++n;
+        if ((current < 0) && (next > 0)) {
+          if (n < (int)pl.max_axis) out[n] = 0.0f;
+          ++n;
+        }
+      }
+      if (n < (int)pl.max_axis) out[n] = (float)mx;
+      ++n;
+    }
+    cnt[a] = n < (int)pl.max_axis ? n : (int)pl.max_axis;
   }
+  __syncthreads();
+  if (tid == 0) {
+    float prod = (float)c.vx_samples * (float)c.vy_samples * (float)c.vth_samples;
+    cnt[3] = prod > 0 ? cnt[0] * cnt[1] * cnt[2] : 0;
+    pl.counters[2 * inst] = 0;
+    pl.counters[2 * inst + 1] = 0;
+  }
+  if (tid < 3) pl.bfs_order[(size_t)first * 3 + (tid == 0 ? rank[0] : (tid == 1 ? rank[1] : rank[2]))] = tid * gridDim.x + blockIdx.x;
 }
 void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
   hipLaunchKernelGGL(k_samples, dim3(count), dim3(64), 0, s, pl, first);
@@ -553,21 +559,30 @@ __global__ __launch_bounds__(1024) void k_bfs(PlannerDev pl, uint32_t first) {
 // obstacleCosts()) are found once, after the sweep, as the obstacle neighbours of the expanded set.
 // ------------------------------------------------------------------------------------------------
 // free-cell bitmap word of one map row (bit b = cell wi*32+b is traversable)
+// four cost bytes -> four "obstacle" bits (LETHAL, INSCRIBED, and NO_INFORMATION unless unknown cells are allowed), SWAR
+__device__ __forceinline__ uint32_t bfsObstacleNibble(uint32_t v, uint32_t unknown_is_obstacle) {
+  const uint32_t low = v & 0x7F7F7F7Fu;
+  uint32_t m = (low + 0x03030303u) & v & 0x80808080u;                                  // byte >= 253
+  if (!unknown_is_obstacle) m &= ~((low + 0x01010101u) & v);                           // ... but not 255
+  m >>= 7;
+  return (m | (m >> 7) | (m >> 14) | (m >> 21)) & 0xFu;
+}
 __device__ __forceinline__ uint32_t bfsFreeWord(const uint8_t* master, uint32_t row, uint32_t nx, uint32_t wi,
                                                 uint32_t unknown_is_obstacle) {
   const uint32_t nb = min(32u, nx - wi * 32);
   uint32_t bits = 0;
+  if ((nx & 15) == 0 && nb == 32) {  // whole word, 16-byte aligned: two wide loads, all in flight together
+    const uint4* p = reinterpret_cast<const uint4*>(master + row * nx + wi * 32);
+    const uint4 a = p[0], b = p[1];
+    const uint32_t obst = bfsObstacleNibble(a.x, unknown_is_obstacle) | (bfsObstacleNibble(a.y, unknown_is_obstacle) << 4) |
+                          (bfsObstacleNibble(a.z, unknown_is_obstacle) << 8) | (bfsObstacleNibble(a.w, unknown_is_obstacle) << 12) |
+                          (bfsObstacleNibble(b.x, unknown_is_obstacle) << 16) | (bfsObstacleNibble(b.y, unknown_is_obstacle) << 20) |
+                          (bfsObstacleNibble(b.z, unknown_is_obstacle) << 24) | (bfsObstacleNibble(b.w, unknown_is_obstacle) << 28);
+    return ~obst;
+  }
   if ((nx & 3) == 0) {
     const uint32_t* p4 = reinterpret_cast<const uint32_t*>(master + row * nx + wi * 32);
-    for (uint32_t q = 0; q < nb / 4; ++q) {
-      const uint32_t v = p4[q];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t cst = (v >> (8 * j)) & 0xFFu;
-        const bool obstacle = cst == kLethal || cst == kInscribed || (cst == kNoInfo && unknown_is_obstacle);
-        bits |= (obstacle ? 0u : 1u) << (4 * q + j);
-      }
-    }
+    for (uint32_t q = 0; q < nb / 4; ++q) bits |= (bfsObstacleNibble(p4[q], unknown_is_obstacle) ^ 0xFu) << (4 * q);
   } else {
     const uint8_t* p = master + row * nx + wi * 32;
     for (uint32_t b = 0; b < nb; ++b) {
@@ -584,6 +599,18 @@ __device__ __forceinline__ uint32_t fromLaneBelow(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t fromLaneAbove(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+}
+
+// k_free_bits: the traversable-cell bitmap of every robot's costmap, [ny][W] words, once per launch for the two or three
+// wavefronts of a robot (each reads its rows twice).  Inside k_bfs_wave the same 160 KB of cost bytes took 14 wide loads
+// per lane that the register budget of the sweep serialises: 16 us per read, against 7 dword loads now.
+__global__ __launch_bounds__(256) void k_free_bits(PlannerDev pl, uint32_t first) {
+  const uint32_t W = (pl.nx + 31) >> 5, words = pl.ny * W;
+  const uint32_t inst = first + blockIdx.y;
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= words) return;
+  const uint32_t row = i / W, wi = i - row * W;
+  pl.bfs_free[(size_t)inst * words + i] = bfsFreeWord(pl.master + (size_t)inst * pl.cells_padded, row, pl.nx, wi, pl.cfg.allow_unknown != 0 ? 0u : 1u);
 }
 
 // LEGACY = the two-grid launch of the legacy TrajectoryPlanner with within_robot bits; the DWA instantiation
@@ -603,7 +630,7 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
   asm volatile("" : "+v"(tid_), "+s"(nx_), "+s"(ny_));
   const uint32_t tid = tid_;
   if (pl.bfs_trace && tid == 0) {
-    unsigned long long* t = pl.bfs_trace + (size_t)item * 4;
+    unsigned long long* t = pl.bfs_trace + (size_t)item * 8;
     t[0] = wall_clock64();
   }
   const Geom g = geomOf(pl, inst);
@@ -623,6 +650,7 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
   uint32_t* edge = sm + 2 * rows_p * W;
   const uint32_t edge_words = (strips + 2) * 2 * W;
   const uint8_t* master = pl.master + (size_t)inst * pl.cells_padded;
+  const uint32_t* freew = pl.bfs_free + (size_t)inst * ny * W;  // traversable-cell bitmap of the robot's costmap (k_free_bits)
   uint32_t* dist = (which == 0 ? pl.path : (which == 1 ? pl.goal : pl.goal_front)) + (size_t)inst * pl.cells;
   const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
   const uint32_t unknown_is_obstacle = pl.cfg.allow_unknown != 0 ? 0u : 1u;
@@ -633,6 +661,7 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
   for (uint32_t i = tid; i < 2 * rows_p * W + 2 * edge_words; i += blockDim.x) sm[i] = 0;
   if (tid < 3) s_flag[tid] = s_open[tid] = 0;
   __syncthreads();
+  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 8 + 4] = wall_clock64();
 
   // --- seeds from the plan (as k_bfs)
   {
@@ -683,6 +712,7 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
   }
   __syncthreads();
 
+  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 8 + 5] = wall_clock64();
   uint32_t blocked[RPT], fr[RPT];
   uint32_t plane[PL][RPT];
 #pragma unroll
@@ -696,7 +726,7 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
     const uint32_t row = r0 + k;
     if (owner && row < ny) {
       fr[k] = seedm[row * W + wi];  // seeds expand whatever their cost (map_grid.cpp:160-187)
-      blocked[k] = ~((bfsFreeWord(master, row, nx, wi, unknown_is_obstacle) | (LEGACY ? bfsWithinWord(pl, which, inst, row, W, wi) : 0u)) & col_mask) | fr[k];
+      blocked[k] = ~((freew[row * W + wi] | (LEGACY ? bfsWithinWord(pl, which, inst, row, W, wi) : 0u)) & col_mask) | fr[k];
     }
   }
   // edge rows of the frontier: E(buffer, strip s, first/last, wi); strip index shifted by one (zero border)
@@ -766,7 +796,7 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
   const bool wave_in_box = bounded && (int)(wave_id * spw * RPT) <= by1 && (int)((wave_id + 1) * spw * RPT) > by0;
 #pragma unroll
   for (int k = 0; k < RPT; ++k) had |= fr[k];
-  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 4 + 2] = wall_clock64();
+  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 8 + 2] = wall_clock64();
   while (true) {
     bool done = false;
     uint32_t code = 0;
@@ -847,7 +877,7 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
       enxt = t;
       ++level;
       if (group_end) {
-        done = !s_flag[group % 3] || (bounded && (!s_open[group % 3] || (pl.bfs_bounded >= 2 && level >= pl.bfs_bounded)));  // nothing new in a whole block of levels (or nothing open in the box): the search is over
+        done = !s_flag[group % 3] || (bounded && !s_open[group % 3]);  // nothing new in a whole block of levels (or nothing open in the box): the search is over
         ++group;
         any_grp = 0;
         if (done || code == kEpoch) break;
@@ -878,14 +908,14 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
     }
   }
 
-  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 4 + 3] = wall_clock64();
+  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 8 + 3] = wall_clock64();
   // --- expanded set = reached free cells + seeds; its obstacle neighbours were touched
   uint32_t ex[RPT], freeb[RPT];
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
     const uint32_t row = r0 + k;
     const bool in = owner && row < ny;
-    freeb[k] = in ? ((bfsFreeWord(master, row, nx, wi, unknown_is_obstacle) | (LEGACY ? bfsWithinWord(pl, which, inst, row, W, wi) : 0u)) & col_mask) : 0u;
+    freeb[k] = in ? ((freew[row * W + wi] | (LEGACY ? bfsWithinWord(pl, which, inst, row, W, wi) : 0u)) & col_mask) : 0u;
     ex[k] = in ? ((blocked[k] & freeb[k]) | seedm[row * W + wi]) : 0u;
   }
   if (owner) {
@@ -906,6 +936,7 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
       blocked[k] = nb & ~freeb[k] & ~fc & col_mask;  // reuse: the touched obstacle cells
     }
   }
+  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 8 + 6] = wall_clock64();
   // --- decode: expanded -> level (0 for seeds); touched obstacle -> obstacleCosts(); else unreachableCellCosts()
   uint32_t lt[RPT];
 #pragma unroll
@@ -1013,7 +1044,7 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
         if (!((lt[k] >> bpos) & 1u)) drow[bpos] = cellValue(pl10, ex[k], blocked[k], bpos);
     }
   }
-  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 4 + 1] = wall_clock64() | ((unsigned long long)level << 48);
+  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 8 + 1] = wall_clock64() | ((unsigned long long)level << 48);
   if (!LEGACY && tid == 0) pl.bfs_levels[(size_t)inst * 3 + which] = level;  // next cycle's dispatch order
 }
 // Persistent launch: one workgroup per CU takes (grid, robot) items off a counter until none is left.  The hardware
@@ -1326,6 +1357,7 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
   {                                                                                                                           \
     const size_t lds_w = bfs_wave_lds(pl.nx, pl.ny, R);                                                                       \
     if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<R, LEG, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); \
+    hipLaunchKernelGGL(k_free_bits, dim3((pl.ny * ((pl.nx + 31) / 32) + 255) / 256, count), dim3(256), 0, s, pl, first);       \
     hipMemsetAsync(pl.bfs_next_item, 0, sizeof(uint32_t), s);                                                                 \
     hipLaunchKernelGGL((k_bfs_wave<R, LEG, P>), dim3(std::min(count * pl.bfs_grids, bfs_cu_count())), dim3(1024), lds_w, s, pl, first, count, pl.bfs_next_item, order); \
     return;                                                                                                                   \

@@ -26,4 +26,6 @@ coef = np.linalg.lstsq(A, d, rcond=None)[0]
 print("duration ~ %.1f us + %.3f us/level" % (coef[0], coef[1]))
 p1 = (a[:, 4] - t0) / 100.0
 p2 = (a[:, 5] - t0) / 100.0
+z = (a[:, 6] - t0) / 100.0; sd = (a[:, 7] - t0) / 100.0; pp = (a[:, 8] - t0) / 100.0
+print("zero LDS", (z - st).mean(), "seeds", (sd - z).mean(), "free words + init", (p1 - sd).mean(), "post-pass", (pp - p2).mean(), "decode", (en - pp).mean())
 print("prologue mean us", (p1 - st).mean(), "levels mean us", (p2 - p1).mean(), "post+decode mean us", (en - p2).mean())
