@@ -1210,3 +1210,52 @@ def test_bounded_map_grids_pockets(nav, orc):
         for vs in ([3.0, 0.0, 0.0], [2.0, 0.3, 0.1], [0.2, 0.0, 0.0]):
             assert fl.check_trajectory(0, vs) == p.check_trajectory(np.asarray(pos, np.float32), np.asarray(vel, np.float32), vs), (variant, vs)
         fl.close()
+
+
+def test_bounded_map_grids_geometry(nav, orc):
+    """Bounded searches at the edges of what the pocket mask covers: a reach too long for it (plain region test), a robot in
+    the corner of the map (region clipped), a robot off the map (whole-grid search), a rectangular map."""
+    from navigation_amd import synth
+    N = L(nav)
+    res = synth.RES
+    rs = np.random.RandomState(11)
+    cases = [
+        # nx, ny, robot cell, config overrides, expect the searches to be bounded
+        (400, 400, (60, 200), dict(sim_time=3.4, sim_granularity=0.17, max_vel_x=0.9, max_trans_vel=0.9), True),   # reach ~ 70 cells: no pocket mask
+        (400, 400, (5, 6), dict(), None),                                                                            # corner: region clipped (and the last cells any search reaches)
+        (400, 400, (-20, 200), dict(), False),                                                                       # off the map
+        (416, 250, (40, 100), dict(), True),                                                                         # rectangular, ragged strips
+    ]
+    for nx, ny, (rx, ry), over, expect_bounded in cases:
+        m = np.zeros((ny, nx), np.uint8)
+        for _ in range(nx * ny // 1500):
+            cx, cy, r = rs.randint(0, nx), rs.randint(0, ny), rs.randint(1, 4)
+            m[max(0, cy - r):cy + r + 1, max(0, cx - r):cx + r + 1] = LETHAL
+        m[rs.random_sample(m.shape) < 0.003] = INSCRIBED  # single blocked cells: pockets between them are likely
+        m[max(0, ry - 3):ry + 4, max(0, rx - 3):max(0, rx + 4)] = 0
+        kw = dict(vx_samples=6, vy_samples=3, vth_samples=7, sim_time=1.7, sim_granularity=0.085, discretize_by_time=1)
+        kw.update(over)
+        cfg = nav.DwaConfig(**kw)
+        fl = nav.Fleet(1, nx, ny, res, layers=N.LAYER_OBSTACLE, keep_sample_costs=True, max_sim_steps=64, max_plan=256)
+        fl.configure_planner(cfg)
+        fl.set_footprint(synth.FOOTPRINT)
+        fl.upload(N.GRID_MASTER, m)
+        p = orc.DwaPlanner(m, res, 0.0, 0.0, orc.DwaConfig(**cfg.as_dict()))
+        fl.set_plan()
+        p.set_plan()
+        x0, y0 = (rx + 0.5) * res, (ry + 0.5) * res
+        plan = np.stack([np.linspace(max(x0, 0.3), (nx - 12) * res, 200), np.linspace(y0, (ny // 2) * res, 200)], 1)
+        pos, vel = [x0, y0, 0.1], [0.2, 0.0, 0.0]
+        _compare_cycle(fl, p, pos, vel, plan, synth.FOOTPRINT)
+        lv = fl.wavefront_levels()[0].astype(int)
+        for gid, which in ((N.GRID_PATH, 0), (N.GRID_GOAL, 1), (N.GRID_GOAL_FRONT, 2)):
+            og = p.grid(which)
+            assert np.array_equal(fl.download(gid, 0, 1)[0].astype(np.float64), og), (nx, ny, rx, ry, which)
+        full = [int(p.grid(w)[p.grid(w) < nx * ny].max()) for w in (0, 1, 2)]
+        if expect_bounded:
+            assert lv[1] < full[1] and lv[2] < full[2], (nx, ny, rx, ry, lv, full)
+        elif expect_bounded is None:
+            assert lv[0] < full[0] and all(lv[w] <= full[w] + 8 for w in range(3)), (lv, full)
+        else:
+            assert all(lv[w] >= full[w] for w in range(3)), (lv, full)
+        fl.close()
