@@ -941,7 +941,7 @@ int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
   }
   launch_samples(pl, first, count, f->stream);
   if (getenv("NAVGPU_DEBUG_BFS_TRACE") && !pl.bfs_trace) f->alloc(&pl.bfs_trace, (size_t)f->desc.n_instances * 3 * 8);
-  PROFILED(f, NAVGPU_K_BFS, launch_bfs(pl, first, count, f->stream, pl.bfs_order + (size_t)first * 3));
+  PROFILED(f, NAVGPU_K_BFS, launch_bfs(pl, first, count, f->stream, pl.bfs_order + (size_t)first * 3, true));
   if (pl.bfs_trace) {
     std::vector<unsigned long long> h((size_t)count * 24);
     hipMemcpyAsync(h.data(), pl.bfs_trace, h.size() * 8, hipMemcpyDeviceToHost, f->stream);

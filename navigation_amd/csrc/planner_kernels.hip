@@ -23,9 +23,20 @@ __device__ __forceinline__ Geom geomOf(const PlannerDev& pl, uint32_t inst) {
 // One lane per axis: `next += step_size` is a sequential fp64 accumulation and must stay one.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t bfsFreeWord(const uint8_t* master, uint32_t row, uint32_t nx, uint32_t wi, uint32_t unknown_is_obstacle);
-__global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first) {
-  const uint32_t inst = first + blockIdx.x;
+__global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first, uint32_t count) {
   const uint32_t tid = threadIdx.x;
+  if (blockIdx.x >= count) {
+    // the blocks behind the per-robot ones build the traversable-cell bitmaps of the launch (what k_free_bits does on its
+    // own for the other callers of launch_bfs): throughput work that fills the CUs while the per-robot waves wait on memory
+    const uint32_t W = (pl.nx + 31) >> 5, words = pl.ny * W, per = (words + 63) / 64;
+    const uint32_t b = blockIdx.x - count, r = b / per, i = (b - r * per) * 64 + tid;
+    if (i < words) {
+      const uint32_t row = i / W, wi = i - row * W;
+      pl.bfs_free[(size_t)(first + r) * words + i] = bfsFreeWord(pl.master + (size_t)(first + r) * pl.cells_padded, row, pl.nx, wi, pl.cfg.allow_unknown != 0 ? 0u : 1u);
+    }
+    return;
+  }
+  const uint32_t inst = first + blockIdx.x;
   const navgpu_dwa_config& c = pl.cfg;
   const navgpu_robot_state st = pl.state[inst];
   // dispatch order of this launch's wavefronts (k_bfs_wave takes items off a counter): longest first, predicted by
@@ -34,7 +45,7 @@ __global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first) {
   // is stored so that they overlap the other loads of this kernel - its time is all memory latency)
   uint32_t rank[3];
   {
-    const uint32_t count = gridDim.x, total = 3 * count;
+    const uint32_t total = 3 * count;
     uint32_t key[3], before[3] = {0, 0, 0};
 #pragma unroll
     for (uint32_t g = 0; g < 3; ++g) key[g] = pl.bfs_levels[(size_t)inst * 3 + (2 - g)];
@@ -207,10 +218,11 @@ __global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first) {
     pl.counters[2 * inst] = 0;
     pl.counters[2 * inst + 1] = 0;
   }
-  if (tid < 3) pl.bfs_order[(size_t)first * 3 + (tid == 0 ? rank[0] : (tid == 1 ? rank[1] : rank[2]))] = tid * gridDim.x + blockIdx.x;
+  if (tid < 3) pl.bfs_order[(size_t)first * 3 + (tid == 0 ? rank[0] : (tid == 1 ? rank[1] : rank[2]))] = tid * count + blockIdx.x;
 }
 void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
-  hipLaunchKernelGGL(k_samples, dim3(count), dim3(64), 0, s, pl, first);
+  const uint32_t words = pl.ny * ((pl.nx + 31) / 32);
+  hipLaunchKernelGGL(k_samples, dim3(count + count * ((words + 63) / 64)), dim3(64), 0, s, pl, first, count);  // + the bitmaps of launch_bfs(..., free_ready)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1342,7 +1354,7 @@ bool bfs_bounded_applies(const PlannerDev& pl) {
   if (force_lds_kernel || !bfs_lds_resident(pl.nx, pl.ny)) return false;
   return bfs_wave_fits(pl.nx, pl.ny, 7) || (bfs_wave_fits(pl.nx, pl.ny, 13) && bfs_wave_lds(pl.nx, pl.ny, 13) <= 156u * 1024u);
 }
-void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order) {
+void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order, bool free_ready) {
   dim3 grid(count, pl.bfs_grids);
   const size_t lds = bfs_lds_bytes(pl.nx, pl.ny);  // dense bit-parallel sweep (no LDS atomics in the loop)
   const int rpt = bfs_rows_per_thread(pl.nx, pl.ny);
@@ -1357,7 +1369,7 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
   {                                                                                                                           \
     const size_t lds_w = bfs_wave_lds(pl.nx, pl.ny, R);                                                                       \
     if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<R, LEG, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); \
-    hipLaunchKernelGGL(k_free_bits, dim3((pl.ny * ((pl.nx + 31) / 32) + 255) / 256, count), dim3(256), 0, s, pl, first);       \
+    if (!free_ready) hipLaunchKernelGGL(k_free_bits, dim3((pl.ny * ((pl.nx + 31) / 32) + 255) / 256, count), dim3(256), 0, s, pl, first); \
     hipMemsetAsync(pl.bfs_next_item, 0, sizeof(uint32_t), s);                                                                 \
     hipLaunchKernelGGL((k_bfs_wave<R, LEG, P>), dim3(std::min(count * pl.bfs_grids, bfs_cu_count())), dim3(1024), lds_w, s, pl, first, count, pl.bfs_next_item, order); \
     return;                                                                                                                   \
