@@ -65,11 +65,13 @@ __global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first, u
   // Bounded wavefronts (k_bfs_wave).  The box = every cell a MapGrid look-up of this robot's samples can fall in: the
   // staged reach around the robot's cell.  The region = the box grown by two cells, clipped to the map.  A search may
   // stop when (a) no cell of the box that it could still reach is open and (b) no frontier cell is inside the region.
-  // "Could still reach" leaves out the POCKETS: free cells of the region that no 4-connected chain of free cells joins
-  // to the region's rim (one cell enclosed by inflated obstacles is enough to keep a search going over the whole map
-  // otherwise).  A wavefront gets into a pocket only from a seed next to it, which (b) waits for.  The pockets are
-  // found here, once per robot for its three grids, by a bit-parallel flood from the rim: two region rows per lane,
-  // whole words filled along a row with an add-carry, neighbours rows by lane shuffles.
+  // "Could still reach" leaves out the POCKETS: free cells that no 4-connected chain of free cells joins to the rim of
+  // the area looked at (one cell enclosed by inflated obstacles is enough to keep a search going over the whole map
+  // otherwise).  A wavefront gets into a pocket only from a seed next to it, which (b) waits for - so the region has
+  // to contain every pocket that counts.  Two areas are flooded from their rims, bit-parallel, two rows per lane, whole
+  // words filled along a row with an add-carry, neighbour rows by lane shuffles: the region, and the largest area the
+  // mask can hold around it (128 rows x 4 words).  When the large one finds pockets in the box that the region alone
+  // does not (a pocket that straddles the region's rim), the large area becomes this robot's region.
   {
     int4 region = make_int4(0, -1, 0, -1);
     int care_ok = 0;
@@ -77,79 +79,105 @@ __global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first, u
     const Geom g = geomOf(pl, inst);
     uint32_t mx = 0, my = 0;
     if (reach && worldToMap(g, (double)st.pos[0], (double)st.pos[1], mx, my)) {
-      const int R = (int)reach + 2;
+      const int R = (int)reach + 2, nxi = (int)pl.nx, nyi = (int)pl.ny, Wm = (nxi + 31) >> 5;
       region.x = max((int)mx - R, 0);
-      region.y = min((int)mx + R, (int)pl.nx - 1);
+      region.y = min((int)mx + R, nxi - 1);
       region.z = max((int)my - R, 0);
-      region.w = min((int)my + R, (int)pl.ny - 1);
+      region.w = min((int)my + R, nyi - 1);
       const int rows = region.w - region.z + 1, wx0 = region.x >> 5, nw = (region.y >> 5) - wx0 + 1;
       if (rows <= kCareRows && nw <= kCareWords) {
         const uint8_t* master = pl.master + (size_t)inst * pl.cells_padded;
         const uint32_t unknown_is_obstacle = pl.cfg.allow_unknown != 0 ? 0u : 1u;
-        const int bx0 = max((int)mx - (int)reach, 0), bx1 = min((int)mx + (int)reach, (int)pl.nx - 1);
-        const int by0 = max((int)my - (int)reach, 0), by1 = min((int)my + (int)reach, (int)pl.ny - 1);
-        auto colMask = [&](int w, int x0, int x1) -> uint32_t {  // bits of word wx0 + w inside [x0, x1]
-          const int lo = max(x0 - (wx0 + w) * 32, 0), hi = min(x1 - (wx0 + w) * 32, 31);
+        const int bx0 = max((int)mx - (int)reach, 0), bx1 = min((int)mx + (int)reach, nxi - 1);
+        const int by0 = max((int)my - (int)reach, 0), by1 = min((int)my + (int)reach, nyi - 1);
+        // the large area: kCareRows rows and kCareWords words around the region (it contains the region)
+        const int fy0 = max(min((int)my - kCareRows / 2, nyi - kCareRows), 0), fy1 = min(fy0 + kCareRows - 1, nyi - 1);
+        const int fw0 = max(min(wx0 - (kCareWords - nw) / 2, Wm - kCareWords), 0), fw1 = min(fw0 + kCareWords - 1, Wm - 1);
+        const int fx0 = fw0 * 32, fx1 = min(fw1 * 32 + 31, nxi - 1);
+        auto colMask = [&](int w, int x0, int x1) -> uint32_t {  // bits of word fw0 + w inside [x0, x1]
+          const int lo = max(x0 - (fw0 + w) * 32, 0), hi = min(x1 - (fw0 + w) * 32, 31);
           return hi >= lo ? ((0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo)) : 0u;
         };
-        uint32_t fm[2][kCareWords], F[2][kCareWords];
+        uint32_t fmL[2][kCareWords], fmR[2][kCareWords], FL[2][kCareWords], FR[2][kCareWords];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int rr = 2 * (int)tid + h, row = region.z + rr;
+          const int row = fy0 + 2 * (int)tid + h;
+          const bool in_r = row >= region.z && row <= region.w;
 #pragma unroll
           for (int w = 0; w < kCareWords; ++w) {
-            fm[h][w] = 0;
-            F[h][w] = 0;
-            if (rr < rows && w < nw) {
-              const uint32_t cm = colMask(w, region.x, region.y);
-              fm[h][w] = bfsFreeWord(master, (uint32_t)row, pl.nx, (uint32_t)(wx0 + w), unknown_is_obstacle) & cm;
-              const uint32_t rim = (rr == 0 || rr == rows - 1) ? cm : (colMask(w, region.x, region.x) | colMask(w, region.y, region.y));
-              F[h][w] = fm[h][w] & rim;
+            fmL[h][w] = fmR[h][w] = FL[h][w] = FR[h][w] = 0;
+            if (row <= fy1 && fw0 + w <= fw1) {
+              const uint32_t cmL = colMask(w, fx0, fx1), cmR = in_r ? colMask(w, region.x, region.y) : 0u;
+              const uint32_t fw_ = bfsFreeWord(master, (uint32_t)row, pl.nx, (uint32_t)(fw0 + w), unknown_is_obstacle);
+              fmL[h][w] = fw_ & cmL;
+              fmR[h][w] = fw_ & cmR;
+              const uint32_t rimL = (row == fy0 || row == fy1) ? cmL : (colMask(w, fx0, fx0) | colMask(w, fx1, fx1));
+              const uint32_t rimR = (row == region.z || row == region.w) ? cmR : (colMask(w, region.x, region.x) | colMask(w, region.y, region.y));
+              FL[h][w] = fmL[h][w] & rimL;
+              FR[h][w] = fmR[h][w] & rimR;
             }
           }
         }
-        bool settled = false;
-        for (int it = 0; it < 256 && !settled; ++it) {
-          uint32_t changed = 0;
+        auto flood = [&](uint32_t (&F)[2][kCareWords], const uint32_t (&fm)[2][kCareWords]) -> bool {
+          for (int it = 0; it < 256; ++it) {
+            uint32_t changed = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+              for (int w = 0; w < kCareWords; ++w) {
+                uint32_t up, dn;
+                if (h == 0) {
+                  up = __shfl_up(F[1][w], 1);
+                  if (tid == 0) up = 0;
+                  dn = F[1][w];
+                } else {
+                  up = F[0][w];
+                  dn = __shfl_down(F[0][w], 1);
+                  if (tid == 63) dn = 0;
+                }
+                const uint32_t cur = F[h][w], f = fm[h][w];
+                uint32_t n = cur | up | dn | (cur << 1) | (cur >> 1);
+                if (w > 0) n |= F[h][w - 1] >> 31;
+                if (w + 1 < kCareWords) n |= F[h][w + 1] << 31;
+                n &= f;
+                // fill the runs of free cells the set bits lie in: towards bit 31 with an add-carry, towards bit 0 mirrored
+                n |= f & ~(f + n);
+                const uint32_t fr_ = __brev(f), nr = __brev(n);
+                n |= __brev(fr_ & ~(fr_ + nr));
+                changed |= n ^ cur;
+                F[h][w] = n;
+              }
+            }
+            if (__builtin_amdgcn_ballot_w64(changed != 0) == 0) return true;
+          }
+          return false;
+        };
+        const bool okR = flood(FR, fmR), okL = flood(FL, fmL);
+        care_ok = okR ? 1 : 0;  // not settled within the bound: no pocket is left out (the search is exact either way)
+        // pockets of the box that only the large area shows -> the large area is the region
+        uint32_t extra = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = fy0 + 2 * (int)tid + h;
+#pragma unroll
+          for (int w = 0; w < kCareWords; ++w)
+            if (row >= by0 && row <= by1) extra |= ((fmL[h][w] & ~FL[h][w]) ^ (fmR[h][w] & ~FR[h][w])) & colMask(w, bx0, bx1);
+        }
+        const bool large = okR && okL && __builtin_amdgcn_ballot_w64(extra != 0) != 0;
+        if (large) region = make_int4(fx0, fx1, fy0, fy1);
+        if (okR) {
+          const int ry0 = region.z, rw0 = region.x >> 5;
+          uint32_t* care = pl.bfs_care + (size_t)inst * kCareRows * kCareWords;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
+            const int row = fy0 + 2 * (int)tid + h, rr = row - ry0;
 #pragma unroll
             for (int w = 0; w < kCareWords; ++w) {
-              uint32_t up, dn;
-              if (h == 0) {
-                up = __shfl_up(F[1][w], 1);
-                if (tid == 0) up = 0;
-                dn = F[1][w];
-              } else {
-                up = F[0][w];
-                dn = __shfl_down(F[0][w], 1);
-                if (tid == 63) dn = 0;
-              }
-              const uint32_t cur = F[h][w], f = fm[h][w];
-              uint32_t n = cur | up | dn | (cur << 1) | (cur >> 1);
-              if (w > 0) n |= F[h][w - 1] >> 31;
-              if (w + 1 < kCareWords) n |= F[h][w + 1] << 31;
-              n &= f;
-              // fill the runs of free cells the set bits lie in: towards bit 31 with an add-carry, towards bit 0 mirrored
-              n |= f & ~(f + n);
-              const uint32_t fr_ = __brev(f), nr = __brev(n);
-              n |= __brev(fr_ & ~(fr_ + nr));
-              changed |= n ^ cur;
-              F[h][w] = n;
+              const int ww = fw0 + w - rw0;
+              if (rr < 0 || rr >= kCareRows || row > region.w || ww < 0 || ww >= kCareWords) continue;
+              const uint32_t pocket = large ? (fmL[h][w] & ~FL[h][w]) : (fmR[h][w] & ~FR[h][w]);
+              care[rr * kCareWords + ww] = (row >= by0 && row <= by1) ? (colMask(w, bx0, bx1) & ~pocket) : 0u;
             }
-          }
-          settled = __builtin_amdgcn_ballot_w64(changed != 0) == 0;
-        }
-        care_ok = settled ? 1 : 0;  // not settled within the bound: no pocket is left out (the search is exact either way)
-        uint32_t* care = pl.bfs_care + (size_t)inst * kCareRows * kCareWords;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int rr = 2 * (int)tid + h, row = region.z + rr;
-#pragma unroll
-          for (int w = 0; w < kCareWords; ++w) {
-            uint32_t cw = 0;
-            if (rr < rows && w < nw && row >= by0 && row <= by1) cw = colMask(w, bx0, bx1) & ~(fm[h][w] & ~F[h][w]);
-            care[rr * kCareWords + w] = cw;
           }
         }
       }
@@ -1118,16 +1146,10 @@ __global__ __launch_bounds__(1024) void k_bfs_global(PlannerDev pl, uint32_t fir
   const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
   const uint32_t unknown_is_obstacle = pl.cfg.allow_unknown != 0 ? 0u : 1u;
   const uint32_t last_mask = (nx & 31) ? ((1u << (nx & 31)) - 1u) : 0xFFFFFFFFu;
+  const uint32_t* freew = pl.bfs_free + (size_t)inst * words;  // k_free_bits (or the extra blocks of k_samples)
   for (uint32_t w = tid; w < words; w += blockDim.x) {
     const uint32_t row = w / W, wi = w - row * W;
-    const uint8_t* p = master + row * nx + wi * 32;
-    const uint32_t nb = min(32u, nx - wi * 32);
-    uint32_t bits = 0;
-    for (uint32_t b = 0; b < nb; ++b) {
-      const uint32_t cst = p[b];
-      const bool obstacle = cst == kLethal || cst == kInscribed || (cst == kNoInfo && unknown_is_obstacle);
-      bits |= (obstacle ? 0u : 1u) << b;
-    }
+    const uint32_t bits = freew[w] & ((wi + 1 == W) ? last_mask : 0xFFFFFFFFu);
     fre[w] = bits | (bfsWithinWord(pl, which, inst, row, W, wi) & ((wi + 1 == W) ? last_mask : 0xFFFFFFFFu));
     vis[w] = (wi + 1 == W) ? ~last_mask : 0u;
     cur[w] = 0;
@@ -1201,6 +1223,20 @@ __global__ __launch_bounds__(1024) void k_bfs_global(PlannerDev pl, uint32_t fir
   const uint32_t lane = tid & 63u, wave = tid >> 6;
   const uint32_t lr = lane >> 2, lc = lane & 3u;
   uint32_t level = 0, buf = 0;  // buf: which flag set belongs to `cur`
+  // bounded search (see k_bfs_wave): the robot's region, its pocket mask, and the words of the bitmaps that cover it
+  int gx0 = 0, gx1 = -1, gy0 = 0, gy1 = -1, care_ok = 0;
+  if (pl.bfs_bounded && pl.bfs_grids == 3) {
+    const int* bb = pl.bfs_box + (size_t)inst * 8;
+    gx0 = bb[0];
+    gx1 = bb[1];
+    gy0 = bb[2];
+    gy1 = bb[3];
+    care_ok = bb[4];
+  }
+  const bool bounded = gx1 >= gx0 && gy1 >= gy0;
+  const uint32_t rg_w0 = (uint32_t)(gx0 >> 5), rg_nw = bounded ? (uint32_t)(gx1 >> 5) - rg_w0 + 1 : 0u;
+  const uint32_t rg_words = bounded ? (uint32_t)(gy1 - gy0 + 1) * rg_nw : 0u;
+  const uint32_t* care = pl.bfs_care + (size_t)inst * kCareRows * kCareWords;
   while (true) {
     int any = 0;
     uint8_t* act_cur = act + buf * kMaxTiles;
@@ -1301,8 +1337,22 @@ __global__ __launch_bounds__(1024) void k_bfs_global(PlannerDev pl, uint32_t fir
     nxt = t;
     buf ^= 1u;
     ++level;
+    if (bounded && (level & 7u) == 0) {  // stop once no cell of the box is open and no frontier cell is in the region
+      int open = 0;
+      for (uint32_t i = tid; i < rg_words; i += blockDim.x) {
+        const uint32_t rr = i / rg_nw, ww = i - rr * rg_nw, wi = rg_w0 + ww, w = ((uint32_t)gy0 + rr) * W + wi;
+        const int c_lo = max(gx0 - (int)(wi * 32), 0), c_hi = min(gx1 - (int)(wi * 32), 31);
+        const uint32_t cm = (0xFFFFFFFFu >> (31 - c_hi)) & (0xFFFFFFFFu << c_lo);
+        const uint32_t cw = care_ok ? (ww < (uint32_t)kCareWords ? care[rr * kCareWords + ww] : 0u) : 0xFFFFFFFFu;
+        if ((((~vis[w] & fre[w] & cw) | cur[w]) & cm) != 0) open = 1;
+      }
+      if (!__syncthreads_or(open)) break;
+    }
   }
-  for (uint32_t w = tid; w < words; w += blockDim.x) {
+  if (tid == 0 && pl.bfs_grids == 3) pl.bfs_levels[(size_t)inst * 3 + which] = level;
+  // (a bounded search is only ever read inside its region: the rest of the grid is left as it is)
+  for (uint32_t i = tid; i < (bounded ? rg_words : words); i += blockDim.x) {
+    const uint32_t w = bounded ? ((uint32_t)gy0 + i / rg_nw) * W + rg_w0 + (i - (i / rg_nw) * rg_nw) : i;
     uint32_t t = ~vis[w];
     if (t) {
       const uint32_t row = w / W, wi = w - row * W;
@@ -1351,7 +1401,8 @@ static uint32_t bfs_cu_count() {
 }
 bool bfs_bounded_applies(const PlannerDev& pl) {
   static const bool force_lds_kernel = getenv("NAVGPU_DEBUG_BFS_LDS") != nullptr;
-  if (force_lds_kernel || !bfs_lds_resident(pl.nx, pl.ny)) return false;
+  if (!bfs_lds_resident(pl.nx, pl.ny)) return true;  // k_bfs_global
+  if (force_lds_kernel) return false;
   return bfs_wave_fits(pl.nx, pl.ny, 7) || (bfs_wave_fits(pl.nx, pl.ny, 13) && bfs_wave_lds(pl.nx, pl.ny, 13) <= 156u * 1024u);
 }
 void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order, bool free_ready) {
@@ -1390,6 +1441,7 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
 #undef NAVGPU_BFS
     return;
   }
+  if (!free_ready) hipLaunchKernelGGL(k_free_bits, dim3((pl.ny * ((pl.nx + 31) / 32) + 255) / 256, count), dim3(256), 0, s, pl, first);
   hipLaunchKernelGGL(k_bfs_global, grid, dim3(1024), 0, s, pl, first, pl.bfs_scratch);
 }
 

@@ -1185,12 +1185,14 @@ def test_bounded_map_grids_pockets(nav, orc):
     res = synth.RES
     cfg_kw = dict(vx_samples=9, vy_samples=7, vth_samples=9, sim_time=1.7, sim_granularity=0.085, discretize_by_time=1, max_vel_y=0.3, min_vel_y=-0.3)
     rx, ry = 60, 120  # robot cell
-    for variant in range(3):
+    for variant in range(5):
         m = np.zeros((n, n), np.uint8)
-        # ring of lethal cells around a free 5 x 5 interior, 12 cells ahead of the robot; variant 1 puts the plan through it
-        cx, cy = rx + 12, ry + (0 if variant == 1 else 9)
-        m[cy - 4:cy + 5, cx - 4:cx + 5] = LETHAL
-        m[cy - 2:cy + 3, cx - 2:cx + 3] = 0
+        # ring of lethal cells around a free 5 x 5 interior, 12 cells ahead of the robot; variant 1 puts the plan through it;
+        # variants 3 and 4: a larger ring that straddles the rim of the robot's region (box = +-30 cells), off / on the plan
+        cx, cy = rx + (12 if variant < 3 else 33), ry + (0 if variant in (1, 4) else 9)
+        h = 4 if variant < 3 else 7
+        m[cy - h:cy + h + 1, cx - h:cx + h + 1] = LETHAL
+        m[cy - h + 2:cy + h - 1, cx - h + 2:cx + h - 1] = 0
         if variant == 2:  # a one-cell pocket next to the robot and a long wall that forces a detour of the goal wavefront
             m[ry - 3:ry, rx + 3:rx + 6] = INSCRIBED
             m[ry - 2, rx + 4] = 0
@@ -1203,7 +1205,8 @@ def test_bounded_map_grids_pockets(nav, orc):
         _compare_cycle(fl, p, pos, vel, plan, synth.FOOTPRINT)
         lv = fl.wavefront_levels()[0]
         # none of them ran over the whole 240 x 240 map (path > 230 levels, goal > 330, behind the wall of variant 2 > 500)
-        assert lv[0] < 120 and lv[1] < (320 if variant < 2 else 450) and lv[2] < (320 if variant < 2 else 450), (variant, lv)
+        # (variants 3, 4: the region is the large area, which the frontier takes longer to leave)
+        assert lv[0] < (120 if variant < 3 else 200) and lv[1] < (320 if variant != 2 else 450) and lv[2] < (320 if variant != 2 else 450), (variant, lv)
         for gid, which in ((N.GRID_PATH, 0), (N.GRID_GOAL, 1), (N.GRID_GOAL_FRONT, 2)):
             assert np.array_equal(fl.download(gid, 0, 1)[0].astype(np.float64), p.grid(which)), (variant, which)
         # a checked trajectory far faster than the limits leaves the box: the grids are completed first
