@@ -805,10 +805,29 @@ extern "C++" int navgpu::ensureCompleteGrids(navgpu_fleet* f, uint32_t first, ui
   return checkLaunch();
 }
 
+// the staged reach depends on the configuration: a reconfigure (or the switch below) between stage and cycle re-derives it
+static int restageReach(navgpu_fleet* f) {
+  if (!f->planner_staged) return NAVGPU_OK;
+  PlannerDev& pl = f->pl;
+  HIP_TRY(waitStream(f->stream));
+  const uint32_t n = f->desc.n_instances;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t np = f->hp_plan_cnt[i];
+    if (!np) {  // never staged
+      f->hp_reach[i] = 0;
+      continue;
+    }
+    const double* last = &f->hp_plan[((size_t)i * pl.max_plan + np - 1) * 2];
+    f->hp_reach[i] = bfsReachCells(f, f->hp_state[i], last[0], last[1]);
+  }
+  HIP_TRY(hipMemcpyAsync(pl.bfs_reach, f->hp_reach, sizeof(uint32_t) * n, hipMemcpyHostToDevice, f->stream));
+  return NAVGPU_OK;
+}
+
 int navgpu_planner_set_bounded_map_grids(navgpu_fleet* f, int32_t enable) {
   if (!f) return NAVGPU_ERR_INVALID;
   f->bounded_grids = enable != 0;
-  return NAVGPU_OK;
+  return restageReach(f);
 }
 int navgpu_planner_wavefront_levels(navgpu_fleet* f, uint32_t first, uint32_t count, uint32_t* levels) {
   if (!f || !levels || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
@@ -880,6 +899,7 @@ int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
   {
     int rc = ensurePrep(f);
     if (rc != NAVGPU_OK) return rc;
+    if ((rc = restageReach(f)) != NAVGPU_OK) return rc;  // new limits, new boxes
   }
   HIP_TRY(waitStream(f->stream));
   return NAVGPU_OK;

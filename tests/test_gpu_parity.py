@@ -1262,3 +1262,34 @@ def test_bounded_map_grids_geometry(nav, orc):
         else:
             assert all(lv[w] >= full[w] for w in range(3)), (lv, full)
         fl.close()
+
+
+def test_bounded_map_grids_reconfigure_between_stage_and_cycle(nav, orc):
+    """DWAPlanner::reconfigure may come between staging and the cycle: the box of the bounded searches follows the new limits."""
+    from navigation_amd import synth
+    N = L(nav)
+    n = 400
+    ins = _inflated_instance(orc, n, 7, synth)
+    slow = dict(vx_samples=7, vy_samples=3, vth_samples=7, sim_time=1.0, sim_granularity=0.1, discretize_by_time=1, max_vel_x=0.2, max_trans_vel=0.2)
+    fast = dict(slow, sim_time=2.5, sim_granularity=0.125, max_vel_x=1.2, max_trans_vel=1.2, acc_lim_x=30.0)
+    fl = nav.Fleet(1, n, n, synth.RES, layers=N.LAYER_OBSTACLE, keep_sample_costs=True, max_sim_steps=64, max_plan=256)
+    fl.configure_planner(nav.DwaConfig(**slow))
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.upload(N.GRID_MASTER, ins["master"])
+    fl.set_plan()
+    pos, vel = ins["pos"].copy(), np.array([0.2, 0.0, 0.0], np.float32)
+    fl.stage_planner([pos], [vel], [ins["plan"]])
+    cfg = nav.DwaConfig(**fast)
+    fl.configure_planner(cfg)   # after the stage: reach 6 cells -> 66 cells
+    fl.planner_cycle()
+    r = fl.results()[0]
+    cost, status, _ = fl.samples(0)
+    p = orc.DwaPlanner(ins["master"], synth.RES, 0.0, 0.0, orc.DwaConfig(**cfg.as_dict()))
+    p.set_plan()
+    o, _, _, cfull, ost = p.cycle(pos, vel, ins["plan"], synth.FOOTPRINT)
+    assert np.array_equal(status, ost)
+    sc = status == 1
+    assert np.array_equal(cost[sc] < 0, cfull[sc] < 0) and np.array_equal(cost[sc][cost[sc] < 0], cfull[sc][cfull[sc] < 0])
+    assert np.allclose(cost[sc][cost[sc] >= 0], cfull[sc][cfull[sc] >= 0], rtol=0, atol=1e-5)
+    assert (r.best_index, r.n_valid) == (o.best_index, o.n_valid)
+    fl.close()
