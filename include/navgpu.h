@@ -489,6 +489,9 @@ typedef enum {
  * listed kernels is bracketed by two hipEventRecord calls; read() synchronises and returns the
  * accumulated device time (ms) and launch count since the last reset. */
 int navgpu_profile_enable(navgpu_fleet* fleet, int32_t enable);
+/* restrict the bracketing to some kernels: bit k = navgpu_kernel_id k (default: all).  Every pair of events costs the
+ * stream a few microseconds, so a throughput measurement selects the kernel it reports on. */
+int navgpu_profile_select(navgpu_fleet* fleet, uint32_t kernel_mask);
 int navgpu_profile_reset(navgpu_fleet* fleet);
 int navgpu_profile_read(navgpu_fleet* fleet, int32_t kernel, double* total_ms, uint64_t* launches);
 const char* navgpu_kernel_name(int32_t kernel);

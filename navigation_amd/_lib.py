@@ -227,6 +227,7 @@ SYMBOLS = [
     ("navgpu_footprint_from_radius", C.c_int, [dbl, vp]),
     ("navgpu_costmap_export", C.c_int, [vp, u32, u32, u32, u32, u32, vp]),
     ("navgpu_profile_enable", C.c_int, [vp, i32]),
+    ("navgpu_profile_select", C.c_int, [vp, u32]),
     ("navgpu_profile_reset", C.c_int, [vp]),
     ("navgpu_profile_read", C.c_int, [vp, i32, C.POINTER(dbl), C.POINTER(C.c_uint64)]),
     ("navgpu_kernel_name", C.c_char_p, [i32]),

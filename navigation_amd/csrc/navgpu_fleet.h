@@ -108,6 +108,7 @@ struct navgpu_fleet {
   float4* d_cell_costs = nullptr;                // [cells] navgpu_planner_cost_cloud
   // profiling
   bool profiling = false;
+  uint32_t prof_mask = ~0u;                     // kernels bracketed by events while profiling (navgpu_profile_select)
   std::vector<EventPair> events;
   std::vector<EventPair> free_events;
   double prof_ms[NAVGPU_K_COUNT] = {0};
@@ -153,7 +154,7 @@ struct navgpu_fleet {
   bool rangeOk(uint32_t first, uint32_t count) const { return count > 0 && first < desc.n_instances && count <= desc.n_instances - first; }
 
   int beginKernel(int k, EventPair* ep) {
-    if (!profiling) return NAVGPU_OK;
+    if (!profiling || !((prof_mask >> k) & 1u)) return NAVGPU_OK;
     if (free_events.empty()) {
       EventPair n{};
       HIP_TRY(hipEventCreate(&n.a));
@@ -167,7 +168,7 @@ struct navgpu_fleet {
     return NAVGPU_OK;
   }
   int endKernel(EventPair* ep) {
-    if (!profiling) return NAVGPU_OK;
+    if (!profiling || !ep->a) return NAVGPU_OK;  // (not one of the selected kernels)
     HIP_TRY(hipEventRecord(ep->b, stream));
     events.push_back(*ep);
     if (events.size() > 8192) return foldEvents();

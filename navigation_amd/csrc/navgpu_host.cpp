@@ -1123,6 +1123,11 @@ int navgpu_profile_enable(navgpu_fleet* f, int32_t enable) {
   f->profiling = enable != 0;
   return NAVGPU_OK;
 }
+int navgpu_profile_select(navgpu_fleet* f, uint32_t kernel_mask) {
+  if (!f) return NAVGPU_ERR_INVALID;
+  f->prof_mask = kernel_mask;
+  return NAVGPU_OK;
+}
 int navgpu_profile_reset(navgpu_fleet* f) {
   if (!f) return NAVGPU_ERR_INVALID;
   int rc = f->foldEvents();

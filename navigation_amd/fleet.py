@@ -389,6 +389,11 @@ class Fleet:
     def profile_reset(self):
         check(self.L.navgpu_profile_reset(self.h), "profile_reset")
 
+    def profile_select(self, names=None):
+        """Bracket only the named kernels with events while profiling (None = all)."""
+        mask = 0xFFFFFFFF if names is None else sum(1 << N.KERNELS.index(k) for k in names)
+        check(self.L.navgpu_profile_select(self.h, mask), "profile_select")
+
     def profile_read(self):
         out = {}
         for k, name in enumerate(N.KERNELS):
