@@ -1293,3 +1293,71 @@ def test_bounded_map_grids_reconfigure_between_stage_and_cycle(nav, orc):
     assert np.allclose(cost[sc][cost[sc] >= 0], cfull[sc][cfull[sc] >= 0], rtol=0, atol=1e-5)
     assert (r.best_index, r.n_valid) == (o.best_index, o.n_valid)
     fl.close()
+
+
+def test_bounded_map_grids_random_stress(nav, orc):
+    """Seeded random clutter, poses, velocities, limits and plans (some through obstacles, some ending near the robot): the
+    bounded and the whole-grid searches must give every sample the same cost, and the completed grids must be equal."""
+    from navigation_amd import synth
+    N = L(nav)
+    res = synth.RES
+    rs = np.random.RandomState(2024)
+    n_inst = 8
+    shorter = total = 0
+    for rnd in range(40):
+        n = int(rs.choice([160, 250, 400]))
+        masters = np.zeros((n_inst, n, n), np.uint8)
+        pos, vel, plans = [], [], []
+        for k in range(n_inst):
+            m = masters[k]
+            for _ in range(rs.randint(5, 60)):   # blobs and thin walls, inscribed halo around some
+                cx, cy = rs.randint(0, n, 2)
+                if rs.rand() < 0.5:
+                    r = rs.randint(1, 6)
+                    m[max(0, cy - r - 1):cy + r + 2, max(0, cx - r - 1):cx + r + 2] = np.maximum(m[max(0, cy - r - 1):cy + r + 2, max(0, cx - r - 1):cx + r + 2], INSCRIBED)
+                    m[max(0, cy - r):cy + r + 1, max(0, cx - r):cx + r + 1] = LETHAL
+                else:
+                    ln = rs.randint(5, 60)
+                    if rs.rand() < 0.5:
+                        m[cy, cx:cx + ln] = LETHAL
+                    else:
+                        m[cy:cy + ln, cx] = LETHAL
+            m[rs.random_sample(m.shape) < rs.choice([0.0, 0.002, 0.02])] = INSCRIBED
+            m[(rs.random_sample(m.shape) < rs.choice([0.0, 0.01])) & (m == 0)] = NOINFO
+            rx, ry = rs.randint(3, n - 3, 2)
+            m[ry - 2:ry + 3, rx - 2:rx + 3] = 0
+            pos.append([(rx + rs.rand()) * res, (ry + rs.rand()) * res, rs.uniform(-3.1, 3.1)])
+            vel.append([rs.uniform(-0.1, 0.6), rs.uniform(-0.1, 0.1), rs.uniform(-1, 1)])
+            gx, gy = rs.uniform(0.05, 0.95, 2) * n * res
+            if rs.rand() < 0.15:  # a goal close to the robot: whole-grid search by rule
+                gx, gy = pos[-1][0] + rs.uniform(-1, 1), pos[-1][1] + rs.uniform(-1, 1)
+            t = np.linspace(0, 1, 120)[:, None]
+            plans.append(np.clip(np.array(pos[-1][:2]) * (1 - t) + np.array([gx, gy]) * t + 0.3 * np.sin(6 * t) * rs.uniform(-1, 1, 2), 0.01, n * res - 0.01))
+        cfg = nav.DwaConfig(vx_samples=6, vy_samples=3, vth_samples=7, sim_time=float(rs.choice([1.0, 1.7, 2.5])), sim_granularity=0.1,
+                            discretize_by_time=int(rs.rand() < 0.7), allow_unknown=int(rs.rand() < 0.5), max_vel_x=float(rs.choice([0.3, 0.55, 0.9])),
+                            max_trans_vel=float(rs.choice([0.55, 0.9])), forward_point_distance=float(rs.choice([0.0, 0.325, 0.6])),
+                            max_vel_y=0.2, min_vel_y=-0.2, use_dwa=int(rs.rand() < 0.8))
+        fl = nav.Fleet(n_inst, n, n, res, layers=N.LAYER_OBSTACLE, keep_sample_costs=True, max_sim_steps=128, max_plan=256)
+        fl.configure_planner(cfg)
+        fl.set_footprint(synth.FOOTPRINT)
+        fl.upload(N.GRID_MASTER, masters)
+        fl.set_plan()
+        out = {}
+        for bounded in (1, 0):
+            fl.set_bounded_map_grids(bounded)
+            res_b = fl.find_best_path(np.array(pos), np.array(vel), np.stack(plans))
+            lv = fl.wavefront_levels()
+            samples = [fl.samples(k) for k in range(n_inst)]
+            grids = [fl.download(g) for g in (N.GRID_PATH, N.GRID_GOAL, N.GRID_GOAL_FRONT)]
+            out[bounded] = (res_b, samples, grids, lv)
+        for k in range(n_inst):
+            a, b = out[1][0][k], out[0][0][k]
+            assert (a.best_index, a.n_valid, a.n_scored, a.cost) == (b.best_index, b.n_valid, b.n_scored, b.cost), (rnd, k)
+            assert np.array_equal(out[1][1][k][1], out[0][1][k][1]) and np.array_equal(out[1][1][k][0], out[0][1][k][0]), (rnd, k)
+        for ga, gb in zip(out[1][2], out[0][2]):
+            assert np.array_equal(ga, gb), rnd
+        assert (out[1][3] <= out[0][3] + 8).all(), rnd
+        shorter += int((out[1][3] + 8 < out[0][3]).sum())
+        total += out[1][3].size
+        fl.close()
+    assert shorter > total // 3, (shorter, total)  # the comparison is not vacuous: many of the searches did stop early
