@@ -1295,7 +1295,8 @@ def test_bounded_map_grids_reconfigure_between_stage_and_cycle(nav, orc):
     fl.close()
 
 
-def test_bounded_map_grids_random_stress(nav, orc):
+@pytest.mark.parametrize("sizes,rounds", [((160, 250, 400), 40), ((600,), 3), ((800,), 3)])  # k_bfs_wave<7>, <13>, k_bfs_global
+def test_bounded_map_grids_random_stress(nav, orc, sizes, rounds):
     """Seeded random clutter, poses, velocities, limits and plans (some through obstacles, some ending near the robot): the
     bounded and the whole-grid searches must give every sample the same cost, and the completed grids must be equal."""
     from navigation_amd import synth
@@ -1304,8 +1305,8 @@ def test_bounded_map_grids_random_stress(nav, orc):
     rs = np.random.RandomState(2024)
     n_inst = 8
     shorter = total = 0
-    for rnd in range(40):
-        n = int(rs.choice([160, 250, 400]))
+    for rnd in range(rounds):
+        n = int(rs.choice(sizes))
         masters = np.zeros((n_inst, n, n), np.uint8)
         pos, vel, plans = [], [], []
         for k in range(n_inst):
