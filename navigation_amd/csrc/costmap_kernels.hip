@@ -887,7 +887,8 @@ __global__ __launch_bounds__(256) void k_inflate_bits(CostmapDev cm, uint32_t fi
     for (int k = 0; k < 8; ++k) {
       const int r = o * 8 + k;
       uint32_t h = 15;
-      if (r < HR) {
+      // (a row without seeds needs no bit scans: wave-uniform, the row words are the same for every lane)
+      if (r < HR && (s_rows[r][0] | s_rows[r][1] | s_rows[r][2] | s_rows[r][3]) != 0u) {
         // cell column c = lane sits at bit 32 + c of the 128-bit row; window = bits [32+c-R, 32+c+R]
         const uint32_t sft = 32u + lane - (uint32_t)R;
         const uint32_t wi = sft >> 5, bs = sft & 31u;
@@ -909,6 +910,8 @@ __global__ __launch_bounds__(256) void k_inflate_bits(CostmapDev cm, uint32_t fi
   uint32_t hw[5];
 #pragma unroll
   for (int k = 0; k < 5; ++k) hw[k] = (wave + k) * 8 < (uint32_t)HR ? s_hd[wave + k][lane] : 0xFFFFFFFFu;
+  // nibble 15 = no seed within R in that row: a wave all of whose columns see none in any of its 8 + 2R rows writes nothing
+  if (__ballot((hw[0] & hw[1] & hw[2] & hw[3] & hw[4]) != 0xFFFFFFFFu) == 0ull) return;
   const int gx = tx0 + (int)lane;
   const int R2 = R * R;
 #pragma unroll
