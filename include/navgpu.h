@@ -262,7 +262,10 @@ int navgpu_inflate(navgpu_fleet* fleet, uint32_t first, uint32_t count, const in
 /* replaces: ObstacleLayer::updateBounds / VoxelLayer::updateBounds on the staged observations;
  * bounds_inout = count x {min_x, min_y, max_x, max_y} */
 int navgpu_obstacle_update_bounds(navgpu_fleet* fleet, uint32_t first, uint32_t count, double* bounds_inout);
-/* replaces: ObstacleLayer::updateCosts (plugins/obstacle_layer.cpp:427-448) */
+/* replaces: ObstacleLayer::updateCosts (plugins/obstacle_layer.cpp:427-448): updateWithOverwrite /
+ * updateWithMax (costmap_layer.cpp:62-124) of the layer grid into the master grid AS IT STANDS — what
+ * the layers before this one wrote (upload it with navgpu_grid_upload) is kept; no window reset and no
+ * static merge here, those belong to navgpu_costmap_update's fused LayeredCostmap::updateMap. */
 int navgpu_obstacle_update_costs(navgpu_fleet* fleet, uint32_t first, uint32_t count, const int32_t* boxes);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -639,8 +639,10 @@ void launch_obstacle(const CostmapDev& cm, uint32_t first, uint32_t count, const
 // (static_layer.cpp:285-299: updateWithTrueOverwrite | updateWithMax) and ObstacleLayer::updateCosts
 // (obstacle_layer.cpp:437-447: updateWithOverwrite | updateWithMax, costmap_layer.cpp:62-124),
 // fused per byte.  16 cells per thread: three 16-byte reads and one 16-byte write, fully coalesced.
+// layer_only: ObstacleLayer::updateCosts alone, as a costmap_2d::Layer plugin runs it - the master
+// grid it is handed already holds what the layers before it wrote (no reset, no static merge).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_merge(CostmapDev cm, uint32_t first, const int32_t* boxes, int static_received) {
+__global__ __launch_bounds__(256) void k_merge(CostmapDev cm, uint32_t first, const int32_t* boxes, int static_received, int layer_only) {
   const uint32_t inst = first + blockIdx.y;
   int x0, xn, y0, yn;
   if (boxes) {
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(256) void k_merge(CostmapDev cm, uint32_t first, co
   if (row_last < y0 || row_first >= yn) return;
   const size_t off = (size_t)inst * cm.cells_padded + base;
   uint4 mv = *reinterpret_cast<const uint4*>(cm.master + off);
-  const bool has_static = (cm.layers & NAVGPU_LAYER_STATIC) && static_received;
+  const bool has_static = (cm.layers & NAVGPU_LAYER_STATIC) && static_received && !layer_only;
   const bool has_obst = (cm.layers & (NAVGPU_LAYER_OBSTACLE | NAVGPU_LAYER_VOXEL)) && cm.obs_enabled;
   uint4 sv = has_static ? *reinterpret_cast<const uint4*>(cm.stat + off) : make_uint4(0, 0, 0, 0);
   uint4 lv = has_obst ? *reinterpret_cast<const uint4*>(cm.obst + off) : make_uint4(0, 0, 0, 0);
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(256) void k_merge(CostmapDev cm, uint32_t first, co
   for (int k = 0; k < 16; ++k) {
     if (base + k < cm.cells && x >= x0 && x < xn && y >= y0 && y < yn) {
       const int sh = (k & 3) * 8;
-      uint8_t m = cm.master_default;  // resetMap
+      uint8_t m = layer_only ? (uint8_t)((mw[k >> 2] >> sh) & 0xFF) : cm.master_default;  // resetMap
       if (has_static) {
         uint8_t sc = (sw[k >> 2] >> sh) & 0xFF;
         if (!cm.static_use_maximum)
@@ -704,10 +706,10 @@ __global__ __launch_bounds__(256) void k_merge(CostmapDev cm, uint32_t first, co
   if (changed) *reinterpret_cast<uint4*>(cm.master + off) = make_uint4(mw[0], mw[1], mw[2], mw[3]);
 }
 
-void launch_merge(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s) {
+void launch_merge(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s, bool layer_only) {
   uint32_t groups = (cm.cells + 15) / 16;
   dim3 grid((groups + 255) / 256, count);
-  hipLaunchKernelGGL(k_merge, grid, dim3(256), 0, s, cm, first, boxes, cm.static_received);
+  hipLaunchKernelGGL(k_merge, grid, dim3(256), 0, s, cm, first, boxes, cm.static_received, layer_only ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -156,7 +156,7 @@ void launch_tp_rollout(const PlannerDev& pl, const TpDev& tp, uint32_t first, ui
 // ---- launchers (defined in the .hip files) ---------------------------------------------------
 void launch_obstacle(const CostmapDev& cm, uint32_t first, uint32_t count, const double* bounds_in, int only_bounds,
                      hipStream_t s);
-void launch_merge(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s);
+void launch_merge(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s, bool layer_only = false);
 void launch_inflate(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s);
 void launch_static_interpret(uint8_t* dst, const int8_t* occ, uint32_t cells, uint32_t cells_padded, uint32_t count,
                              int track_unknown_space, int trinary, int lethal_threshold, int unknown_cost_value, hipStream_t s);

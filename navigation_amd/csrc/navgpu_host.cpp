@@ -731,7 +731,7 @@ int navgpu_obstacle_update_costs(navgpu_fleet* f, uint32_t first, uint32_t count
     HIP_TRY(hipMemcpyAsync(f->d_boxes_tmp, boxes, sizeof(int32_t) * 4 * count, hipMemcpyHostToDevice, f->stream));
     d_boxes = f->d_boxes_tmp;
   }
-  PROFILED(f, NAVGPU_K_MERGE, launch_merge(f->cm, first, count, d_boxes, f->stream));
+  PROFILED(f, NAVGPU_K_MERGE, launch_merge(f->cm, first, count, d_boxes, f->stream, true));
   if (boxes) HIP_TRY(waitStream(f->stream));
   return checkLaunch();
 }

@@ -1551,7 +1551,10 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     for (int b = 0; b < 32; ++b) {
       const int lx = 32 * j + b;
       uint32_t o = 1, f = 1;
-      if (lx < win) {
+      // cells off the MAP count as set like cells outside the window: a footprint vertex there fails
+      // worldToMap, i.e. footprintCost = -1 (costmap_model.cpp:77-99), which only the polygon walk reports
+      const int gx = wx0 + lx, gy = wy0 + y;
+      if (lx < win && gx >= 0 && gy >= 0 && gx < (int)g.nx && gy < (int)g.ny) {
         const uint8_t cc = s_win[y * win + lx];
         o = cc != 0 ? 1u : 0u;
         f = (uint8_t)(cc - kLethal) <= fail_span_w ? 1u : 0u;

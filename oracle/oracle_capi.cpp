@@ -481,6 +481,14 @@ void orc_dwa_get_grid(void* h, int which, double* out) {
   MapGridCritic* c[4] = {&p->planner.path, &p->planner.goal, &p->planner.goal_front, &p->planner.alignment};
   memcpy(out, c[which]->map.dist.data(), c[which]->map.dist.size() * sizeof(double));
 }
+// the velocity samples SimpleTrajectoryGenerator::initialise laid out for the last cycle (slot order)
+int orc_dwa_get_samples(void* h, float* out_xyz, int cap) {
+  auto* p = static_cast<PlannerHandle*>(h);
+  const auto& sm = p->planner.gen.samples;
+  for (size_t i = 0; i < sm.size() && (int)i < cap; ++i)
+    for (int k = 0; k < 3; ++k) out_xyz[3 * i + k] = sm[i][k];
+  return (int)sm.size();
+}
 double orc_dwa_alignment_scale(void* h) { return static_cast<PlannerHandle*>(h)->planner.alignment.scale; }
 void orc_dwa_get_oscillation(void* h, uint32_t* flags, float* prev_xyz) {
   auto* p = static_cast<PlannerHandle*>(h);

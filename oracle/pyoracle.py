@@ -140,6 +140,7 @@ def lib():
     sig("orc_dwa_check_trajectory", i, vp, f32p, f32p, f32p)
     sig("orc_dwa_update_plan", None, vp, f32p, f64p, u)
     sig("orc_dwa_get_grid", None, vp, i, f64p)
+    sig("orc_dwa_get_samples", i, vp, f32p, i)
     sig("orc_dwa_alignment_scale", d, vp)
     sig("orc_dwa_get_oscillation", None, vp, C.POINTER(u), f32p)
     sig("orc_dwa_set_oscillation", None, vp, u, f32p)
@@ -426,6 +427,13 @@ class DwaPlanner:
         out = np.zeros(self.shape, np.float64)
         self.L.orc_dwa_get_grid(self.h, which, out)
         return out
+
+    def samples(self):
+        """Velocity samples of the last cycle, (n, 3) float32 in slot order."""
+        cap = (self.cfg.vx_samples + 2) * (self.cfg.vy_samples + 2) * (self.cfg.vth_samples + 2)
+        out = np.zeros((cap, 3), np.float32)
+        n = self.L.orc_dwa_get_samples(self.h, out, cap)
+        return out[:n].copy()
 
     def oscillation(self):
         f = C.c_uint32()

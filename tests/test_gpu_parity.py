@@ -255,7 +255,8 @@ def _inflated_instance(orc, n, idx, synth):
     return ins
 
 
-def _check_planner(nav, orc, n, cfg_kw, n_inst=2, footprint=None, allow_unknown=1, unknown_frac=0.0, cycles=1, seed0=0):
+def _check_planner(nav, orc, n, cfg_kw, n_inst=2, footprint=None, allow_unknown=1, unknown_frac=0.0, cycles=1, seed0=0,
+                   plan_len=None):
     from navigation_amd import synth
     N = L(nav)
     fp = synth.FOOTPRINT if footprint is None else footprint
@@ -282,10 +283,10 @@ def _check_planner(nav, orc, n, cfg_kw, n_inst=2, footprint=None, allow_unknown=
             pos[:, 0] += 0.03 * cyc
             pos[:, 2] += 0.4 * cyc
             vel[:, 2] = -vel[:, 2]
-        plans = np.stack([i["plan"] for i in insts])
+        plans = np.stack([i["plan"][:plan_len] for i in insts])
         res = fl.find_best_path(pos, vel, plans)
         for k, ins in enumerate(insts):
-            ores, otraj, cref, cfull, ostatus = planners[k].cycle(pos[k], vel[k], ins["plan"], fp)
+            ores, otraj, cref, cfull, ostatus = planners[k].cycle(pos[k], vel[k], plans[k], fp)
             # MapGrid grids, bit-exact
             for gid, which in ((N.GRID_PATH, 0), (N.GRID_GOAL, 1), (N.GRID_GOAL_FRONT, 2)):
                 g = fl.download(gid, k, 1)[0]
@@ -293,6 +294,8 @@ def _check_planner(nav, orc, n, cfg_kw, n_inst=2, footprint=None, allow_unknown=
                 assert np.array_equal(g.astype(np.float64), og), f"MapGrid {which} differs (inst {k}, cycle {cyc})"
             cost, status, vels = fl.samples(k)
             assert len(cost) == ores.n_samples == res[k].n_samples
+            # VelocityIterator / SimpleTrajectoryGenerator::initialise: every slot's (vx, vy, vtheta), bit for bit
+            assert np.array_equal(vels.view(np.uint32), planners[k].samples().view(np.uint32)), "sample velocities differ"
             assert np.array_equal(status, ostatus), "generator accept/reject mask differs"
             scored = status == 1
             # footprint-collision / failure-code mask bit-exact, costs within 1e-5
@@ -615,7 +618,8 @@ def _planner_pair(nav, orc, n, master, cfg_kw, fp, max_fp=16):
 def _compare_cycle(fl, p, pos, vel, plan, fp):
     r = fl.find_best_path([pos], [vel], [plan])[0]
     o, otraj, _, cfull, ost = p.cycle(np.asarray(pos, np.float32), np.asarray(vel, np.float32), plan, fp)
-    cost, status, _ = fl.samples(0)
+    cost, status, vels = fl.samples(0)
+    assert np.array_equal(vels.view(np.uint32), p.samples().view(np.uint32)), "sample velocities differ"
     assert np.array_equal(status, ost)
     sc = status == 1
     assert np.array_equal(cost[sc] < 0, cfull[sc] < 0)

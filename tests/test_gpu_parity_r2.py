@@ -1,0 +1,336 @@
+"""Parity tests added in round 2 (same bar as test_gpu_parity.py: the HIP path through the C-ABI against the
+CPU oracle, bit-exact on bytes / indices / codes, 1e-5 on cost floats).  They close the holes the round-1 review
+named: footprints leaving a clean map border, the continued-acceleration generator, updateWithOverwrite, the
+layer-granular ObstacleLayer::updateCosts, the inflation cost table as the device applies it, BASELINE configs[2]
+at its full 256 robots with LaserScan cycles, and configs[4]'s voxel layer at 1000x1000."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import (FREE, INSCRIBED, LETHAL, NOINFO, L, _check_planner, _compare_cycle, _planner_pair, nav)  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+# ----------------------------------------------------------------------------------------------
+# CostmapModel::footprintCost at the map edge (costmap_model.cpp:74-101): a footprint vertex that
+# fails worldToMap makes the point -1 -> ObstacleCostFunction -6, whatever the cells in reach hold.
+# All-FREE maps: the only way to fail is through the border, and every shortcut would say "free".
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("poly5", [False, True])
+@pytest.mark.parametrize("allow_unknown", [0, 1])
+@pytest.mark.parametrize("sum_scores", [0, 1])
+def test_planner_clean_border_offmap_vertices(nav, orc, poly5, allow_unknown, sum_scores):
+    from navigation_amd import synth
+    n = 120
+    size = n * synth.RES
+    fp = synth.FOOTPRINT5 if poly5 else synth.FOOTPRINT
+    cfgk = dict(vx_samples=6, vy_samples=4, vth_samples=7, sim_time=1.2, sim_granularity=0.1, discretize_by_time=1,
+                min_vel_x=-0.2, allow_unknown=allow_unknown, sum_scores=sum_scores)
+    master = np.zeros((n, n), np.uint8)
+    fl, p = _planner_pair(nav, orc, n, master, cfgk, fp)
+    n_edge_fail = n_valid = 0
+    mid = size / 2
+    spots = []
+    for d in (0.10, 0.15, 0.20, 0.35, 0.5):  # start illegal ... start legal, the border within the samples' reach
+        spots += [(d, mid), (size - d, mid), (mid, d), (mid, size - d)]          # the four borders
+    spots += [(0.12, 0.17), (size - 0.12, size - 0.17), (0.14, size - 0.11), (size - 0.19, 0.13)]  # the corners
+    for k, (x, y) in enumerate(spots):
+        # plan from the robot into the map's middle so that the MapGrids are reachable
+        plan = np.stack([np.linspace(x, mid, 40), np.linspace(y, mid, 40)], 1)
+        for yaw in (0.0, 0.6 + 0.37 * k, -2.2 + 0.11 * k):
+            r, cost, st = _compare_cycle(fl, p, [x, y, yaw], [0.1, 0.0, 0.2], plan, fp)
+            sc = st == 1
+            n_edge_fail += int((cost[sc] == -6.0).sum())
+            n_valid += int((cost[sc] >= 0).sum())
+    assert n_edge_fail > 0 and n_valid > 0, "the border case was not reached"
+    fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# use_dwa = false: the goal/sim_time-limited sample window (simple_trajectory_generator.cpp:91-105) and
+# continued acceleration inside the rollout (computeNewVelocities each step, :221-248)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("discretize_by_time", [0, 1])
+@pytest.mark.parametrize("plan_len", [200, 12])  # goal 8 m away / 0.5 m away (the window is goal-limited then)
+def test_planner_continued_acceleration(nav, orc, discretize_by_time, plan_len):
+    kw = dict(use_dwa=0, vx_samples=7, vy_samples=5, vth_samples=9, sim_time=1.5, discretize_by_time=discretize_by_time)
+    if discretize_by_time:
+        kw["sim_granularity"] = 0.1
+    _check_planner(nav, orc, 200, kw, n_inst=2, cycles=2, seed0=70, plan_len=plan_len)
+
+
+def test_planner_continued_acceleration_sum_scores_polygon(nav, orc):
+    from navigation_amd import synth
+    _check_planner(nav, orc, 160, dict(use_dwa=0, vx_samples=5, vy_samples=4, vth_samples=6, sim_time=1.0, sim_granularity=0.1,
+                                       discretize_by_time=1, sum_scores=1, min_vel_x=-0.2), n_inst=2, seed0=74,
+                   footprint=synth.FOOTPRINT5, allow_unknown=0, unknown_frac=0.01)
+
+
+# ----------------------------------------------------------------------------------------------
+# combination_method = 0: ObstacleLayer::updateCosts -> updateWithOverwrite (costmap_layer.cpp:107-124)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("track_unknown", [False, True])
+def test_costmap_cycles_overwrite(nav, orc, track_unknown):
+    from navigation_amd import synth
+    N = L(nav)
+    n, nI = 200, 3
+    insts = [synth.make_instance(n, 80 + i) for i in range(nI)]
+    insc = synth.inscribed_radius(synth.FOOTPRINT)
+    fl = nav.Fleet(nI, n, n, synth.RES, layers=N.LAYER_STATIC | N.LAYER_OBSTACLE | N.LAYER_INFLATION, max_points=720,
+                   max_observations=2, track_unknown=track_unknown)
+    fl.configure_obstacle(combination_method=0)
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, insc)
+    oracles = []
+    for i, ins in enumerate(insts):
+        occ = np.where(ins["cells"] == 254, 100, 0).astype(np.int8)
+        occ[5:30, 5:30] = -1  # unknown static area
+        fl.add_static_map(occ, first=i, count=1)
+        o = orc.LayeredCostmap(track_unknown)
+        o.set_footprint(synth.FOOTPRINT)
+        o.add_static(occ, res=synth.RES)
+        o.add_obstacle(combination_method=0)
+        o.add_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, exact=True)
+        o.set_footprint(synth.FOOTPRINT)
+        oracles.append(o)
+    n_overwritten = 0
+    for cyc in range(3):
+        obs, poses = [], []
+        for i, ins in enumerate(insts):
+            pts = synth.laser_scan(ins, cyc)
+            org = (float(ins["pos"][0]), float(ins["pos"][1]), 0.3)
+            obs.append(dict(instance=i, points=pts, origin=org, obstacle_range=2.5, raytrace_range=3.0))
+            poses.append([float(v) for v in ins["pos"]])
+            oracles[i].clear_observations()
+            oracles[i].add_observation(pts, origin=org, obstacle_range=2.5, raytrace_range=3.0)
+            oracles[i].update_map(*poses[-1])
+        fl.stage_observations(poses, obs)
+        fl.update_map()
+        m, ol, b = fl.master(), fl.download(N.GRID_OBSTACLE), fl.bounds()
+        for i in range(nI):
+            assert np.array_equal(b[i], oracles[i].bounds()), (cyc, i)
+            assert np.array_equal(ol[i], oracles[i].layer(2)), (cyc, i)
+            assert np.array_equal(m[i], oracles[i].master()), (cyc, i)
+            # overwrite really differs from max somewhere: a raytraced FREE cell on top of a static lethal one
+            st = np.where(insts[i]["cells"] == 254, 254, 0)
+            n_overwritten += int(((ol[i] == FREE) & (st == 254)).sum())
+    assert n_overwritten > 0 or not track_unknown
+    fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# navgpu_obstacle_update_costs = ObstacleLayer::updateCosts alone (obstacle_layer.cpp:427-448): the master it is
+# handed already holds the earlier layers' output, which must survive outside what the layer grid overrides.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("combination_method", [0, 1])
+def test_obstacle_update_costs_keeps_earlier_layers(nav, orc, combination_method):
+    N = L(nav)
+    n = 96
+    rs = np.random.RandomState(7 + combination_method)
+    fl = nav.Fleet(2, n, n, 0.05, layers=N.LAYER_OBSTACLE, max_points=64, track_unknown=True)
+    fl.configure_obstacle(combination_method=combination_method)
+    masters, layers = [], []
+    for k in range(2):
+        m = rs.randint(0, 253, (n, n)).astype(np.uint8)  # "static layer" content already in the master
+        m[rs.random_sample((n, n)) < 0.05] = NOINFO
+        m[10:20, 10:60] = LETHAL
+        lay = np.full((n, n), NOINFO, np.uint8)
+        lay[rs.random_sample((n, n)) < 0.3] = FREE
+        lay[rs.random_sample((n, n)) < 0.05] = LETHAL
+        masters.append(m)
+        layers.append(lay)
+    fl.upload(N.GRID_MASTER, np.stack(masters))
+    fl.upload(N.GRID_OBSTACLE, np.stack(layers))
+    boxes = [[5, 7, 90, 80], [0, 0, n, n]]
+    fl.obstacle_update_costs(boxes)
+    got = fl.master()
+    for k in range(2):
+        x0, y0, xn, yn = boxes[k]
+        exp = masters[k].copy()
+        sub_m, sub_l = exp[y0:yn, x0:xn], layers[k][y0:yn, x0:xn]
+        if combination_method == 0:   # updateWithOverwrite (costmap_layer.cpp:107-124)
+            take = sub_l != NOINFO
+        else:                          # updateWithMax (costmap_layer.cpp:62-85)
+            take = (sub_l != NOINFO) & ((sub_m == NOINFO) | (sub_m < sub_l))
+        sub_m[take] = sub_l[take]
+        assert np.array_equal(got[k], exp), (combination_method, k)
+    fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# the inflation cost table AS THE DEVICE APPLIES IT: one seed, every (dx, dy) within and just beyond the radius
+# against InflationLayer::computeCaches' cached_costs_ (inflation_layer.cpp:295-328)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("res,radius,scaling,insc", [(0.05, 0.55, 10.0, 0.2), (0.05, 0.7, 3.0, 0.3), (0.1, 1.0, 1.0, 0.0),
+                                                    (0.025, 0.3, 25.0, 0.11), (0.05, 1.2, 5.0, 0.46)])
+def test_inflate_cost_table_through_device(nav, orc, res, radius, scaling, insc):
+    N = L(nav)
+    R, costs, dists = orc.cost_lut(res, radius, scaling, insc)
+    n = 2 * (R + 3) + 1
+    c = n // 2
+    g = np.zeros((n, n), np.uint8)
+    g[c, c] = LETHAL
+    fl = nav.Fleet(1, n, n, res, layers=N.LAYER_INFLATION)
+    fl.configure_inflation(radius, scaling, insc)
+    fl.upload(N.GRID_MASTER, g)
+    fl.inflate(boxes=[[0, 0, n, n]])
+    got = fl.master()[0]
+    exp = np.zeros((n, n), np.uint8)
+    for dy in range(-c, c + 1):
+        for dx in range(-c, c + 1):
+            ax, ay = abs(dx), abs(dy)
+            if ax <= R + 1 and ay <= R + 1 and dists[ax, ay] <= R:  # enqueue's `distance > cell_inflation_radius_` test (:286)
+                exp[c + dy, c + dx] = costs[ax, ay]
+    assert np.array_equal(got, exp)
+    assert np.array_equal(got, orc.inflate(g, res, radius, scaling, insc, exact=False))
+    assert got[c, c] == LETHAL and (got[c, c + 1] == INSCRIBED) == (res <= insc)
+    fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE configs[2] at full size: 256 robots on one GPU, 400x400 costmaps, a LaserScan update every cycle,
+# 32x32x16 samples, 20 steps.  Oracle on 8 robots (all grids, winners), size-independent properties on all 256.
+# ----------------------------------------------------------------------------------------------
+def test_config2_full_fleet_256_with_scans(nav, orc):
+    from navigation_amd import synth
+    N = L(nav)
+    n, nI, n_cyc = 400, 256, 2
+    checked = (0, 37, 64, 101, 128, 190, 222, 255)
+    insc = synth.inscribed_radius(synth.FOOTPRINT)
+    fl = nav.Fleet(nI, n, n, synth.RES, layers=N.LAYER_STATIC | N.LAYER_OBSTACLE | N.LAYER_INFLATION, max_points=720,
+                   max_observations=1, keep_sample_costs=True)
+    fl.configure_obstacle()
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, insc)
+    cfg = synth.fleet_config()
+    fl.configure_planner(cfg)
+    ocfg = orc.DwaConfig(**cfg.as_dict())
+    insts = [synth.make_instance(n, i) for i in range(nI)]
+    oracles = {}
+    for i, ins in enumerate(insts):
+        occ = np.where(ins["cells"] == 254, 100, 0).astype(np.int8)
+        fl.add_static_map(occ, first=i, count=1)
+        if i in checked:
+            o = orc.LayeredCostmap(False)
+            o.set_footprint(synth.FOOTPRINT)
+            o.add_static(occ, res=synth.RES)
+            o.add_obstacle()
+            o.add_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, exact=True)
+            o.set_footprint(synth.FOOTPRINT)
+            oracles[i] = o
+    planners = {}
+    fl.set_plan()
+    pos = np.stack([i["pos"] for i in insts]).copy()
+    vel = np.stack([i["vel"] for i in insts]).copy()
+    plans = np.stack([i["plan"] for i in insts])
+    static_lethal = np.stack([i["cells"] for i in insts]) == 254
+    for cyc in range(n_cyc):
+        obs, poses = [], []
+        for i, ins in enumerate(insts):
+            pts = synth.laser_scan(ins, cyc)
+            org = (float(ins["pos"][0]), float(ins["pos"][1]), 0.3)
+            obs.append(dict(instance=i, points=pts, origin=org, obstacle_range=2.5, raytrace_range=3.0))
+            poses.append([float(v) for v in ins["pos"]])
+            if i in oracles:
+                oracles[i].clear_observations()
+                oracles[i].add_observation(pts, origin=org, obstacle_range=2.5, raytrace_range=3.0)
+                oracles[i].update_map(*poses[-1])
+        fl.stage_observations(poses, obs)
+        fl.update_map()
+        m = fl.master()
+        b = fl.bounds()
+        # properties, all 256: static lethal cells stay lethal (max-merge), no unknowns are created, every marked
+        # point of the scan is lethal in the master, the update box is inside the map and not empty
+        assert (m[static_lethal] == LETHAL).all() and (m != NOINFO).all()
+        assert (b[:, 0] >= 0).all() and (b[:, 2] >= 0).all() and (b[:, 1] <= n).all() and (b[:, 3] <= n).all()
+        assert (b[:, 1] > b[:, 0]).all() and (b[:, 3] > b[:, 2]).all()
+        for i in (3, 77, 200):
+            pts = obs[i]["points"]
+            d2 = ((pts - np.array(obs[i]["origin"], np.float32)) ** 2).sum(1)
+            near = pts[(d2 < 2.5 ** 2 - 1e-3) & (d2 > 0.6 ** 2)]  # beyond the footprint polygon that updateCosts clears
+            cx, cy = (near[:, 0] / synth.RES).astype(int), (near[:, 1] / synth.RES).astype(int)
+            assert (m[i][cy, cx] == LETHAL).all()
+        for i, o in oracles.items():
+            assert np.array_equal(b[i], o.bounds()), (cyc, i)
+            assert np.array_equal(m[i], o.master()), (cyc, i)
+        # planner on the updated costmaps
+        p2 = pos.copy()
+        p2[:, 2] += 0.3 * cyc
+        res = fl.find_best_path(p2, vel, plans)
+        for i in range(nI):
+            cost, status, _ = fl.samples(i) if (i in oracles or i % 16 == 5) else (None, None, None)
+            if cost is None:
+                assert res[i].n_samples > 16384 and 0 <= res[i].n_valid <= res[i].n_scored <= res[i].n_samples
+                continue
+            ok = (status == 1) & (cost >= 0)
+            assert res[i].n_valid == ok.sum() and res[i].n_scored == (status == 1).sum()
+            if ok.any():
+                assert res[i].best_index == int(np.flatnonzero(ok)[np.argmin(cost[ok])]) and res[i].cost == cost[ok].min()
+            else:
+                assert res[i].best_index == -1
+        for i in oracles:
+            if i not in planners:
+                planners[i] = orc.DwaPlanner(m[i], synth.RES, 0.0, 0.0, ocfg)
+                planners[i].set_plan()
+            else:
+                planners[i].set_costmap(m[i])
+            ores, otraj, cref, cfull, ostatus = planners[i].cycle(p2[i], vel[i], plans[i], synth.FOOTPRINT)
+            cost, status, vels = fl.samples(i)
+            assert np.array_equal(status, ostatus)
+            assert np.array_equal(vels.view(np.uint32), planners[i].samples().view(np.uint32))
+            sc = status == 1
+            assert np.array_equal(cost[sc] < 0, cfull[sc] < 0)
+            assert np.array_equal(cost[sc][cost[sc] < 0], cfull[sc][cfull[sc] < 0])
+            assert np.allclose(cost[sc][cost[sc] >= 0], cfull[sc][cfull[sc] >= 0], rtol=0, atol=1e-5)
+            r = res[i]
+            assert (r.best_index, r.n_valid, r.n_scored) == (ores.best_index, ores.n_valid, ores.n_scored)
+            assert abs(r.cost - ores.cost) <= 1e-5 and r.oscillation_flags == ores.oscillation_flags
+            for gid, which in ((N.GRID_PATH, 0), (N.GRID_GOAL, 1), (N.GRID_GOAL_FRONT, 2)):
+                assert np.array_equal(fl.download(gid, i, 1)[0].astype(np.float64), planners[i].grid(which)), (cyc, i, which)
+    fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE configs[4] on one robot: 1000x1000 costmap with the voxel_grid 3-D obstacle layer + inflation, then the
+# 64x64x32-sample planner with the 5-vertex polygon footprint on the costmap the voxel layer produced.
+# ----------------------------------------------------------------------------------------------
+def test_config4_voxel_layer_1000x1000_and_planner(nav, orc):
+    from navigation_amd import synth
+    N = L(nav)
+    n = 1000
+    ins = synth.make_instance(n, 90)
+    insc = synth.inscribed_radius(synth.FOOTPRINT5)
+    fl = nav.Fleet(1, n, n, synth.RES, layers=N.LAYER_VOXEL | N.LAYER_INFLATION, track_unknown=False, max_points=1440,
+                   max_observations=2, keep_sample_costs=True, max_sim_steps=64, max_plan=256)
+    fl.configure_obstacle(z_voxels=10, origin_z=0.0, z_resolution=0.2, unknown_threshold=15, mark_threshold=0, max_obstacle_height=2.0)
+    fl.set_footprint(synth.FOOTPRINT5)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, insc)
+    o = orc.LayeredCostmap(False)
+    o.resize(n, n, synth.RES, 0, 0)
+    o.set_footprint(synth.FOOTPRINT5)
+    o.add_voxel(z_voxels=10, origin_z=0.0, z_resolution=0.2, unknown_threshold=15, mark_threshold=0, max_obstacle_height=2.0)
+    o.add_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, exact=True)
+    o.set_footprint(synth.FOOTPRINT5)
+    pose = [float(v) for v in ins["pos"]]
+    for cyc in range(3):
+        pts = synth.laser_scan(ins, cyc, z=0.3, z_jitter=1.5)
+        org = (pose[0], pose[1], 0.3 + 0.2 * cyc)
+        # long ranges so that marks and 3-D rays cover a large part of the 50 m map
+        obs = [dict(instance=0, points=pts, origin=org, obstacle_range=9.0, raytrace_range=9.5)]
+        o.clear_observations()
+        o.add_observation(pts, origin=org, obstacle_range=9.0, raytrace_range=9.5)
+        o.update_map(*pose)
+        fl.stage_observations([pose], obs)
+        fl.update_map()
+        assert np.array_equal(fl.download(N.GRID_VOXEL)[0], o.voxels()), ("voxel columns", cyc)
+        assert np.array_equal(fl.download(N.GRID_OBSTACLE)[0], o.layer(2)), ("voxel layer 2-D grid", cyc)
+        assert np.array_equal(fl.bounds()[0], o.bounds()), ("box", cyc)
+        assert np.array_equal(fl.master()[0], o.master()), ("master", cyc)
+    m = fl.master()[0]
+    assert (m == LETHAL).sum() > 50
+    cfg = nav.DwaConfig(vx_samples=64, vy_samples=64, vth_samples=32, sim_time=2.0, sim_granularity=0.1, discretize_by_time=1)
+    fl.configure_planner(cfg)
+    p = orc.DwaPlanner(m, synth.RES, 0.0, 0.0, orc.DwaConfig(**cfg.as_dict()))
+    r, cost, st = _compare_cycle(fl, p, ins["pos"], ins["vel"], ins["plan"], synth.FOOTPRINT5)
+    assert r.n_samples > 131072
+    fl.close()
