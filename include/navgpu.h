@@ -281,6 +281,11 @@ int navgpu_planner_set_plan(navgpu_fleet* fleet, uint32_t first, uint32_t count)
  * fp64 libm, the same arithmetic the reference runs once per cycle. */
 int navgpu_planner_stage(navgpu_fleet* fleet, uint32_t first, uint32_t count, const navgpu_robot_state* states,
                          const double* plan_xy, uint32_t n_plan_total);
+/* A control cycle whose local plan has not changed since the last navgpu_planner_stage (move_base hands a new plan
+ * at planner_frequency, the pose changes at controller_frequency): stages pose and velocity only, 24 B per robot
+ * (pos_xyth, vel_xyth = count x 3 floats), and re-derives the nose goal / alignment switch of
+ * DWAPlanner::updatePlanAndLocalCosts (dwa_planner.cpp:254-285) from the resident plan.  Needs a staged plan. */
+int navgpu_planner_stage_poses(navgpu_fleet* fleet, uint32_t first, uint32_t count, const float* pos_xyth, const float* vel_xyth);
 /* replaces: DWAPlanner::findBestPath (dwa_planner.cpp:292-371) =
  * SimpleTrajectoryGenerator::initialise + SimpleScoredSamplingPlanner::findBestTrajectory
  * (4 x MapGridCostFunction::prepare, rollout + six critics per sample, first-strict-minimum) +
@@ -301,6 +306,9 @@ int navgpu_planner_set_bounded_map_grids(navgpu_fleet* fleet, int32_t enable);
 /* introspection: the number of wavefront levels the last cycle ran for the path / goal / goal_front grid of each instance
  * (levels = count x 3).  A whole-grid search runs until nothing new is reached, a bounded one stops earlier. */
 int navgpu_planner_wavefront_levels(navgpu_fleet* fleet, uint32_t first, uint32_t count, uint32_t* levels);
+/* introspection: the cell box {x0, x1, y0, y1} (inclusive) the last cycle's bounded wavefronts settled per instance
+ * (boxes = count x 4); the whole map for an instance whose grids were searched whole */
+int navgpu_planner_wavefront_boxes(navgpu_fleet* fleet, uint32_t first, uint32_t count, int32_t* boxes);
 int navgpu_planner_results(navgpu_fleet* fleet, uint32_t first, uint32_t count, navgpu_plan_result* results);
 /* winning trajectory of one instance: xyth = n_points x {x,y,theta}; returns n_points or <0 */
 int navgpu_planner_trajectory(navgpu_fleet* fleet, uint32_t instance, double* xyth, uint32_t capacity_points);

@@ -197,9 +197,11 @@ SYMBOLS = [
     ("navgpu_planner_configure", C.c_int, [vp, C.POINTER(DwaConfig)]),
     ("navgpu_planner_set_plan", C.c_int, [vp, u32, u32]),
     ("navgpu_planner_stage", C.c_int, [vp, u32, u32, vp, vp, u32]),
+    ("navgpu_planner_stage_poses", C.c_int, [vp, u32, u32, vp, vp]),
     ("navgpu_planner_cycle", C.c_int, [vp, u32, u32]),
     ("navgpu_planner_set_bounded_map_grids", C.c_int, [vp, C.c_int32]),
     ("navgpu_planner_wavefront_levels", C.c_int, [vp, u32, u32, vp]),
+    ("navgpu_planner_wavefront_boxes", C.c_int, [vp, u32, u32, vp]),
     ("navgpu_planner_results", C.c_int, [vp, u32, u32, vp]),
     ("navgpu_planner_trajectory", C.c_int, [vp, u32, vp, u32]),
     ("navgpu_planner_samples", C.c_int, [vp, u32, vp, vp, vp, u32]),

@@ -171,6 +171,21 @@ void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStr
 void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order = nullptr, bool free_ready = false);
 uint32_t launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s);  // returns blocks per instance
 void launch_select(const PlannerDev& pl, uint32_t first, uint32_t count, uint32_t n_blocks, hipStream_t s);
+// the poses of up to 64 robots as one kernel-argument block (< 4 KB)
+constexpr uint32_t kPoseChunk = 64;
+struct PoseChunk {
+  navgpu_robot_state* state;  // device arrays, indexed by absolute instance
+  double* front_last;
+  int32_t* align_on;
+  uint32_t* bfs_reach;
+  uint32_t first, count;
+  navgpu_robot_state st[kPoseChunk];
+  double front[2 * kPoseChunk];
+  int32_t align[kPoseChunk];
+  uint32_t reach[kPoseChunk];
+};
+static_assert(sizeof(PoseChunk) <= 4096, "kernel arguments are limited to 4 KB");
+void launch_stage_poses(const PoseChunk& c, hipStream_t s);
 size_t bfs_lds_bytes(uint32_t nx, uint32_t ny);
 bool bfs_bounded_applies(const PlannerDev& pl);  // the wavefront kernel launch_bfs picks for this map can stop at the robot's box
 size_t score_table_bytes(const PlannerDev& pl);

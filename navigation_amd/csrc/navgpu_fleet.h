@@ -74,6 +74,7 @@ struct navgpu_fleet {
   }
   navgpu_robot_state* hp_state = nullptr;
   navgpu_plan_result* hp_result = nullptr;
+  bool hp_dma_pending = false;  // a full stage's copies out of hp_state / hp_front / hp_align / hp_reach may still be queued
   // DWAPlannerROS mirror (navgpu_local_planner_*): per-instance controller state, host only
   struct LocalPlannerState {
     std::vector<double> plan;      // stored global plan, (x, y, yaw) triples in the plan's frame (prunePlan shrinks it)

@@ -149,10 +149,11 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   pl.max_plan = f->desc.max_plan;
   pl.max_sim_steps = f->desc.max_sim_steps;
   A(pl.state, n);
-  A(pl.plan, (size_t)n * pl.max_plan * 2);
-  A(pl.plan_count, n);
   A(pl.front_last, (size_t)n * 2);
   A(pl.align_on, n);
+  A(pl.bfs_reach, n);
+  A(pl.plan, (size_t)n * pl.max_plan * 2);
+  A(pl.plan_count, n);
   A(pl.fp_spec, (size_t)n * kMaxFootprint * 2);
   A(pl.fp_n, n);
   A(pl.axis_count, (size_t)n * 4);
@@ -164,7 +165,6 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   pl.within = nullptr;
   A(pl.bfs_box, (size_t)n * 8);
   A(pl.bfs_care, (size_t)n * kCareRows * kCareWords);
-  A(pl.bfs_reach, n);
   A(pl.bfs_next_item, 4);
   A(pl.bfs_free, (size_t)n * cm.ny * ((cm.nx + 31) / 32));
   A(pl.bfs_levels, (size_t)n * 3);
@@ -821,6 +821,7 @@ static int restageReach(navgpu_fleet* f) {
     f->hp_reach[i] = bfsReachCells(f, f->hp_state[i], last[0], last[1]);
   }
   HIP_TRY(hipMemcpyAsync(pl.bfs_reach, f->hp_reach, sizeof(uint32_t) * n, hipMemcpyHostToDevice, f->stream));
+  f->hp_dma_pending = true;
   return NAVGPU_OK;
 }
 
@@ -947,6 +948,78 @@ int navgpu_planner_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
   HIP_TRY(hipMemcpyAsync(pl.align_on + first, f->hp_align + first, sizeof(int32_t) * count, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(hipMemcpyAsync(pl.bfs_reach + first, f->hp_reach + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
   f->planner_staged = true;
+  f->hp_dma_pending = true;
+  return NAVGPU_OK;
+}
+
+// A control cycle whose plan has not changed (the plan arrives at ~1 Hz, the pose at controller_frequency): only pose and
+// velocity are staged, 24 B per robot; the nose goal, the alignment switch and the wavefront box are re-derived from the
+// resident plan exactly as navgpu_planner_stage derives them.  The values travel as kernel arguments (k_stage_poses): the call
+// never waits for the stream.
+int navgpu_planner_stage_poses(navgpu_fleet* f, uint32_t first, uint32_t count, const float* pos_xyth, const float* vel_xyth) {
+  if (!f || !pos_xyth || !vel_xyth || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  if (!f->planner_configured || !f->planner_staged) return NAVGPU_ERR_STATE;
+  PlannerDev& pl = f->pl;
+  const navgpu_dwa_config& c = pl.cfg;
+  for (uint32_t i = first; i < first + count; ++i)
+    if (!f->hp_plan_cnt[i]) {
+      g_last_error = "navgpu_planner_stage_poses: instance " + std::to_string(i) + " has no staged plan";
+      return NAVGPU_ERR_STATE;
+    }
+  if (f->hp_dma_pending) {  // the host mirrors written below may still feed a full stage's copies
+    HIP_TRY(waitStream(f->stream));
+    f->hp_dma_pending = false;
+  }
+  for (uint32_t li = 0; li < count; ++li) {
+    const uint32_t i = first + li;
+    navgpu_robot_state& s = f->hp_state[i];
+    for (int k = 0; k < 3; ++k) {
+      s.pos[k] = pos_xyth[3 * li + k];
+      s.vel[k] = vel_xyth[3 * li + k];
+    }
+    const double* last = &f->hp_plan[((size_t)i * pl.max_plan + f->hp_plan_cnt[i] - 1) * 2];
+    const double gx = last[0], gy = last[1];
+    // DWAPlanner::updatePlanAndLocalCosts (dwa_planner.cpp:254-285), as in navgpu_planner_stage
+    const double sq_dist = (s.pos[0] - gx) * (s.pos[0] - gx) + (s.pos[1] - gy) * (s.pos[1] - gy);
+    const double angle_to_goal = atan2(gy - s.pos[1], gx - s.pos[0]);
+    f->hp_front[2 * i] = gx + c.forward_point_distance * cos(angle_to_goal);
+    f->hp_front[2 * i + 1] = gy + c.forward_point_distance * sin(angle_to_goal);
+    f->hp_align[i] = sq_dist > c.forward_point_distance * c.forward_point_distance * c.cheat_factor ? 1 : 0;
+    f->hp_reach[i] = bfsReachCells(f, s, gx, gy);
+  }
+  f->touchInputs(first, count);
+  PoseChunk ch;
+  ch.state = pl.state;
+  ch.front_last = pl.front_last;
+  ch.align_on = pl.align_on;
+  ch.bfs_reach = pl.bfs_reach;
+  for (uint32_t at = 0; at < count; at += kPoseChunk) {
+    ch.first = first + at;
+    ch.count = std::min(kPoseChunk, count - at);
+    memcpy(ch.st, f->hp_state + ch.first, sizeof(navgpu_robot_state) * ch.count);
+    memcpy(ch.front, f->hp_front + (size_t)ch.first * 2, sizeof(double) * 2 * ch.count);
+    memcpy(ch.align, f->hp_align + ch.first, sizeof(int32_t) * ch.count);
+    memcpy(ch.reach, f->hp_reach + ch.first, sizeof(uint32_t) * ch.count);
+    launch_stage_poses(ch, f->stream);
+  }
+  return checkLaunch();
+}
+
+// the cell box (x0, x1, y0, y1, inclusive) the last cycle's bounded wavefronts had to settle for each instance;
+// {0, nx-1, 0, ny-1} for a robot whose grids were searched whole
+int navgpu_planner_wavefront_boxes(navgpu_fleet* f, uint32_t first, uint32_t count, int32_t* boxes) {
+  if (!f || !boxes || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  for (uint32_t li = 0; li < count; ++li) {
+    const uint32_t i = first + li;
+    if (f->grid_partial[i])
+      memcpy(boxes + 4 * li, &f->h_box[(size_t)4 * i], sizeof(int32_t) * 4);
+    else {
+      boxes[4 * li] = 0;
+      boxes[4 * li + 1] = (int32_t)f->pl.nx - 1;
+      boxes[4 * li + 2] = 0;
+      boxes[4 * li + 3] = (int32_t)f->pl.ny - 1;
+    }
+  }
   return NAVGPU_OK;
 }
 

@@ -2363,4 +2363,23 @@ void launch_select(const PlannerDev& pl, uint32_t first, uint32_t count, uint32_
   hipLaunchKernelGGL(k_select, dim3(count), dim3(64), 0, s, pl, first, n_blocks);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_stage_poses (navgpu_planner_stage_poses): the poses of a cycle travel as KERNEL ARGUMENTS, 64 robots (3.5 KB) per
+// launch - the runtime copies the argument block when the launch is queued, so there is no staging buffer whose reuse
+// the host would have to wait for.  (An H2D hipMemcpyAsync of this size was measured to block until the stream had
+// drained, an event wait to cost 2 ms while timing events are recorded in the same process, and a host spin on a
+// device-written flag to starve the queue.)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_stage_poses(PoseChunk c) {
+  const uint32_t li = threadIdx.x;
+  if (li >= c.count) return;
+  const uint32_t i = c.first + li;
+  c.state[i] = c.st[li];
+  c.front_last[2 * i] = c.front[2 * li];
+  c.front_last[2 * i + 1] = c.front[2 * li + 1];
+  c.align_on[i] = c.align[li];
+  c.bfs_reach[i] = c.reach[li];
+}
+void launch_stage_poses(const PoseChunk& c, hipStream_t s) { hipLaunchKernelGGL(k_stage_poses, dim3(1), dim3(64), 0, s, c); }
+
 }  // namespace navgpu

@@ -217,6 +217,19 @@ class Fleet:
         check(self.L.navgpu_planner_stage(self.h, first, n, C.cast(states, C.c_void_p), _ptr(packed_plans),
                                           len(packed_plans)), "planner_stage")
 
+    def stage_poses(self, pos, vel, first=0):
+        """A control cycle whose plan is unchanged: pose + velocity only (pos, vel: (count, 3) float32, C-contiguous)."""
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        vel = np.ascontiguousarray(vel, np.float32).reshape(-1, 3)
+        check(self.L.navgpu_planner_stage_poses(self.h, first, len(pos), _ptr(pos), _ptr(vel)), "planner_stage_poses")
+
+    def wavefront_boxes(self, first=0, count=None):
+        """Cell boxes (x0, x1, y0, y1, inclusive) the last cycle's bounded wavefronts settled, [count, 4]."""
+        first, count = self._range(first, count)
+        out = np.zeros((count, 4), np.int32)
+        check(self.L.navgpu_planner_wavefront_boxes(self.h, first, count, _ptr(out)), "wavefront_boxes")
+        return out
+
     def set_bounded_map_grids(self, enable):
         """navgpu_planner_set_bounded_map_grids: wavefronts stop once the robot's box is settled (default on)."""
         check(self.L.navgpu_planner_set_bounded_map_grids(self.h, 1 if enable else 0), "set_bounded_map_grids")

@@ -334,3 +334,57 @@ def test_config4_voxel_layer_1000x1000_and_planner(nav, orc):
     r, cost, st = _compare_cycle(fl, p, ins["pos"], ins["vel"], ins["plan"], synth.FOOTPRINT5)
     assert r.n_samples > 131072
     fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# navgpu_planner_stage_poses: a cycle with an unchanged plan stages pose + velocity only and must give what a full
+# stage of the same inputs gives (= the oracle's cycle).  More cycles than the staging ring has slots, a full stage in
+# between, robots near the end of their plan (whole-grid searches) and far from it (bounded ones).
+# ----------------------------------------------------------------------------------------------
+def test_stage_poses_equals_full_stage(nav, orc):
+    from navigation_amd import synth
+    from test_gpu_parity import _inflated_instance
+    N = L(nav)
+    n, nI = 200, 3
+    cfg = nav.DwaConfig(vx_samples=8, vy_samples=6, vth_samples=9, sim_time=1.5, sim_granularity=0.1, discretize_by_time=1)
+    ocfg = orc.DwaConfig(**cfg.as_dict())
+    insts = [_inflated_instance(orc, n, 120 + i, synth) for i in range(nI)]
+    fl = nav.Fleet(nI, n, n, synth.RES, layers=N.LAYER_OBSTACLE, keep_sample_costs=True, max_sim_steps=64)
+    fl.configure_planner(cfg)
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.upload(N.GRID_MASTER, np.stack([i["master"] for i in insts]))
+    planners = [orc.DwaPlanner(i["master"], synth.RES, 0.0, 0.0, ocfg) for i in insts]
+    fl.set_plan()
+    for p in planners:
+        p.set_plan()
+    plans = [insts[0]["plan"], insts[1]["plan"][:25], insts[2]["plan"][:120]]  # goal 8 m, 1 m, 4.8 m away
+    pos = np.stack([i["pos"] for i in insts]).copy()
+    vel = np.stack([i["vel"] for i in insts]).copy()
+    with pytest.raises(nav.NavgpuError):
+        fl.stage_poses(pos, vel)  # no plan staged yet
+    rs = np.random.RandomState(3)
+    for cyc in range(11):
+        if cyc in (0, 6):
+            fl.stage_planner(pos, vel, plans)       # the plan "arrives"
+        else:
+            pos = (pos + rs.normal(size=pos.shape) * [0.03, 0.03, 0.2]).astype(np.float32)
+            vel = (vel + rs.normal(size=vel.shape) * [0.05, 0.0, 0.1]).astype(np.float32)
+            fl.stage_poses(pos, vel)
+        fl.planner_cycle()
+        res = fl.results()
+        for k in range(nI):
+            o, otraj, _, cfull, ost = planners[k].cycle(pos[k], vel[k], plans[k], synth.FOOTPRINT)
+            cost, status, vels = fl.samples(k)
+            assert np.array_equal(status, ost) and np.array_equal(vels.view(np.uint32), planners[k].samples().view(np.uint32))
+            sc = status == 1
+            assert np.array_equal(cost[sc] < 0, cfull[sc] < 0)
+            assert np.array_equal(cost[sc][cost[sc] < 0], cfull[sc][cfull[sc] < 0])
+            assert np.allclose(cost[sc][cost[sc] >= 0], cfull[sc][cfull[sc] >= 0], rtol=0, atol=1e-5)
+            r = res[k]
+            assert (r.best_index, r.n_valid, r.n_scored) == (o.best_index, o.n_valid, o.n_scored), (cyc, k)
+            assert abs(r.cost - o.cost) <= 1e-5 and r.oscillation_flags == o.oscillation_flags
+            for gid, which in ((N.GRID_PATH, 0), (N.GRID_GOAL, 1), (N.GRID_GOAL_FRONT, 2)):
+                assert np.array_equal(fl.download(gid, k, 1)[0].astype(np.float64), planners[k].grid(which)), (cyc, k, which)
+    b = fl.wavefront_boxes()
+    assert b.shape == (nI, 4) and (b[:, 0] <= b[:, 1]).all() and (b[:, 2] <= b[:, 3]).all()
+    fl.close()

@@ -11,6 +11,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   lc=$(echo $c | tr A-Z a-z)
   cp $out/$c/r_counter_collection.csv $out/${tag}_pmc_$lc.csv
 done
+# instruction mix (two more PMC passes; SQ counters only): VALU / SALU wave-instructions and the busy clock
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE"; do
+  n=$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/$n -o r -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-single > $out/$n.json 2> $out/$n.err
+  cp $out/$n/r_counter_collection.csv $out/${tag}_pmc_$(echo $n | tr A-Z a-z).csv
+done
 python3 - "$out" "$tag" <<'PY'
 import csv, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
@@ -37,4 +43,29 @@ json.dump(dict(source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate p
                caveat="gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x and is uncalibrated for gathers",
                kernels=kern), open(f"{out}/{tag}_hbm_traffic.json", "w"), indent=1)
 print(json.dumps(kern, indent=1))
+# ---- instruction mix per profiled region: mean per launch, summed over the 8 XCDs
+mix = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in ("sq_insts_valu", "sq_active_inst_valu"):
+    for r in csv.DictReader(open(f"{out}/{tag}_pmc_{f}.csv")):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("navgpu::", "").split("<")[0]
+        mix[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+regions = {}
+for g, members in GROUPS.items():
+    main = [m for m in MAIN.get(g, members) if m in mix]
+    if not main: continue
+    launches = max(len(mix[m]["SQ_INSTS_VALU"]) for m in main)
+    tot = lambda c: sum(sum(mix[m][c]) for m in members if m in mix) / max(launches, 1)
+    clk = tot("GRBM_GUI_ACTIVE") / 8.0  # rocprofv3 sums the 8 XCDs
+    v = dict(insts_valu=tot("SQ_INSTS_VALU"), insts_salu=tot("SQ_INSTS_SALU"), insts_lds=tot("SQ_INSTS_LDS"), insts_smem=tot("SQ_INSTS_SMEM"),
+             insts_vmem_rd=tot("SQ_INSTS_VMEM_RD"), insts_vmem_wr=tot("SQ_INSTS_VMEM_WR"), active_inst_valu_quadcycles=tot("SQ_ACTIVE_INST_VALU"),
+             active_inst_sca_quadcycles=tot("SQ_ACTIVE_INST_SCA"), wave_cycles_quadcycles=tot("SQ_WAVE_CYCLES"), waves=tot("SQ_WAVES"),
+             gpu_clocks=clk, launches=launches, device_kernels=[m for m in members if m in mix])
+    # a SIMD holds one VALU instruction at a time: busy fraction = VALU-active cycles / (1024 SIMDs x kernel clocks)
+    v["valu_busy"] = 4.0 * v["active_inst_valu_quadcycles"] / (1024.0 * clk) if clk else None
+    v["bound"] = "valu" if (v["valu_busy"] or 0) >= 0.5 else "latency"
+    regions[g] = v
+json.dump(dict(source="rocprofv3 --pmc (SQ instruction counters, separate passes from the TCC ones); mean per launch, summed over XCDs",
+               valu_busy="4 x SQ_ACTIVE_INST_VALU (quad-cycles -> cycles) / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)", regions=regions),
+          open(f"{out}/{tag}_pmc_summary.json", "w"), indent=1)
+print(json.dumps({k: (round(v["valu_busy"], 3), round(v["insts_valu"] / 1e6, 1), round(v["insts_salu"] / 1e6, 1)) for k, v in regions.items()}))
 PY
