@@ -114,9 +114,10 @@ struct PlannerDev {
   uint32_t fp_rcells;         // Chebyshev radius (cells) that contains every footprint cell around the centre cell
   uint32_t fp_chunk;          // cells of the longest footprint edge (+1): picks the k_score<CHUNK> instantiation
   uint32_t use_tables, tab_steps, tab_nfp, tab_nth;
+  uint32_t tab_bytes;         // score_table_bytes(): the tables' share of the LDS image (0 without tables)
   uint8_t* prep;              // [n][prep_stride] LDS image of k_score (window, reach bitmaps, heading tables), built per cycle by k_score_prep*
   uint32_t prep_stride, prep_bytes;
-  uint32_t debug;             // timing ablation bits (NAVGPU_DEBUG_SCORE), 0 in product use  // k_score<TABLES>: shared per-(v_theta, step) tables in LDS
+  // k_score<TABLES>: shared per-(v_theta, step) tables in LDS
   double* sample_cost;        // [n][max_samples] or null
   int32_t* sample_status;     // [n][max_samples] or null
   double* part_cost;          // [n][score_blocks]

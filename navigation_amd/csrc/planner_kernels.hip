@@ -1473,9 +1473,11 @@ struct ScoreOut {
 // per (v_theta sample, step) by the workgroup into LDS and shared by all (vx, vy) samples, and lanes
 // are mapped so that a wave shares one v_theta: identical edge shapes => convergent Bresenham loops.
 // The arithmetic per value is unchanged (same operations, same rounding), only deduplicated.
-__host__ __device__ inline size_t score_bits_bytes(int win) {  // 2 x [win][nw][2] words, 16-byte aligned
+__host__ __device__ inline size_t score_bits_bytes(int win) {  // [win][nw][4] words (part of the LDS image), 16-byte aligned
   return (((size_t)4 * win * ((win + 31) >> 5) * 4) + 15) & ~(size_t)15;
 }
+// the two [win][nw][2] word arrays the dilation passes work in: behind the image, only where the image is BUILT (PREP != 2)
+__host__ __device__ inline size_t score_scratch_bytes(int win) { return score_bits_bytes(win); }
 // PREP: 0 = build the LDS image (window, bitmaps, tables) in this workgroup; 1 = build it and store it to
 // pl.prep (k_score_prep*, one workgroup per robot); 2 = load the stored image (the scoring workgroups of
 // a robot all use the same one: 74 of them in the 32x32x16 configuration)
@@ -1530,17 +1532,22 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       s_win[i] = v;
     }
   }
-  // ---- footprint shortcuts.  The cells a footprint with centre cell c can touch lie within the
-  // Chebyshev radius fp_rcells of c (>= circumscribed radius in cells + 1).  Two bitmaps of the window,
-  // dilated by that radius, are built once per workgroup (bit-parallel: rows of 32-cell words, shifts
-  // for the horizontal pass, word ORs for the vertical one; everything outside the window counts as set):
-  //   s_fb[..][0]: some cell in reach is not FREE_SPACE  -> clear = the point's footprint cost is exactly 0
-  //   s_fb[..][1]: some cell in reach fails pointCost    -> clear = the point is legal (cost not needed)
+  // ---- per-cell screens of the window, four bitmaps interleaved per 32-cell word: s_fb[(y * nw + j) * 4 + k]
+  // Footprint shortcuts: the cells a footprint with centre cell c can touch lie within the Chebyshev radius
+  // fp_rcells of c (>= circumscribed radius in cells + 1).  Two bitmaps of the window, dilated by that radius, are
+  // built once per robot (bit-parallel: rows of 32-cell words, shifts for the horizontal pass, word ORs for the
+  // vertical one; everything outside the window or off the map counts as set):
+  //   k = 0: some cell in reach is not FREE_SPACE  -> clear = the point's footprint cost is exactly 0
+  //   k = 1: some cell in reach fails pointCost    -> clear = the point is legal (cost not needed)
+  // MapGrid screens (not dilated): a trajectory point only has to NOT be an obstacle / unreachable cell of the path and
+  // goal grids unless it is the last one (aggregation Last, map_grid_cost_function.cpp:92-127):
+  //   k = 2: path grid holds obstacleCosts() or unreachableCellCosts() here    k = 3: the goal grid does
   const int win_bytes = (win * win + 15) & ~15;
   const int nw = (win + 31) >> 5;
-  uint32_t* s_ba = reinterpret_cast<uint32_t*>(s_dyn + win_bytes);  // [win][nw][2] raw, later the result
-  uint32_t* s_bb = s_ba + 2 * win * nw;                               // [win][nw][2] after the horizontal pass
-  uint32_t* s_fb = s_ba;
+  uint32_t* s_fb = reinterpret_cast<uint32_t*>(s_dyn + win_bytes);  // [win][nw][4]
+  // build scratch behind the image (window + bitmaps + tables): [win][nw][2] raw, [win][nw][2] after the horizontal pass
+  uint32_t* s_ba = reinterpret_cast<uint32_t*>(s_dyn + win_bytes + score_bits_bytes(win) + (TABLES ? pl.tab_bytes : 0u));
+  uint32_t* s_bb = s_ba + 2 * win * nw;
   const int rc = (int)pl.fp_rcells;
   const uint8_t fail_span_w = (pl.cfg.allow_unknown != 0) ? 0 : 1;
   __syncthreads();
@@ -1585,7 +1592,32 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     uint32_t m = (y - rc < 0 || y + rc >= win) ? 0xFFFFFFFFu : 0u;
     if (!m)
       for (int d = -rc; d <= rc; ++d) m |= s_bb[it + 2 * d * nw];
-    s_fb[it] = m;
+    s_fb[4 * cell + (it & 1)] = m;
+  }
+  {  // MapGrid screens: 64 consecutive cells of a (padded) window row per wave step, packed by ballot
+    const uint32_t n_obst = pl.cells, n_unreach = pl.cells + 1;
+    const int row_cells = nw * 32;
+    for (int base = (int)(tid & ~63u); base < win * row_cells; base += (int)blockDim.x) {
+      const int idx = base + (int)(tid & 63u);
+      const int y = idx / row_cells, lx = idx - y * row_cells;
+      const int gx = wx0 + lx, gy = wy0 + y;
+      bool pf = true, gf = true;
+      if (lx < win && gx >= 0 && gy >= 0 && gx < (int)g.nx && gy < (int)g.ny) {
+        const uint32_t dp = dpath[gy * g.nx + gx], dg = dgoal[gy * g.nx + gx];
+        pf = dp == n_obst || dp == n_unreach;
+        gf = dg == n_obst || dg == n_unreach;
+      }
+      const unsigned long long mp = __ballot(pf), mg = __ballot(gf);
+      if ((tid & 63u) == 0) {
+        const int w = idx >> 5;  // linear word index y * nw + j; a wave covers two words (possibly of two rows)
+        s_fb[4 * w + 2] = (uint32_t)mp;
+        s_fb[4 * w + 3] = (uint32_t)mg;
+        if (w + 1 < win * nw) {
+          s_fb[4 * (w + 1) + 2] = (uint32_t)(mp >> 32);
+          s_fb[4 * (w + 1) + 3] = (uint32_t)(mg >> 32);
+        }
+      }
+    }
   }
   }
   // The LDS window is kept in "walk order": with allow_unknown the bytes 254 (LETHAL) and 255 (NO_INFORMATION)
@@ -1662,16 +1694,16 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   const double inv_res = pl.inv_res;
   // Costmap2D::worldToMap with the two fp64 divisions replaced by a multiply; exact: whenever the
   // product is not clear of an integer by 1e-7 (error bound 5e-10 below 1e6 cells) the division is redone.
+  // Straight-line: the quotient is clamped to [-1, 1e6] first (a point left of / below the origin floors to -1, one
+  // beyond any supported grid - or NaN - to a cell that fails the size test), so the only branch is the rare redo.
   auto w2m = [&](double wx, double wy, uint32_t& mx, uint32_t& my) -> bool {
-    if (wx < g.ox || wy < g.oy) return false;
     const double dx = wx - g.ox, dy = wy - g.oy;
-    const double qx = dx * inv_res, qy = dy * inv_res;
-    if (!(qx < 1.0e6) || !(qy < 1.0e6)) return false;  // beyond any supported grid (also NaN)
+    const double qx = fmin(fmax(dx * inv_res, -1.0), 1.0e6), qy = fmin(fmax(dy * inv_res, -1.0), 1.0e6);
     double fx = floor(qx), fy = floor(qy);
     const double rx = qx - fx, ry = qy - fy;
-    if (__builtin_expect(rx < 1.0e-7 || rx > 1.0 - 1.0e-7 || ry < 1.0e-7 || ry > 1.0 - 1.0e-7, 0)) {
-      fx = (double)(int)(dx / g.res);
-      fy = (double)(int)(dy / g.res);
+    if (__builtin_expect(fmin(rx, ry) < 1.0e-7 || fmax(rx, ry) > 1.0 - 1.0e-7, 0)) {
+      fx = !(dx >= 0.0) ? -1.0 : (qx >= 1.0e6 ? 1.0e6 : (double)(int)(dx / g.res));  // wx < origin -> false (costmap_2d.cpp:210)
+      fy = !(dy >= 0.0) ? -1.0 : (qy >= 1.0e6 ? 1.0e6 : (double)(int)(dy / g.res));
     }
     mx = (uint32_t)(int)fx;
     my = (uint32_t)(int)fy;
@@ -1726,7 +1758,6 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       num_steps = (int)ns;
       if (num_steps <= 0) reject = true;  // `return num_steps > 0` (:250)
       if (num_steps > (int)pl.max_sim_steps) num_steps = (int)pl.max_sim_steps;  // host validates the capacity
-      if (pl.debug & 8u) num_steps = 1;  // timing ablation: setup + epilogue only
     }
     // DWAPlanner::checkTrajectory ignores generateTrajectory's return value and scores whatever
     // points exist (dwa_planner.cpp:229-230): a rejected sample is an empty trajectory, cost 0.
@@ -1737,7 +1768,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     if (!reject) {
       status = NAVGPU_SAMPLE_SCORED;
       const double dt = c.sim_time / num_steps;
-      const bool continued = !c.use_dwa;
+      const bool continued = TABLES ? false : !c.use_dwa;  // (the tables exist for use_dwa only)
       float px = st.pos[0], py = st.pos[1], pth = st.pos[2];
       float lv[3] = {vs[0], vs[1], vs[2]};
       const float acc[3] = {(float)c.acc_lim_x, (float)c.acc_lim_y, (float)c.acc_lim_theta};
@@ -1777,13 +1808,23 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
         fail_code = -9.0;
         first_fail = 1;
       }
+      // a critic is live while no critic before it in the order has failed; the lowest enabled order decides when
+      // nothing is left to evaluate
+      const int min_order = en_obs ? 1 : en_gf ? 2 : en_al ? 3 : en_path ? 4 : en_goal ? 5 : 6;
+      // the forward point (x + fpd cos, y + fpd sin) stays on the map whenever the centre cell is this many cells
+      // away from every border; only then may a step skip its worldToMap
+      const uint32_t fwd_margin = (uint32_t)fmin(ceil(fabs(fpd) * inv_res) + 1.0, 1.0e6);
+      const bool fwd_screen = !(en_gf || en_al) || (2u * fwd_margin < g.nx && 2u * fwd_margin < g.ny);
+      const uint32_t fwd_lo = (en_gf || en_al) ? fwd_margin : 0u, fwd_nx = g.nx - 2u * fwd_lo, fwd_ny = g.ny - 2u * fwd_lo;
+      // which of the four screens count: obstacle (dilated "not free" with sum_scores, else dilated "can fail"), path, goal
+      const uint32_t scr_x = (en_obs && c.sum_scores) ? ~0u : 0u, scr_y = (en_obs && !c.sum_scores) ? ~0u : 0u,
+                     scr_z = en_path ? ~0u : 0u, scr_w = en_goal ? ~0u : 0u;
+      const bool screen_on = fwd_screen && (nfp >= 3 || !en_obs);
       if (osc_fail) {
         total = -5.0;
       } else {
         for (int step = 0; step < num_steps; ++step) {
-          const bool live_obs = en_obs && 1 < first_fail, live_gf = en_gf && 2 < first_fail, live_al = en_al && 3 < first_fail,
-                     live_path = en_path && 4 < first_fail, live_goal = en_goal && 5 < first_fail;
-          if (!(live_obs || live_gf || live_al || live_path || live_goal)) break;
+          if (first_fail <= min_order) break;
           const int te = TABLES ? t_ith * K + step : 0;
           if (TABLES) pth = s_th[te];
           const double x = px, y = py, th = pth;
@@ -1796,19 +1837,32 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           }
           uint32_t cx = 0, cy = 0;
           const bool ok_c = w2m(x, y, cx, cy);
+          // ---- screen: on every point but the last a critic can only FAIL (its value is overwritten: aggregation
+          // Last; with sum_scores the obstacle critic adds the point's cost, which is 0 when everything in reach is
+          // free).  One 16-byte LDS read says whether any critic could fail here; if none can, the point is done.
+          bool screened = false;
+          if (screen_on && step != num_steps - 1 && ok_c && inWin((int)cx, (int)cy)) {
+            const int lxw = (int)cx - wx0;
+            const uint4 fb = reinterpret_cast<const uint4*>(s_fb)[((int)cy - wy0) * nw + (lxw >> 5)];
+            const uint32_t any = (fb.x & scr_x) | (fb.y & scr_y) | (fb.z & scr_z) | (fb.w & scr_w);
+            screened = !((any >> (lxw & 31)) & 1u) && (cx - fwd_lo < fwd_nx) && (cy - fwd_lo < fwd_ny);
+          }
+          if (!screened) {
+          const bool live_obs = en_obs && 1 < first_fail, live_gf = en_gf && 2 < first_fail, live_al = en_al && 3 < first_fail,
+                     live_path = en_path && 4 < first_fail, live_goal = en_goal && 5 < first_fail;
           // all_free: every cell the footprint can touch is FREE_SPACE -> the step costs exactly 0.
           // Without sum_scores only the LAST point's footprint cost survives (obstacle_cost_function.cpp:
           // cost = f_cost), the earlier points only have to be legal: no failing cell in reach is enough.
           bool all_free = false;
-          if (live_obs && ok_c && nfp >= 3 && inWin((int)cx, (int)cy) && !(pl.debug & 4u)) {
+          if (live_obs && ok_c && nfp >= 3 && inWin((int)cx, (int)cy)) {
             const int lxw = (int)cx - wx0;
-            const uint2 fb = reinterpret_cast<const uint2*>(s_fb)[((int)cy - wy0) * nw + (lxw >> 5)];
+            const uint2 fb = reinterpret_cast<const uint2*>(s_fb)[2 * (((int)cy - wy0) * nw + (lxw >> 5))];
             const bool not_free = (fb.x >> (lxw & 31)) & 1u, can_fail = (fb.y >> (lxw & 31)) & 1u;
             all_free = !not_free || (!c.sum_scores && step != num_steps - 1 && !can_fail);
           }
           if (live_obs && all_free) {
             v_obs = c.sum_scores ? v_obs + 0.0 : 0.0;
-          } else if (live_obs && !(pl.debug & 2u)) {
+          } else if (live_obs) {
             double f_cost = 0.0;
             bool bad = !ok_c;  // CostmapModel::footprintCost: centre off the map -> -1
             if (!bad) {
@@ -1946,7 +2000,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
             } else {
               const uint32_t cell = cy * g.nx + cx;
               if (en_path && 4 < first_fail) {
-                const uint32_t d = (pl.debug & 1u) ? 7u : dpath[cell];
+                const uint32_t d = dpath[cell];
                 if (d == N_obst) {
                   fail_code = -3.0;
                   first_fail = 4;
@@ -1957,7 +2011,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
                   v_path = d;
               }
               if (en_goal && 5 < first_fail) {
-                const uint32_t d = (pl.debug & 1u) ? 9u : dgoal[cell];
+                const uint32_t d = dgoal[cell];
                 if (d == N_obst) {
                   fail_code = -3.0;
                   first_fail = 5;
@@ -1990,6 +2044,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
               if (en_al && 3 < first_fail) v_al = dpath[cell];
             }
           }
+          }  // !screened
           // ---- advance (computeNewPositions :253-260): fp64 on fp32 state, rounded back to fp32
           if (continued) {
             float t1[3];
@@ -2093,7 +2148,7 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_explicit(PlannerDev pl,
   score_body<true, false, kScoreThreads>(pl, first, explicit_sample);
 }
 
-size_t score_window_bytes(uint32_t win) {  // costmap window + the two dilated bitmaps (raw/result + horizontal pass)
+size_t score_window_bytes(uint32_t win) {  // costmap window + the four per-cell screens
   return (((size_t)win * win + 15) & ~(size_t)15) + score_bits_bytes((int)win);
 }
 size_t score_table_bytes(const PlannerDev& pl) {
@@ -2104,25 +2159,25 @@ size_t score_prep_bytes(const PlannerDev& pl) {  // the LDS image k_score_prep* 
 }
 uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s) {
   PlannerDev pl = pl_in;
-  size_t extra_lds = 0;
-  // timing ablations / occupancy experiments only (tools/probe_score.py); read once, all off in product use
-  static const uint32_t dbg_bits = getenv("NAVGPU_DEBUG_SCORE") ? (uint32_t)atoi(getenv("NAVGPU_DEBUG_SCORE")) : 0u;
-  static const size_t dbg_lds = getenv("NAVGPU_DEBUG_SCORE_LDS") ? (size_t)atoi(getenv("NAVGPU_DEBUG_SCORE_LDS")) : 0;
+  // A/B switch for the per-(v_theta, step) tables (tools/probe_score.py); read once, off in product use
   static const bool dbg_no_tables = getenv("NAVGPU_DEBUG_NO_TABLES") && atoi(getenv("NAVGPU_DEBUG_NO_TABLES"));
-  pl.debug = dbg_bits;
-  extra_lds = dbg_lds;
   if (dbg_no_tables) pl.use_tables = 0;
-  const size_t win_bytes = score_window_bytes(pl.win) + extra_lds;
+  const size_t win_bytes = score_window_bytes(pl.win);
+  const size_t scratch = score_scratch_bytes((int)pl.win);  // only where the image is built
+  pl.tab_bytes = 0;
   if (explicit_sample) {
-    hipLaunchKernelGGL(k_score_explicit, dim3(1, count), dim3(kScoreThreads), win_bytes, s, pl, first, explicit_sample);
+    const size_t lds_x = win_bytes + scratch;
+    if (lds_x > 48 * 1024) hipFuncSetAttribute((const void*)k_score_explicit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x);
+    hipLaunchKernelGGL(k_score_explicit, dim3(1, count), dim3(kScoreThreads), lds_x, s, pl, first, explicit_sample);
     return 1;
   }
-  pl.prep_bytes = (uint32_t)score_prep_bytes(pl);  // (after the debug overrides of use_tables)
+  pl.prep_bytes = (uint32_t)score_prep_bytes(pl);  // (after the debug override of use_tables)
   if (pl.use_tables) {
+    pl.tab_bytes = (uint32_t)score_table_bytes(pl);
     const size_t lds = win_bytes + score_table_bytes(pl);
     const uint32_t blocks = (pl.max_samples + kScoreThreadsTab - 1) / kScoreThreadsTab;
-    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_score_prep_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_score_prep_tab, dim3(1, count), dim3(kScoreThreadsTab), lds, s, pl, first);
+    if (lds + scratch > 48 * 1024) hipFuncSetAttribute((const void*)k_score_prep_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + scratch));
+    hipLaunchKernelGGL(k_score_prep_tab, dim3(1, count), dim3(kScoreThreadsTab), lds + scratch, s, pl, first);
 #define NAVGPU_SCORE_TAB(C)                                                                                              \
   {                                                                                                                      \
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_score_tab<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -2135,8 +2190,8 @@ uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, c
 #undef NAVGPU_SCORE_TAB
     return blocks;
   }
-  if (win_bytes > 48 * 1024) hipFuncSetAttribute((const void*)k_score_prep_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes);
-  hipLaunchKernelGGL(k_score_prep_gen, dim3(1, count), dim3(kScoreThreads), win_bytes, s, pl, first);
+  if (win_bytes + scratch > 48 * 1024) hipFuncSetAttribute((const void*)k_score_prep_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(win_bytes + scratch));
+  hipLaunchKernelGGL(k_score_prep_gen, dim3(1, count), dim3(kScoreThreads), win_bytes + scratch, s, pl, first);
 #define NAVGPU_SCORE_GEN(C)                                                                                                    \
   {                                                                                                                            \
     if (win_bytes > 48 * 1024) hipFuncSetAttribute((const void*)k_score_gen<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes); \
