@@ -1023,6 +1023,16 @@ int navgpu_planner_wavefront_boxes(navgpu_fleet* f, uint32_t first, uint32_t cou
   return NAVGPU_OK;
 }
 
+#ifdef NAVGPU_SCORE_STATS  // experiment builds only: the LDS image k_score_prep* stored for one robot
+extern "C" int navgpu_debug_prep_image(navgpu_fleet* f, uint32_t inst, uint8_t* out, uint32_t cap, uint32_t* win, uint32_t* bytes) {
+  waitStream(f->stream);
+  const uint32_t n = std::min<uint32_t>(cap, f->pl.prep_stride);
+  hipMemcpy(out, f->pl.prep + (size_t)inst * f->pl.prep_stride, n, hipMemcpyDeviceToHost);
+  *win = f->pl.win;
+  *bytes = n;
+  return 0;
+}
+#endif
 int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
   if (!f->planner_configured || !f->planner_staged) return NAVGPU_ERR_STATE;

@@ -1461,6 +1461,15 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
 // The costmap window the trajectories can reach is staged in LDS; cells outside it (never needed
 // with a correctly sized window) fall back to a global load, so results never depend on it.
 // ------------------------------------------------------------------------------------------------
+#if defined(NAVGPU_SCORE_TIMING) && !defined(NAVGPU_SCORE_STATS)  // phase stamps only (no counters in the loop)
+__device__ unsigned long long g_score_stats[24];
+#endif
+#ifdef NAVGPU_SCORE_STATS  // experiment builds only (make EXTRA=-DNAVGPU_SCORE_STATS, tools/probe_score_stats.py)
+__device__ unsigned long long g_score_stats[24];  // lane-steps, unscreened lanes, wave-steps, waves with an unscreened lane, walk lanes, waves with a walk, last-step waves
+#define SCORE_STAT(i, v) atomicAdd(&g_score_stats[i], (unsigned long long)(v))
+#else
+#define SCORE_STAT(i, v)
+#endif
 struct ScoreOut {
   double total;
   int status;
@@ -1495,6 +1504,9 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
 
   const uint32_t inst = first + blockIdx.y;
   const uint32_t tid = threadIdx.x;
+#ifdef NAVGPU_SCORE_TIMING
+  const unsigned long long ts0 = wall_clock64();
+#endif
   const navgpu_dwa_config& c = pl.cfg;
   const Geom g = geomOf(pl, inst);
   const navgpu_robot_state st = pl.state[inst];
@@ -1680,6 +1692,9 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     __syncthreads();
   }
 
+#ifdef NAVGPU_SCORE_TIMING
+  const unsigned long long ts1 = wall_clock64();
+#endif
   // NOTE: the LDS read is unconditional (clamped index) and the global fallback sits in its own
   // rarely-taken branch; a `cond ? lds[i] : global[j]` form makes hipcc merge both into one FLAT load.
   auto inWin = [&](int x, int y) { return (unsigned)(x - wx0) < (unsigned)win && (unsigned)(y - wy0) < (unsigned)win; };
@@ -1844,9 +1859,35 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           if (screen_on && step != num_steps - 1 && ok_c && inWin((int)cx, (int)cy)) {
             const int lxw = (int)cx - wx0;
             const uint4 fb = reinterpret_cast<const uint4*>(s_fb)[((int)cy - wy0) * nw + (lxw >> 5)];
-            const uint32_t any = (fb.x & scr_x) | (fb.y & scr_y) | (fb.z & scr_z) | (fb.w & scr_w);
+            // (a critic that has already failed, or that follows one that has, cannot change the outcome any more)
+            const uint32_t any = (fb.x & scr_x) | (fb.y & scr_y) | (first_fail > 4 ? fb.z & scr_z : 0u) | (first_fail > 5 ? fb.w & scr_w : 0u);
             screened = !((any >> (lxw & 31)) & 1u) && (cx - fwd_lo < fwd_nx) && (cy - fwd_lo < fwd_ny);
+#ifdef NAVGPU_SCORE_STATS
+            SCORE_STAT(8, (fb.y >> (lxw & 31)) & 1u);
+            SCORE_STAT(9, (fb.z >> (lxw & 31)) & 1u);
+            SCORE_STAT(10, (fb.w >> (lxw & 31)) & 1u);
+            SCORE_STAT(11, !((cx - fwd_lo < fwd_nx) && (cy - fwd_lo < fwd_ny)));
+#endif
           }
+#ifdef NAVGPU_SCORE_STATS
+          else if (step != num_steps - 1) {
+            SCORE_STAT(12, !ok_c);
+            SCORE_STAT(13, ok_c && !inWin((int)cx, (int)cy));
+            SCORE_STAT(14, !screen_on);
+          }
+#endif
+#ifdef NAVGPU_SCORE_STATS
+          {
+            const unsigned long long act = __ballot(true), uns = __ballot(!screened);
+            if (__ffsll((long long)act) - 1 == (int)(tid & 63)) {
+              SCORE_STAT(0, __popcll(act));
+              SCORE_STAT(1, __popcll(uns));
+              SCORE_STAT(2, 1);
+              SCORE_STAT(3, uns != 0);
+              SCORE_STAT(6, step == num_steps - 1);
+            }
+          }
+#endif
           if (!screened) {
           const bool live_obs = en_obs && 1 < first_fail, live_gf = en_gf && 2 < first_fail, live_al = en_al && 3 < first_fail,
                      live_path = en_path && 4 < first_fail, live_goal = en_goal && 5 < first_fail;
@@ -1863,6 +1904,15 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           if (live_obs && all_free) {
             v_obs = c.sum_scores ? v_obs + 0.0 : 0.0;
           } else if (live_obs) {
+#ifdef NAVGPU_SCORE_STATS
+            {
+              const unsigned long long wk = __ballot(ok_c && nfp >= 3);
+              if (__ffsll((long long)__ballot(true)) - 1 == (int)(tid & 63)) {
+                SCORE_STAT(4, __popcll(wk));
+                SCORE_STAT(5, wk != 0);
+              }
+            }
+#endif
             double f_cost = 0.0;
             bool bad = !ok_c;  // CostmapModel::footprintCost: centre off the map -> -1
             if (!bad) {
@@ -2093,6 +2143,9 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     }
   }
 
+#ifdef NAVGPU_SCORE_TIMING
+  const unsigned long long ts2 = wall_clock64();
+#endif
   // ---- workgroup argmin (lowest index wins ties == first strict minimum of the sequential loop)
   const bool valid = in_range && status == NAVGPU_SAMPLE_SCORED && total >= 0.0;
   double bc = valid ? total : 1.0e300;
@@ -2114,6 +2167,17 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     atomicAdd(&s_cnt[1], __popcll(m_valid));
   }
   __syncthreads();
+#ifdef NAVGPU_SCORE_TIMING
+  if (PREP == 2 && (tid & 63) == 0) {
+    const unsigned long long ts3 = wall_clock64();
+    atomicAdd(&g_score_stats[16], ts1 - ts0);  // image load, per wave
+    atomicAdd(&g_score_stats[17], ts2 - ts1);  // sample setup + rollout, per wave
+    atomicAdd(&g_score_stats[18], ts3 - ts2);  // reduction + wait for the slowest wave of the workgroup
+    atomicAdd(&g_score_stats[19], 1ull);
+    if (tid == 0) atomicAdd(&g_score_stats[20], ts3 - ts0);  // workgroup residence
+    if (tid == 0) atomicAdd(&g_score_stats[21], 1ull);
+  }
+#endif
   if (tid == 0) {
     for (int w = 1; w < THREADS / 64; ++w)
       if (s_rc[w] < bc || (s_rc[w] == bc && s_ri[w] < bi)) {
@@ -2437,4 +2501,14 @@ __global__ __launch_bounds__(64) void k_stage_poses(PoseChunk c) {
 }
 void launch_stage_poses(const PoseChunk& c, hipStream_t s) { hipLaunchKernelGGL(k_stage_poses, dim3(1), dim3(64), 0, s, c); }
 
+#if defined(NAVGPU_SCORE_STATS) || defined(NAVGPU_SCORE_TIMING)
+extern "C" int navgpu_debug_score_stats(unsigned long long* out8, int reset) {
+  if (out8) hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_score_stats), sizeof(unsigned long long) * 24);
+  if (reset) {
+    unsigned long long z[24] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_score_stats), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 }  // namespace navgpu
