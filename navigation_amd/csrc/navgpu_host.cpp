@@ -661,27 +661,37 @@ int navgpu_costmap_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
   return NAVGPU_OK;  // copies stay in flight on the fleet's stream; the kernels are ordered behind them
 }
 
+// rolling window: the origins staged by navgpu_costmap_stage are applied to the resident grids (Costmap2D::updateOrigin,
+// costmap_2d.cpp:264-313; VoxelLayer::updateOrigin, voxel_layer.cpp:385-440) before anything reads or writes them
+static int applyPendingShift(navgpu_fleet* f, uint32_t first, uint32_t count) {
+  CostmapDev& cm = f->cm;
+  if (!(f->desc.rolling_window && f->shift_pending)) return NAVGPU_OK;
+  if (first != f->shift_first || count != f->shift_count) return NAVGPU_ERR_STATE;
+  // the ping-pong swap is fleet-wide, so a rolling fleet is staged and updated as a whole
+  if (first != 0 || count != f->desc.n_instances) return NAVGPU_ERR_INVALID;
+  launch_shift_u8(cm.master, cm.master_alt, cm, first, count, cm.master_default, f->stream);
+  std::swap(cm.master, cm.master_alt);
+  f->pl.master = cm.master;
+  if (cm.obst) {
+    launch_shift_u8(cm.obst, cm.obst_alt, cm, first, count, cm.obstacle_default, f->stream);
+    std::swap(cm.obst, cm.obst_alt);
+  }
+  if (cm.voxel) {
+    launch_shift_u32(cm.voxel, cm.voxel_alt, cm, first, count, 0x0000FFFFu, f->stream);
+    std::swap(cm.voxel, cm.voxel_alt);
+  }
+  f->shift_pending = false;
+  return NAVGPU_OK;
+}
+
 int navgpu_costmap_update(navgpu_fleet* f, uint32_t first, uint32_t count) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
   f->touchInputs(first, count);
   CostmapDev& cm = f->cm;
   if ((cm.layers & NAVGPU_LAYER_INFLATION) && !f->inflation_configured) return NAVGPU_ERR_STATE;
-  if (f->desc.rolling_window && f->shift_pending) {
-    if (first != f->shift_first || count != f->shift_count) return NAVGPU_ERR_STATE;
-    // the ping-pong swap is fleet-wide, so a rolling fleet is staged and updated as a whole
-    if (first != 0 || count != f->desc.n_instances) return NAVGPU_ERR_INVALID;
-    launch_shift_u8(cm.master, cm.master_alt, cm, first, count, cm.master_default, f->stream);
-    std::swap(cm.master, cm.master_alt);
-    f->pl.master = cm.master;
-    if (cm.obst) {
-      launch_shift_u8(cm.obst, cm.obst_alt, cm, first, count, cm.obstacle_default, f->stream);
-      std::swap(cm.obst, cm.obst_alt);
-    }
-    if (cm.voxel) {
-      launch_shift_u32(cm.voxel, cm.voxel_alt, cm, first, count, 0x0000FFFFu, f->stream);
-      std::swap(cm.voxel, cm.voxel_alt);
-    }
-    f->shift_pending = false;
+  {
+    int rc = applyPendingShift(f, first, count);
+    if (rc) return rc;
   }
   PROFILED(f, NAVGPU_K_OBSTACLE, launch_obstacle(cm, first, count, nullptr, 0, f->stream));
   PROFILED(f, NAVGPU_K_MERGE, launch_merge(cm, first, count, nullptr, f->stream));
@@ -716,6 +726,10 @@ int navgpu_inflate(navgpu_fleet* f, uint32_t first, uint32_t count, const int32_
 int navgpu_obstacle_update_bounds(navgpu_fleet* f, uint32_t first, uint32_t count, double* bounds) {
   if (!f || !bounds || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
   if (!f->cm.obst) return NAVGPU_ERR_STATE;
+  {
+    int rc = applyPendingShift(f, first, count);  // ObstacleLayer::updateBounds :344-345: updateOrigin first
+    if (rc) return rc;
+  }
   HIP_TRY(hipMemcpyAsync(f->d_bounds_tmp, bounds, sizeof(double) * 4 * count, hipMemcpyHostToDevice, f->stream));
   PROFILED(f, NAVGPU_K_OBSTACLE, launch_obstacle(f->cm, first, count, f->d_bounds_tmp, 1, f->stream));
   HIP_TRY(hipMemcpyAsync(bounds, f->d_bounds_tmp, sizeof(double) * 4 * count, hipMemcpyDeviceToHost, f->stream));

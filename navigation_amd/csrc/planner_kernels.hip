@@ -1688,7 +1688,24 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       for (uint32_t i = tid; i < n16; i += blockDim.x) img[i] = lds[i];
       return;
     }
-    for (uint32_t i = tid; i < n16; i += blockDim.x) lds[i] = img[i];
+    if (!TABLES) {
+      for (uint32_t i = tid; i < n16; i += blockDim.x) lds[i] = img[i];
+    } else {
+      // window + screens, and of the tables only the v_theta rows this workgroup's samples use (lanes are
+      // v_theta-major: 512 lanes of a 33 x 33 (vx, vy) grid span two of the 17 rows), at their usual place
+      const int nxy = max(cnt[0] * cnt[1], 1), nth_all = max(cnt[2], 1);
+      const int r0 = min((int)(blockIdx.x * blockDim.x) / nxy, nth_all - 1);
+      const int r1 = min((int)(blockIdx.x * blockDim.x + blockDim.x - 1) / nxy, nth_all - 1);
+      const int n16w = (int)((win_bytes + score_bits_bytes(win)) >> 4);
+      const int o_trig = n16w + r0 * K * 2, n_trig = (r1 - r0 + 1) * K * 2;                             // 32 B per entry
+      const int o_rot = n16w + (int)pl.tab_nth * K * 2 + r0 * K * tnfp, n_rot = (r1 - r0 + 1) * K * tnfp;  // 16 B per vertex
+      for (int i = tid; i < n16w + n_trig + n_rot; i += blockDim.x) {
+        const int j = i < n16w ? i : i < n16w + n_trig ? o_trig + (i - n16w) : o_rot + (i - n16w - n_trig);
+        lds[j] = img[j];
+      }
+      const float* g_th = reinterpret_cast<const float*>(img + n16w + (size_t)pl.tab_nth * K * (2 + tnfp));
+      for (int i = r0 * K + (int)tid; i < (r1 + 1) * K; i += blockDim.x) s_th[i] = g_th[i];
+    }
     __syncthreads();
   }
 
