@@ -531,7 +531,10 @@ __global__ __launch_bounds__(256) void k_obstacle(CostmapDev cm, uint32_t first,
       bounds_io_out[4 * blockIdx.x + 1] = b.min_y;
       bounds_io_out[4 * blockIdx.x + 2] = b.max_x;
       bounds_io_out[4 * blockIdx.x + 3] = b.max_y;
-      s_box_valid = 0;
+      // layer-granular use (costmap_2d::Layer adapters): the footprint polygon is cleared here, ahead of the
+      // navgpu_obstacle_update_costs that the host's LayeredCostmap issues next (ObstacleLayer::updateCosts :431-434;
+      // updateFootprint has put the polygon into the bounds, so that call always follows)
+      s_box_valid = 1;
     } else {
       if (cm.layers & NAVGPU_LAYER_INFLATION) {  // InflationLayer::updateBounds
         if (st->need_reinflation) {

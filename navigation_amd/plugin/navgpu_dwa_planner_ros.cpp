@@ -128,8 +128,10 @@ bool DWAPlannerROS::uploadCostmap() {
          navgpu_grid_upload(fleet_, NAVGPU_GRID_MASTER, 0, 1, cm->getCharMap()) == NAVGPU_OK;
 }
 
-bool DWAPlannerROS::gpuFindBestPath(const tf::Stamped<tf::Pose>& pose, const tf::Stamped<tf::Pose>& vel,
-                                    const std::vector<geometry_msgs::PoseStamped>& plan, navgpu_plan_result* out) {
+bool DWAPlannerROS::gpuStage(const tf::Stamped<tf::Pose>& pose, const tf::Stamped<tf::Pose>& vel,
+                             const std::vector<geometry_msgs::PoseStamped>& plan) {
+  // what every cycle does before it branches (dwa_planner_ros.cpp:268-274): the costmap the planner borrows, the
+  // footprint, and DWAPlanner::updatePlanAndLocalCosts (target poses, nose goal, alignment switch).  No wavefront runs here.
   std::vector<geometry_msgs::Point> fp = costmap_ros_->getRobotFootprint();
   std::vector<double> fxy;
   for (size_t i = 0; i < fp.size(); ++i) { fxy.push_back(fp[i].x); fxy.push_back(fp[i].y); }
@@ -139,15 +141,27 @@ bool DWAPlannerROS::gpuFindBestPath(const tf::Stamped<tf::Pose>& pose, const tf:
   st.pos[0] = pose.getOrigin().getX(); st.pos[1] = pose.getOrigin().getY(); st.pos[2] = tf::getYaw(pose.getRotation());
   st.vel[0] = vel.getOrigin().getX();  st.vel[1] = vel.getOrigin().getY();  st.vel[2] = tf::getYaw(vel.getRotation());
   st.plan_first = 0; st.plan_count = plan.size();
-  return uploadCostmap() && navgpu_set_footprint(fleet_, 0, 1, fxy.data(), fp.size()) == NAVGPU_OK &&
-         navgpu_planner_stage(fleet_, 0, 1, &st, pxy.data(), plan.size()) == NAVGPU_OK &&
-         navgpu_planner_cycle(fleet_, 0, 1) == NAVGPU_OK && navgpu_planner_results(fleet_, 0, 1, out) == NAVGPU_OK;
+  staged_ = st;
+  return uploadCostmap() && navgpu_set_footprint(fleet_, 0, 1, fxy.empty() ? NULL : &fxy[0], fp.size()) == NAVGPU_OK &&
+         navgpu_planner_stage(fleet_, 0, 1, &st, &pxy[0], plan.size()) == NAVGPU_OK;
+}
+
+bool DWAPlannerROS::gpuFindBestPath(navgpu_plan_result* out) {  // DWAPlanner::findBestPath (dwa_planner.cpp:292-371)
+  return navgpu_planner_cycle(fleet_, 0, 1) == NAVGPU_OK && navgpu_planner_results(fleet_, 0, 1, out) == NAVGPU_OK;
 }
 
 bool DWAPlannerROS::gpuCheckTrajectory(Eigen::Vector3f pos, Eigen::Vector3f vel, Eigen::Vector3f vs) {
-  // LatchedStopRotateController's collision oracle (dwa_planner_ros.cpp:281-285, dwa_planner.cpp:213-237);
-  // the state staged by the last gpuFindBestPath/stage call of this cycle is reused
-  (void)pos; (void)vel;
+  // LatchedStopRotateController's collision oracle (dwa_planner_ros.cpp:281-285 -> DWAPlanner::checkTrajectory,
+  // dwa_planner.cpp:213-237): scores ONE sample from (pos, vel) against the MapGrids of the last findBestPath - the
+  // reference does not refresh them here either.  The controller passes the current pose and odometry velocity
+  // (latched_stop_rotate_controller.cpp:126-131, 167-172); should they differ from what this cycle staged, they are re-staged.
+  bool same = true;
+  for (int k = 0; k < 3; ++k) same = same && staged_.pos[k] == pos[k] && staged_.vel[k] == vel[k];
+  if (!same) {
+    float p[3] = {pos[0], pos[1], pos[2]}, v0[3] = {vel[0], vel[1], vel[2]};
+    if (navgpu_planner_stage_poses(fleet_, 0, 1, p, v0) != NAVGPU_OK) return false;
+    for (int k = 0; k < 3; ++k) { staged_.pos[k] = pos[k]; staged_.vel[k] = vel[k]; }
+  }
   float v[3] = {vs[0], vs[1], vs[2]};
   int32_t ok = 0;
   return navgpu_planner_check_trajectory(fleet_, 0, v, &ok) == NAVGPU_OK && ok;
@@ -160,20 +174,16 @@ bool DWAPlannerROS::computeVelocityCommands(geometry_msgs::Twist& cmd_vel) {  //
   if (transformed_plan.empty()) return false;
   tf::Stamped<tf::Pose> robot_vel;
   odom_helper_.getRobotVel(robot_vel);
+  if (!gpuStage(current_pose_, robot_vel, transformed_plan)) return false;  // dp_->updatePlanAndLocalCosts (:274)
 
-  if (latchedStopRotateController_.isPositionReached(&planner_util_, current_pose_)) {
-    // stage this cycle's state so checkTrajectory sees it, then run the reference controller (f-1)
-    navgpu_plan_result unused;
-    std::vector<geometry_msgs::Point> fp = costmap_ros_->getRobotFootprint();
-    (void)fp;
-    gpuFindBestPath(current_pose_, robot_vel, transformed_plan, &unused);  // also refreshes the MapGrids
+  if (latchedStopRotateController_.isPositionReached(&planner_util_, current_pose_)) {  // :276-288
     base_local_planner::LocalPlannerLimits limits = planner_util_.getCurrentLimits();
     return latchedStopRotateController_.computeVelocityCommandsStopRotate(
         cmd_vel, limits.getAccLimits(), sim_period_, &planner_util_, odom_helper_, current_pose_,
         boost::bind(&DWAPlannerROS::gpuCheckTrajectory, this, _1, _2, _3));
   }
   navgpu_plan_result r;
-  if (!gpuFindBestPath(current_pose_, robot_vel, transformed_plan, &r)) return false;
+  if (!gpuFindBestPath(&r)) return false;
   cmd_vel.linear.x = r.drive[0];   // dwa_planner_ros.cpp:210-212
   cmd_vel.linear.y = r.drive[1];
   cmd_vel.angular.z = r.drive[2];  // yaw of createQuaternionFromYaw(thetav) == thetav

@@ -34,8 +34,9 @@ class DWAPlannerROS : public nav_core::BaseLocalPlanner {
  private:
   void reconfigureCB(dwa_local_planner::DWAPlannerConfig& config, uint32_t level);
   bool uploadCostmap();
-  bool gpuFindBestPath(const tf::Stamped<tf::Pose>& pose, const tf::Stamped<tf::Pose>& vel,
-                       const std::vector<geometry_msgs::PoseStamped>& local_plan, navgpu_plan_result* out);
+  bool gpuStage(const tf::Stamped<tf::Pose>& pose, const tf::Stamped<tf::Pose>& vel,
+                const std::vector<geometry_msgs::PoseStamped>& local_plan);
+  bool gpuFindBestPath(navgpu_plan_result* out);
   bool gpuCheckTrajectory(Eigen::Vector3f pos, Eigen::Vector3f vel, Eigen::Vector3f vel_samples);
 
   tf::TransformListener* tf_;
@@ -48,6 +49,7 @@ class DWAPlannerROS : public nav_core::BaseLocalPlanner {
   bool setup_, initialized_;
   navgpu_fleet* fleet_;
   navgpu_dwa_config cfg_;
+  navgpu_robot_state staged_;  // pose / velocity of the last stage
   double sim_period_;
   tf::Stamped<tf::Pose> current_pose_;
   std::vector<geometry_msgs::PoseStamped> last_local_plan_;

@@ -388,3 +388,67 @@ def test_stage_poses_equals_full_stage(nav, orc):
     b = fl.wavefront_boxes()
     assert b.shape == (nI, 4) and (b[:, 0] <= b[:, 1]).all() and (b[:, 2] <= b[:, 3]).all()
     fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# The call sequence of the costmap_2d::Layer adapters (navigation_amd/plugin/navgpu_layers.cpp, LayerBridge) on a
+# ROLLING local costmap: stage -> navgpu_obstacle_update_bounds (shifts the resident layer grid, clears, marks) ->
+# upload the host's master -> navgpu_obstacle_update_costs -> navgpu_inflate -> download.  The host side of
+# LayeredCostmap::updateMap (updateOrigin of the master, resetMap of the box, layered_costmap.cpp:86-137) is done in numpy.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("voxel", [False, True])
+def test_layer_adapter_sequence_rolling(nav, orc, voxel):
+    from navigation_amd import synth
+    N = L(nav)
+    n = 120
+    insc = synth.inscribed_radius(synth.FOOTPRINT)
+    layers = (N.LAYER_VOXEL if voxel else N.LAYER_OBSTACLE) | N.LAYER_INFLATION
+    fl = nav.Fleet(1, n, n, synth.RES, layers=layers, track_unknown=True, max_points=720, max_observations=1, rolling_window=True)
+    fl.configure_obstacle()
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, insc)
+    o = orc.LayeredCostmap(True)
+    o.resize(n, n, synth.RES, 0, 0)
+    o.set_rolling(True)
+    o.set_footprint(synth.FOOTPRINT)
+    o.add_voxel() if voxel else o.add_obstacle()
+    o.add_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, exact=True)
+    o.set_footprint(synth.FOOTPRINT)
+    world = synth.make_instance(400, 77)
+    host_master = np.full((n, n), NOINFO, np.uint8)  # LayeredCostmap(track_unknown): default NO_INFORMATION
+    origin = np.zeros(2)
+    for cyc in range(6):
+        x, y, yaw = 3.0 + 0.41 * cyc + (7.0 if cyc == 4 else 0.0), 2.5 + 0.23 * cyc, 0.3 * cyc
+        inst = dict(world)
+        inst["pos"] = np.array([x, y, yaw], np.float32)
+        pts = synth.laser_scan(inst, cyc, max_range=4.0, z=0.3, z_jitter=1.0 if voxel else None)
+        org = (float(x), float(y), 0.3)
+        o.clear_observations()
+        o.add_observation(pts, origin=org, obstacle_range=2.5, raytrace_range=3.0)
+        o.update_map(float(x), float(y), float(yaw))
+        # --- the adapter's updateBounds
+        fl.stage_observations([[float(x), float(y), float(yaw)]],
+                              [dict(instance=0, points=pts, origin=org, obstacle_range=2.5, raytrace_range=3.0)])
+        fl.obstacle_update_bounds([[1e30, 1e30, -1e30, -1e30]])
+        new_origin = fl.origins()[0]
+        assert np.array_equal(new_origin, o.origin()), ("origin", cyc)
+        # --- host side of LayeredCostmap::updateMap: master.updateOrigin + resetMap(box)
+        cox, coy = int(round((new_origin[0] - origin[0]) / synth.RES)), int(round((new_origin[1] - origin[1]) / synth.RES))
+        shifted = np.full((n, n), NOINFO, np.uint8)
+        ys, xs = np.mgrid[0:n, 0:n]
+        sy, sx = ys + coy, xs + cox
+        ok = (sy >= 0) & (sy < n) & (sx >= 0) & (sx < n)
+        shifted[ys[ok], xs[ok]] = host_master[sy[ok], sx[ok]]
+        host_master, origin = shifted, new_origin.copy()
+        x0, xn, y0, yn = [int(v) for v in o.bounds()]
+        host_master[y0:yn, x0:xn] = NOINFO
+        # --- the adapter's updateCosts
+        fl.upload(N.GRID_MASTER, host_master)
+        fl.obstacle_update_costs([[x0, y0, xn, yn]])
+        fl.inflate(boxes=[[x0, y0, xn, yn]])
+        host_master = fl.master()[0]
+        assert np.array_equal(fl.download(N.GRID_OBSTACLE)[0], o.layer(2)), ("layer grid", cyc)
+        if voxel:
+            assert np.array_equal(fl.download(N.GRID_VOXEL)[0], o.voxels()), ("voxel columns", cyc)
+        assert np.array_equal(host_master, o.master()), ("master", cyc)
+    fl.close()
