@@ -112,7 +112,12 @@ typedef struct {
  * (LayeredCostmap::getInscribedRadius, set through InflationLayer::onFootprintChanged) */
 typedef struct {
   int32_t enabled;
-  int32_t reserved;
+  int32_t priority_queue_order; /* 0 (default): the order-independent windowed exact Euclidean transform - every cell takes
+                                   the cost of its nearest LETHAL cell - on the parallel kernels.  1: InflationLayer::updateCosts
+                                   as written (inflation_layer.cpp:226-293), byte for byte: a cell keeps the source carried by
+                                   whichever neighbour std::priority_queue popped first (ties in libstdc++ heap order); one
+                                   sequential walk per robot, far slower.  The two differ in ~6e-5 of the cells of a 400x400
+                                   map at 1 % obstacles; 0 is never lower than 1 */
   double inflation_radius;
   double cost_scaling_factor;
   double inscribed_radius;

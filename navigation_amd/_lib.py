@@ -41,7 +41,7 @@ class ObstacleParams(C.Structure):
 
 
 class InflationParams(C.Structure):
-    _fields_ = [("enabled", C.c_int32), ("reserved", C.c_int32), ("inflation_radius", C.c_double),
+    _fields_ = [("enabled", C.c_int32), ("priority_queue_order", C.c_int32), ("inflation_radius", C.c_double),
                 ("cost_scaling_factor", C.c_double), ("inscribed_radius", C.c_double)]
 
 

@@ -950,9 +950,122 @@ __global__ __launch_bounds__(256) void k_inflate_bits(CostmapDev cm, uint32_t fi
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_inflate_pq: InflationLayer::updateCosts + enqueue (plugins/inflation_layer.cpp:172-293) AS WRITTEN - the
+// reference-order mode (navgpu_inflation_params::priority_queue_order).  The reference's result depends on the
+// order in which std::priority_queue<CellData> pops equal distances (SURVEY 7 hard part 1), i.e. on libstdc++'s
+// push_heap / pop_heap (bits/stl_heap.h: __push_heap, __adjust_heap), which are deterministic sift-up / sift-down
+// loops; they are restated below verbatim in structure, with the reference's comparison (inflation_layer.h:82-85:
+// a < b  <=>  a.distance_ > b.distance_) on the reference's own keys (cached_distances_ = host hypot()).  The walk
+// is sequential by nature: one lane per robot does it, the other lanes of its wave only clear seen_.  Byte-identical
+// to the reference; two to three orders of magnitude slower than k_inflate_bits, and not what bench.py measures.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_inflate_pq(CostmapDev cm, uint32_t first, const int32_t* boxes) {
+  const uint32_t inst = first + blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  int min_i, min_j, max_i, max_j;
+  if (boxes) {
+    min_i = boxes[4 * blockIdx.x + 0];
+    min_j = boxes[4 * blockIdx.x + 1];
+    max_i = boxes[4 * blockIdx.x + 2];
+    max_j = boxes[4 * blockIdx.x + 3];
+  } else {
+    const InstCostmapState* st = cm.state + inst;
+    if (!st->box_valid) return;
+    min_i = st->box[0];
+    max_i = st->box[1];
+    min_j = st->box[2];
+    max_j = st->box[3];
+  }
+  uint8_t* master = cm.master + (size_t)inst * cm.cells_padded;
+  uint8_t* seen = cm.pq_seen + (size_t)inst * cm.cells_padded;
+  PqCell* heap = cm.pq_heap + (size_t)inst * cm.pq_cap;
+  const uint32_t size_x = cm.nx, size_y = cm.ny;
+  const int R = (int)cm.R;
+  const uint32_t n = cm.R + 2;  // stride of the caches
+  // memset(seen_, false, ...) (:198)
+  for (uint32_t i = tid * 16; i < cm.cells_padded; i += 64 * 16) *reinterpret_cast<uint4*>(seen + i) = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  if (tid != 0) return;
+  min_i = max(0, min_i - R);  // :204-212
+  min_j = max(0, min_j - R);
+  max_i = min((int)size_x, max_i + R);
+  max_j = min((int)size_y, max_j + R);
+  long len = 0;  // inflation_queue_.size()
+  // std::push_heap: __push_heap(first, holeIndex, topIndex = 0, value, comp)
+  auto pushHeap = [&](long hole, const PqCell& value) {
+    long parent = (hole - 1) / 2;
+    while (hole > 0 && heap[parent].distance > value.distance) {
+      heap[hole] = heap[parent];
+      hole = parent;
+      parent = (hole - 1) / 2;
+    }
+    heap[hole] = value;
+  };
+  auto enqueue = [&](uint32_t index, uint32_t mx, uint32_t my, uint32_t sx, uint32_t sy) {  // :277-293
+    if (seen[index]) return;
+    const uint32_t dx = mx > sx ? mx - sx : sx - mx, dy = my > sy ? my - sy : sy - my;
+    const double distance = cm.dist_lut[dx * n + dy];
+    if (distance > (double)cm.R) return;
+    if ((uint64_t)len >= cm.pq_cap) return;  // cannot happen: capacity = 4 pushes per cell + the seeds
+    PqCell c;
+    c.distance = distance;
+    c.index = index;
+    c.src_x = (uint16_t)sx;
+    c.src_y = (uint16_t)sy;
+    pushHeap(len++, c);  // priority_queue::push = push_back + push_heap
+  };
+  for (int j = min_j; j < max_j; j++)  // :214-226
+    for (int i = min_i; i < max_i; i++) {
+      const uint32_t index = (uint32_t)j * size_x + (uint32_t)i;
+      if (master[index] == kLethal) enqueue(index, i, j, i, j);
+    }
+  while (len > 0) {  // :228-266
+    const PqCell cur = heap[0];  // top()
+    // priority_queue::pop = pop_heap + pop_back; std::pop_heap acts only on more than one element
+    if (len > 1) {
+      const PqCell value = heap[len - 1];
+      const long l = len - 1;  // __adjust_heap(first, 0, l, value)
+      long hole = 0, child = 0;
+      while (child < (l - 1) / 2) {
+        child = 2 * (child + 1);
+        if (heap[child].distance > heap[child - 1].distance) child--;  // comp(first + secondChild, first + (secondChild - 1))
+        heap[hole] = heap[child];
+        hole = child;
+      }
+      if ((l & 1) == 0 && child == (l - 2) / 2) {
+        child = 2 * (child + 1);
+        heap[hole] = heap[child - 1];
+        hole = child - 1;
+      }
+      pushHeap(hole, value);
+    }
+    --len;
+    const uint32_t index = cur.index;
+    if (seen[index]) continue;
+    seen[index] = 1;
+    const uint32_t my = index / size_x, mx = index - my * size_x, sx = cur.src_x, sy = cur.src_y;
+    const uint32_t dx = mx > sx ? mx - sx : sx - mx, dy = my > sy ? my - sy : sy - my;
+    const uint8_t cost = cm.lut[dx * n + dy];  // costLookup (within the radius the table is cached_costs_)
+    const uint8_t old_cost = master[index];
+    if (old_cost == kNoInfo && cost >= kInscribed)
+      master[index] = cost;
+    else
+      master[index] = old_cost > cost ? old_cost : cost;
+    if (mx > 0) enqueue(index - 1, mx - 1, my, sx, sy);
+    if (my > 0) enqueue(index - size_x, mx, my - 1, sx, sy);
+    if (mx < size_x - 1) enqueue(index + 1, mx + 1, my, sx, sy);
+    if (my < size_y - 1) enqueue(index + size_x, mx, my + 1, sx, sy);
+  }
+}
+
 void launch_inflate(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s) {
   if (!cm.infl_enabled) return;
   const int R = (int)cm.R;
+  if (cm.infl_pq) {
+    hipLaunchKernelGGL(k_inflate_pq, dim3(count), dim3(64), 0, s, cm, first, boxes);
+    return;
+  }
   if (cm.lut2_ok && R >= 1 && R <= 14) {
     dim3 grid((cm.nx + kBX - 1) / kBX, (cm.ny + kBY - 1) / kBY, count);
     if (R == 11)

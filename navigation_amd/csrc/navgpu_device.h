@@ -38,6 +38,12 @@ struct ObsCsr {  // one observation, device form
   double obstacle_range, raytrace_range;
 };
 
+// CellData of inflation_layer.h:55-80 as the heap stores it (x_, y_ follow from index_)
+struct PqCell {
+  double distance;
+  uint32_t index;
+  uint16_t src_x, src_y;
+};
 struct CostmapDev {
   uint32_t nx, ny, cells, cells_padded;
   double res;
@@ -60,6 +66,12 @@ struct CostmapDev {
   uint8_t* lut;        // (R+2)^2 cost table with 0 where cached distance > R
   uint8_t* lut2;       // [256] cost by squared cell distance (k_inflate_bits), valid when lut2_ok
   int32_t lut2_ok;
+  // reference-order mode (navgpu_inflation_params::priority_queue_order): InflationLayer's own priority-queue walk
+  int32_t infl_pq;
+  double* dist_lut;    // (R+2)^2 cached_distances_ = hypot(i, j), host libm
+  uint8_t* pq_seen;    // [n][cells] seen_
+  PqCell* pq_heap;     // [n][pq_cap] the binary heap std::priority_queue<CellData> keeps
+  uint64_t pq_cap;
   InstCostmapState* state;  // [n]
   // staged cycle inputs
   double* pose;        // [n][3]

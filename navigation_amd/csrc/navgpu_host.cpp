@@ -469,6 +469,23 @@ int navgpu_inflation_configure(navgpu_fleet* f, const navgpu_inflation_params* p
     return NAVGPU_ERR_INVALID;
   }
   HIP_TRY(hipMemcpyAsync(cm.lut, lut.data(), lut.size(), hipMemcpyHostToDevice, f->stream));
+  // reference-order mode: cached_distances_ (hypot by this host's libm, as the reference builds them) and the
+  // priority queue's storage - every cell is pushed at most once by each of its four neighbours, plus once as a seed
+  std::vector<double> dist_lut((size_t)n * n);
+  cm.infl_pq = p->priority_queue_order ? 1 : 0;
+  if (cm.infl_pq) {
+    for (uint32_t i = 0; i < n; ++i)
+      for (uint32_t j = 0; j < n; ++j) dist_lut[(size_t)i * n + j] = hypot(i, j);
+    if (cm.nx > 65535 || cm.ny > 65535) return NAVGPU_ERR_CAPACITY;
+    int rc;
+    if (!cm.dist_lut && (rc = f->alloc(&cm.dist_lut, (size_t)66 * 66))) return rc;
+    if (!cm.pq_seen && (rc = f->alloc(&cm.pq_seen, (size_t)f->desc.n_instances * cm.cells_padded))) return rc;
+    if (!cm.pq_heap) {
+      cm.pq_cap = (uint64_t)5 * cm.cells;
+      if ((rc = f->alloc(&cm.pq_heap, (size_t)f->desc.n_instances * cm.pq_cap))) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(cm.dist_lut, dist_lut.data(), sizeof(double) * dist_lut.size(), hipMemcpyHostToDevice, f->stream));
+  }
   // cost by squared distance for the bit-parallel kernel: max over the (i, j) pairs that share d^2,
   // usable only if it is non-increasing in d^2 (then max-over-seeds == cost of the nearest seed)
   std::vector<uint8_t> lut2(256, 0);
@@ -496,7 +513,7 @@ int navgpu_inflation_configure(navgpu_fleet* f, const navgpu_inflation_params* p
   HIP_TRY(waitStream(f->stream));
   const bool changed = !f->inflation_configured || f->infl.inflation_radius != p->inflation_radius ||
                        f->infl.cost_scaling_factor != p->cost_scaling_factor || f->infl.inscribed_radius != p->inscribed_radius ||
-                       f->infl.enabled != p->enabled;
+                       f->infl.enabled != p->enabled || f->infl.priority_queue_order != p->priority_queue_order;
   f->infl = *p;
   f->inflation_configured = true;
   cm.R = R;

@@ -116,8 +116,9 @@ class Fleet:
                            max_obstacle_height, origin_z, z_resolution, unknown_threshold, mark_threshold)
         check(self.L.navgpu_obstacle_configure(self.h, C.byref(p)), "obstacle_configure")
 
-    def configure_inflation(self, inflation_radius, cost_scaling_factor, inscribed_radius, enabled=True):
-        p = InflationParams(int(enabled), 0, inflation_radius, cost_scaling_factor, inscribed_radius)
+    def configure_inflation(self, inflation_radius, cost_scaling_factor, inscribed_radius, enabled=True, priority_queue_order=False):
+        """priority_queue_order: reproduce InflationLayer::updateCosts' own priority-queue walk byte for byte (slow)."""
+        p = InflationParams(int(enabled), int(priority_queue_order), inflation_radius, cost_scaling_factor, inscribed_radius)
         check(self.L.navgpu_inflation_configure(self.h, C.byref(p)), "inflation_configure")
 
     def set_footprint(self, xy, first=0, count=None):

@@ -123,7 +123,7 @@ void InflationBounds::update(bool* need_reinflation, double inflation_radius, do
 // ----------------------------------------------------------------------------- InflationLayer
 InflationLayer::InflationLayer() : need_reinflation_(false), dsrv_(NULL) {
   p_.enabled = 1;
-  p_.reserved = 0;
+  p_.priority_queue_order = 0;
   p_.inflation_radius = 0;
   p_.cost_scaling_factor = 0;
   p_.inscribed_radius = 0;
@@ -133,6 +133,9 @@ void InflationLayer::onInitialize() {  // inflation_layer.cpp:70-99
   ros::NodeHandle nh("~/" + name_);
   current_ = true;
   need_reinflation_ = false;
+  bool pq = false;  // byte-for-byte the reference's priority-queue walk instead of the exact transform (slow)
+  nh.param("navgpu_priority_queue_order", pq, false);
+  p_.priority_queue_order = pq;
   if (!dsrv_) dsrv_ = new dynamic_reconfigure::Server<costmap_2d::InflationPluginConfig>(nh);
   dsrv_->setCallback(boost::bind(&InflationLayer::reconfigureCB, this, _1, _2));
   matchSize();
@@ -285,6 +288,9 @@ void GpuLayers::onInitialize() {
   vp_.mark_threshold = mark_threshold;
   nh.param("inflation_radius", ip_.inflation_radius, 0.55);  // InflationPlugin.cfg:8-9
   nh.param("cost_scaling_factor", ip_.cost_scaling_factor, 10.0);
+  bool pq = false;
+  nh.param("navgpu_priority_queue_order", pq, false);
+  ip_.priority_queue_order = pq;
   need_reinflation_ = true;
   ObstacleLayer::onInitialize();
 }

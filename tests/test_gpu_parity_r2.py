@@ -452,3 +452,84 @@ def test_layer_adapter_sequence_rolling(nav, orc, voxel):
             assert np.array_equal(fl.download(N.GRID_VOXEL)[0], o.voxels()), ("voxel columns", cyc)
         assert np.array_equal(host_master, o.master()), ("master", cyc)
     fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# priority_queue_order = 1: InflationLayer::updateCosts as written (inflation_layer.cpp:226-293), byte for byte -
+# including the cells where the reference's heap order makes it differ from the exact transform
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,density,unk", [(64, 0.01, 0.0), (64, 0.05, 0.1), (97, 0.02, 0.05), (400, 0.01, 0.0), (400, 0.001, 0.02),
+                                            (250, 0.2, 0.0)])
+def test_inflate_reference_priority_queue_order(nav, orc, n, density, unk):
+    from test_gpu_parity import _random_map
+    N = L(nav)
+    rs = np.random.RandomState(n * 7 + int(density * 1000))  # the maps of test_inflate_full_window
+    maps = np.stack([_random_map(rs, n, density, unk) for _ in range(3)])
+    fl = nav.Fleet(3, n, n, 0.05, layers=N.LAYER_INFLATION)
+    fl.configure_inflation(0.55, 10.0, 0.2, priority_queue_order=True)
+    fl.upload(N.GRID_MASTER, maps)
+    fl.inflate(boxes=[[0, 0, n, n]] * 3)
+    got = fl.master()
+    n_vs_exact = 0
+    for k in range(3):
+        ref = orc.inflate(maps[k], 0.05, 0.55, 10.0, 0.2, exact=False)
+        assert np.array_equal(got[k], ref), f"map {k}: {int((got[k] != ref).sum())} cells differ from the reference's priority-queue walk"
+        n_vs_exact += int((ref != orc.inflate(maps[k], 0.05, 0.55, 10.0, 0.2, exact=True)).sum())
+    print(f"n={n} density={density}: byte-identical to the reference walk; {n_vs_exact} cells of it differ from the exact transform")
+    if (n, density) == (400, 0.01):
+        assert n_vs_exact > 0  # the case SURVEY 7 hard part 1 is about is really exercised
+    # partial boxes and another radius / resolution on the same fleet geometry
+    boxes = [[10, 20, min(60, n), min(90, n)], [0, 0, n, n], [n // 2, 0, n // 2 + 1, n]]
+    fl.configure_inflation(1.0, 3.0, 0.35, priority_queue_order=True)
+    fl.upload(N.GRID_MASTER, maps)
+    fl.inflate(boxes=boxes)
+    got = fl.master()
+    for k in range(3):
+        assert np.array_equal(got[k], orc.inflate(maps[k], 0.05, 1.0, 3.0, 0.35, box=boxes[k], exact=False)), ("box", k)
+    # and back to the default mode on the same fleet
+    fl.configure_inflation(0.55, 10.0, 0.2)
+    fl.upload(N.GRID_MASTER, maps)
+    fl.inflate(boxes=[[0, 0, n, n]] * 3)
+    assert np.array_equal(fl.master()[0], orc.inflate(maps[0], 0.05, 0.55, 10.0, 0.2, exact=True))
+    fl.close()
+
+
+def test_layered_cycles_reference_priority_queue_order(nav, orc):
+    """LayeredCostmap::updateMap cycles (static + obstacle + inflation) with the inflation layer in reference order:
+    master grids byte-identical to the oracle running the reference's own walk."""
+    from navigation_amd import synth
+    N = L(nav)
+    n, nI = 200, 2
+    insts = [synth.make_instance(n, 140 + i, density=0.01) for i in range(nI)]
+    insc = synth.inscribed_radius(synth.FOOTPRINT)
+    fl = nav.Fleet(nI, n, n, synth.RES, layers=N.LAYER_STATIC | N.LAYER_OBSTACLE | N.LAYER_INFLATION, max_points=720, max_observations=1)
+    fl.configure_obstacle()
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, insc, priority_queue_order=True)
+    oracles = []
+    for i, ins in enumerate(insts):
+        occ = np.where(ins["cells"] == 254, 100, 0).astype(np.int8)
+        fl.add_static_map(occ, first=i, count=1)
+        o = orc.LayeredCostmap(False)
+        o.set_footprint(synth.FOOTPRINT)
+        o.add_static(occ, res=synth.RES)
+        o.add_obstacle()
+        o.add_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, exact=False)
+        o.set_footprint(synth.FOOTPRINT)
+        oracles.append(o)
+    for cyc in range(3):
+        obs, poses = [], []
+        for i, ins in enumerate(insts):
+            pts = synth.laser_scan(ins, cyc)
+            org = (float(ins["pos"][0]), float(ins["pos"][1]), 0.3)
+            obs.append(dict(instance=i, points=pts, origin=org, obstacle_range=2.5, raytrace_range=3.0))
+            poses.append([float(v) for v in ins["pos"]])
+            oracles[i].clear_observations()
+            oracles[i].add_observation(pts, origin=org, obstacle_range=2.5, raytrace_range=3.0)
+            oracles[i].update_map(*poses[-1])
+        fl.stage_observations(poses, obs)
+        fl.update_map()
+        m = fl.master()
+        for i in range(nI):
+            assert np.array_equal(m[i], oracles[i].master()), (cyc, i)
+    fl.close()
