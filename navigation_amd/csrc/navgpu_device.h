@@ -181,7 +181,7 @@ void launch_shift_u32(const uint32_t* src, uint32_t* dst, const CostmapDev& cm, 
 
 void launch_cell_costs(const PlannerDev& pl, uint32_t inst, float4* out, hipStream_t s);
 void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
-void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order = nullptr, bool free_ready = false);
+void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order = nullptr, bool free_ready = false, int n_whole = -1);
 uint32_t launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s);  // returns blocks per instance
 void launch_select(const PlannerDev& pl, uint32_t first, uint32_t count, uint32_t n_blocks, hipStream_t s);
 // the poses of up to 64 robots as one kernel-argument block (< 4 KB)

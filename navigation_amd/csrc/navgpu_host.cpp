@@ -1069,13 +1069,15 @@ int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
   if (!f->planner_configured || !f->planner_staged) return NAVGPU_ERR_STATE;
   PlannerDev& pl = f->pl;
   pl.bfs_bounded = 1;  // per robot: bfs_reach (0 = whole grid)
+  int n_whole = 0;  // robots that search their whole grids this cycle (near the end of their plan, off the map, bounding off)
   for (uint32_t i = first; i < first + count; ++i) {
     f->grid_partial[i] = robotBox(f, i, f->hp_state[i].pos, f->hp_reach[i], &f->h_box[(size_t)4 * i]) ? 1 : 0;
+    n_whole += f->grid_partial[i] ? 0 : 1;
     f->cycle_gen[i] = f->inputs_gen[i];
   }
   launch_samples(pl, first, count, f->stream);
   if (getenv("NAVGPU_DEBUG_BFS_TRACE") && !pl.bfs_trace) f->alloc(&pl.bfs_trace, (size_t)f->desc.n_instances * 3 * 8);
-  PROFILED(f, NAVGPU_K_BFS, launch_bfs(pl, first, count, f->stream, pl.bfs_order + (size_t)first * 3, true));
+  PROFILED(f, NAVGPU_K_BFS, launch_bfs(pl, first, count, f->stream, pl.bfs_order + (size_t)first * 3, true, n_whole));
   if (pl.bfs_trace) {
     std::vector<unsigned long long> h((size_t)count * 24);
     hipMemcpyAsync(h.data(), pl.bfs_trace, h.size() * 8, hipMemcpyDeviceToHost, f->stream);

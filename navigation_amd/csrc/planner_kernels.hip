@@ -657,8 +657,29 @@ __global__ __launch_bounds__(256) void k_free_bits(PlannerDev pl, uint32_t first
 // keeps the constants (and the register allocation) it was tuned with
 // PL = level planes kept in registers: 10 (epochs of 1023 levels) for RPT 7; 3 (epochs of 7 levels, the cells written out
 // at every epoch end) for RPT 13, which extends the kernel to maps of up to 640 x 624 cells
-template <int RPT, bool LEGACY, int PL>
-__device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t inst, const int which, const uint32_t item) {
+// DIRECT = the variant for BOUNDED searches: no level planes at all.  Only the cells of the robot's region are ever read
+// (DESIGN 4a), so the few lanes that own region words store a cell's distance the moment the wavefront reaches it
+// and the rest of the workgroup just sweeps; without the 70 plane registers nothing spills (the plane variant writes
+// 244 B of scratch per lane and item: 9x the bytes of the region's distances) and a level costs a third fewer vector
+// instructions.  split: a launch of the plane variant beside a DIRECT one takes the whole-grid searches only.
+template <int RPT, bool LEGACY, int PL, bool DIRECT = false>
+__device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t inst, const int which, const uint32_t item, const int split = 0) {
+  static_assert(!DIRECT || !LEGACY, "the legacy planner always searches the whole grid");
+  // Bounded search (pl.bfs_bounded): the critics read a MapGrid only at cells the robot's samples can reach, a box
+  // around the robot (k_samples).  A level-synchronous wavefront has every reached cell final, so the sweep may stop
+  // once no cell of that box is left open (neither reached nor an obstacle); cells it has not reached by then read
+  // unreachableCellCosts() and the host completes the grid before anybody reads it outside the box.
+  int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, care_ok = 0;  // the robot's region (box + 2 cells) and whether its pockets are known
+  if (!LEGACY && pl.bfs_bounded) {
+    const int4 bb = reinterpret_cast<const int4*>(pl.bfs_box)[2 * inst];
+    bx0 = __builtin_amdgcn_readfirstlane(bb.x);
+    bx1 = __builtin_amdgcn_readfirstlane(bb.y);
+    by0 = __builtin_amdgcn_readfirstlane(bb.z);
+    by1 = __builtin_amdgcn_readfirstlane(bb.w);
+    care_ok = __builtin_amdgcn_readfirstlane(pl.bfs_box[8 * inst + 4]);
+  }
+  const bool bounded = !LEGACY && bx1 >= bx0 && by1 >= by0;
+  if (DIRECT ? !bounded : (split != 0 && bounded)) return;  // (uniform over the workgroup) the other variant's item
   extern __shared__ __align__(16) uint32_t sm[];
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_flag[3];
@@ -754,11 +775,13 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
 
   if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 8 + 5] = wall_clock64();
   uint32_t blocked[RPT], fr[RPT];
-  uint32_t plane[PL][RPT];
+  uint32_t plane[DIRECT ? 1 : PL][DIRECT ? 1 : RPT];
+  if constexpr (!DIRECT) {
 #pragma unroll
-  for (int b = 0; b < PL; ++b)
+    for (int b = 0; b < PL; ++b)
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) plane[b][k] = 0;
+      for (int k = 0; k < RPT; ++k) plane[b][k] = 0;
+  }
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
     blocked[k] = 0xFFFFFFFFu;  // rows beyond the grid and idle lanes never take part
@@ -786,20 +809,24 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
   // Levels are recorded bit-sliced relative to an epoch of 2^PL - 1 levels; in the rare case of a
   // longer search the cells of a finished epoch are written out and the planes start again.
   const uint32_t base_w = r0 * W + wi;
-  constexpr uint32_t kEpoch = (1u << PL) - 1u;
+  constexpr uint32_t kEpoch = DIRECT ? 0xFFFFFFFFu : (1u << PL) - 1u;  // (a DIRECT search stores whole distances: no epochs)
   constexpr int kLow = 3;  // planes 0..2 are updated every level, the others once per block of 8 levels
   uint32_t level = 0, epoch_base = 0;
-  uint32_t bstart[RPT];    // `blocked` at the start of the current block
+  uint32_t bstart[DIRECT ? 1 : RPT];    // `blocked` at the start of the current block
+  if constexpr (!DIRECT) {
 #pragma unroll
-  for (int k = 0; k < RPT; ++k) bstart[k] = blocked[k];
+    for (int k = 0; k < RPT; ++k) bstart[k] = blocked[k];
+  }
   auto closeBlock = [&](uint32_t hi) {  // cells reached since the block began get the block's high bits
+    if constexpr (!DIRECT) {
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      const uint32_t got = blocked[k] & ~bstart[k];
-      bstart[k] = blocked[k];
+      for (int k = 0; k < RPT; ++k) {
+        const uint32_t got = blocked[k] & ~bstart[k];
+        bstart[k] = blocked[k];
 #pragma unroll
-      for (int b = kLow; b < PL; ++b)
-        if ((hi >> (b - kLow)) & 1u) plane[b][k] |= got;
+        for (int b = kLow; b < PL; ++b)
+          if ((hi >> (b - kLow)) & 1u) plane[b][k] |= got;
+      }
     }
   };
   // one neighbour-expansion of row k: fc = the row's frontier, up/down = the rows above/below
@@ -819,21 +846,24 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
   const uint32_t wave_id = tid >> 6;
   uint32_t group = 0, any_grp = 0;  // termination is checked once per block of 2^kLow levels
   uint32_t had = 0;                 // OR of this lane's frontier words
-  // Bounded search (pl.bfs_bounded): the critics read a MapGrid only at cells the robot's samples can reach, a box
-  // around the robot (k_samples).  A level-synchronous wavefront has every reached cell final, so the sweep may stop
-  // once no cell of that box is left open (neither reached nor an obstacle); cells it has not reached by then read
-  // unreachableCellCosts() and the host completes the grid before anybody reads it outside the box.
-  int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, care_ok = 0;  // the robot's region (box + 2 cells) and whether its pockets are known
-  if (!LEGACY && pl.bfs_bounded) {
-    const int4 bb = reinterpret_cast<const int4*>(pl.bfs_box)[2 * inst];
-    bx0 = __builtin_amdgcn_readfirstlane(bb.x);
-    bx1 = __builtin_amdgcn_readfirstlane(bb.y);
-    by0 = __builtin_amdgcn_readfirstlane(bb.z);
-    by1 = __builtin_amdgcn_readfirstlane(bb.w);
-    care_ok = __builtin_amdgcn_readfirstlane(pl.bfs_box[8 * inst + 4]);
-  }
-  const bool bounded = !LEGACY && bx1 >= bx0 && by1 >= by0;
   const bool wave_in_box = bounded && (int)(wave_id * spw * RPT) <= by1 && (int)((wave_id + 1) * spw * RPT) > by0;
+  // DIRECT: the lanes that own words of the region store the distances themselves, cell by cell as they are reached
+  // (a word of the region sees new cells on a few dozen of the levels; every other lane never enters)
+  const bool region_lane = DIRECT && owner && wave_in_box && (int)wi >= (bx0 >> 5) && (int)wi <= (bx1 >> 5);
+  auto storeCells = [&](int k, uint32_t cells, uint32_t value) {
+    const uint32_t row = r0 + k;
+    if (cells == 0 || (int)row < by0 || (int)row > by1 || row >= ny) return;
+    uint32_t* drow = dist + row * nx + wi * 32;
+    while (cells) {
+      const uint32_t bpos = (uint32_t)__ffs(cells) - 1u;
+      cells &= cells - 1;
+      drow[bpos] = value;
+    }
+  };
+  if (region_lane) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) storeCells(k, fr[k], 0u);  // the seeds: distance 0
+  }
 #pragma unroll
   for (int k = 0; k < RPT; ++k) had |= fr[k];
   if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 8 + 2] = wall_clock64();
@@ -873,12 +903,21 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
 #pragma unroll
         for (int k = 0; k < RPT; ++k) had |= fr[k];
         any_grp |= had;
+        if constexpr (DIRECT) {
+          if (wave_in_box) {  // wave-uniform
+            if (region_lane && had) {
 #pragma unroll
-        for (int b = 0; b < kLow; ++b) {
-          if (code & (1u << b)) {  // wave-uniform
-            asm volatile("" ::: "memory");  // keep it a branch: half of these are skipped
+              for (int k = 0; k < RPT; ++k) storeCells(k, fr[k], level + 1);
+            }
+          }
+        } else {
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) plane[b][k] |= fr[k];
+          for (int b = 0; b < kLow; ++b) {
+            if (code & (1u << b)) {  // wave-uniform
+              asm volatile("" ::: "memory");  // keep it a branch: half of these are skipped
+#pragma unroll
+              for (int k = 0; k < RPT; ++k) plane[b][k] |= fr[k];
+            }
           }
         }
       }
@@ -925,7 +964,7 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
     }
     if (done) break;
     // epoch full: write its cells out, remember them in `late`, restart the planes
-    {
+    if constexpr (!DIRECT) {
       uint32_t cell0 = r0 * nx + wi * 32;
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
@@ -999,7 +1038,17 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
   const uint32_t dec_y0 = bounded ? (uint32_t)by0 : 0u, dec_rows = bounded ? (uint32_t)(by1 - by0 + 1) : ny;
   const uint32_t dec_w0 = bounded ? (uint32_t)(bx0 >> 5) : 0u, dec_w1 = bounded ? (uint32_t)(bx1 >> 5) : W - 1;
   __syncthreads();  // everyone is done with seedm / late / the edge buffers
-  if (bounded && !wave_in_box) {
+  if constexpr (DIRECT) {
+    // the reached cells have their distances already; what is left of the region: obstacle cells an expanded cell
+    // touched -> obstacleCosts(), everything else -> unreachableCellCosts()
+    if (region_lane) {
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        storeCells(k, blocked[k], N_obst);
+        storeCells(k, ~ex[k] & ~blocked[k] & col_mask, N_unreach);
+      }
+    }
+  } else if (bounded && !wave_in_box) {
     // none of this wave's rows is in the region
   } else if (coalesced) {
     uint4* stage = reinterpret_cast<uint4*>(sm) + (size_t)wave_id * nwords * 4;
@@ -1092,8 +1141,11 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
 // very different length (bounded ones end after 60..600 levels) a CU that is done early waits for the head of its
 // engine's queue: measured 0.71 ms of work per CU spread over 1.21 ms.  Items are ordered longest first (goal_front,
 // goal, path).  Every workgroup leaves the loop as soon as the counter has passed the last item.
-template <int RPT, bool LEGACY, int PL>
-__global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first, uint32_t count, uint32_t* next_item, const uint32_t* order) {
+// A bounded search keeps few of its 16 waves busy at any level (the wavefront is a thin ring on its way to the robot's
+// box) and its levels are a chain of neighbour hand-shakes: latency, not issue slots.  The DIRECT variant is therefore
+// built for 64 registers, two workgroups per CU, and a CU works on two searches at once.
+template <int RPT, bool LEGACY, int PL, bool DIRECT = false>
+__global__ __launch_bounds__(1024, DIRECT ? 8 : 4) void k_bfs_wave(PlannerDev pl, uint32_t first, uint32_t count, uint32_t* next_item, const uint32_t* order, int split) {
   __shared__ uint32_t s_item;
   const uint32_t total = count * (LEGACY ? 2u : 3u);
   for (;;) {
@@ -1103,7 +1155,7 @@ __global__ __launch_bounds__(1024) void k_bfs_wave(PlannerDev pl, uint32_t first
     if (slot >= total) break;
     const uint32_t item = order ? order[slot] : slot;  // longest searches first: by the level count of the previous cycle (k_samples)
     const uint32_t g = item / count;
-    bfsWaveGrid<RPT, LEGACY, PL>(pl, first + (item - g * count), (LEGACY ? 1 : 2) - (int)g, item);
+    bfsWaveGrid<RPT, LEGACY, PL, DIRECT>(pl, first + (item - g * count), (LEGACY ? 1 : 2) - (int)g, item, split);
     __syncthreads();  // s_item and the LDS staging of the decode are reused by the next item
   }
 }
@@ -1405,7 +1457,9 @@ bool bfs_bounded_applies(const PlannerDev& pl) {
   if (force_lds_kernel) return false;
   return bfs_wave_fits(pl.nx, pl.ny, 7) || (bfs_wave_fits(pl.nx, pl.ny, 13) && bfs_wave_lds(pl.nx, pl.ny, 13) <= 156u * 1024u);
 }
-void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order, bool free_ready) {
+void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order, bool free_ready, int n_whole) {
+  // n_whole: how many of the robots search their whole grid this cycle (< 0 = unknown / all): a bounded launch runs the
+  // DIRECT variant for the bounded searches and, only if there are any, the plane variant for the others
   dim3 grid(count, pl.bfs_grids);
   const size_t lds = bfs_lds_bytes(pl.nx, pl.ny);  // dense bit-parallel sweep (no LDS atomics in the loop)
   const int rpt = bfs_rows_per_thread(pl.nx, pl.ny);
@@ -1421,8 +1475,16 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
     const size_t lds_w = bfs_wave_lds(pl.nx, pl.ny, R);                                                                       \
     if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<R, LEG, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); \
     if (!free_ready) hipLaunchKernelGGL(k_free_bits, dim3((pl.ny * ((pl.nx + 31) / 32) + 255) / 256, count), dim3(256), 0, s, pl, first); \
-    hipMemsetAsync(pl.bfs_next_item, 0, sizeof(uint32_t), s);                                                                 \
-    hipLaunchKernelGGL((k_bfs_wave<R, LEG, P>), dim3(std::min(count * pl.bfs_grids, bfs_cu_count())), dim3(1024), lds_w, s, pl, first, count, pl.bfs_next_item, order); \
+    hipMemsetAsync(pl.bfs_next_item, 0, 2 * sizeof(uint32_t), s);                                                             \
+    const bool direct = !LEG && pl.bfs_bounded && n_whole >= 0 && (uint32_t)n_whole < count;                                  \
+    if (!direct || n_whole > 0)                                                                                               \
+      hipLaunchKernelGGL((k_bfs_wave<R, LEG, P>), dim3(std::min(count * pl.bfs_grids, bfs_cu_count())), dim3(1024), lds_w, s, pl, first, count, pl.bfs_next_item, order, direct ? 1 : 0); \
+    if constexpr (!LEG) {                                                                                                     \
+      if (direct) {                                                                                                           \
+        if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<R, false, P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); \
+        hipLaunchKernelGGL((k_bfs_wave<R, false, P, true>), dim3(std::min(count * pl.bfs_grids, (2 * lds_w <= 156u * 1024u ? 2u : 1u) * bfs_cu_count())), dim3(1024), lds_w, s, pl, first, count, pl.bfs_next_item + 1, order, 0); \
+      }                                                                                                                       \
+    }                                                                                                                         \
     return;                                                                                                                   \
   }
     if (!force_lds_kernel && bfs_wave_fits(pl.nx, pl.ny, 7)) {
