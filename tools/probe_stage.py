@@ -1,4 +1,5 @@
-"""Where does a cycle's host time go?  Per-call host durations of the async timed loop (stage_poses / update_map / planner_cycle)."""
+"""Where does a cycle's host time go?  Per-call host durations of the async timed loop (stage_poses / update_map / planner_cycle).
+   python tools/probe_stage.py [torch]"""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,8 +15,10 @@ poses = bench.PoseSchedule(pos_h, vel_h, 64, 1)
 for k in range(5):
     bench.step(fl, poses, k)
 fl.sync()
-for mode in ("fixed", "poses", "poses+prof"):
-    if mode == "poses+prof":
+for rep in range(2):
+  for mode in ("fixed", "poses", "fixed+prof", "poses+prof", "poses64+prof"):
+    fl.profile(False)
+    if "prof" in mode:
         fl.profile_select(["k_score"])
         fl.profile(True)
         fl.profile_reset()
@@ -24,7 +27,9 @@ for mode in ("fixed", "poses", "poses+prof"):
     K = 50
     for k in range(K):
         a = time.perf_counter()
-        if mode != "fixed":
+        if mode.startswith("poses64"):
+            fl.stage_poses(poses.pos[k % 64][:64], poses.vel[:64])
+        elif mode.startswith("poses"):
             fl.stage_poses(poses.pos[k % 64], poses.vel)
         b = time.perf_counter()
         fl.update_map()
