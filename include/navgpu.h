@@ -512,6 +512,42 @@ int navgpu_profile_reset(navgpu_fleet* fleet);
 int navgpu_profile_read(navgpu_fleet* fleet, int32_t kernel, double* total_ms, uint64_t* launches);
 const char* navgpu_kernel_name(int32_t kernel);
 
+/* ------------------------------------------------------------------------------------------ */
+/* navfn::NavFn - global-planner potential expansion and path extraction       */
+/* ------------------------------------------------------------------------------------------ */
+/* A batch of independent plans on maps of one size (one plan per robot of a fleet).  What is computed is exactly what
+ * navfn::NavFn computes - potentials, priority-buffer order, the early stop at the start cell, the interpolated path -
+ * bit for bit (the expansion is an order-dependent sequential process: one GPU lane walks each plan, the batch is the
+ * parallel dimension).  Coordinates are cells, origin upper left, as in the reference (navfn.h:108-112). */
+typedef struct navgpu_navfn navgpu_navfn;
+typedef struct {
+  int32_t found;          /* calcNavFnDijkstra / calcNavFnAstar return value (navfn.cpp:293-345)           */
+  int32_t path_length;    /* NavFn::getPathLen(), 0 when no path was found                                 */
+  int32_t cycles;         /* propagation cycles used                                                       */
+  float start_potential;  /* potarr[start] (NavFn::getLastPathCost after calcNavFnAstar)                   */
+} navgpu_navfn_result;
+/* replaces: NavFn::NavFn / setNavArr (navfn.cpp:110-215) for n_plans plans */
+int navgpu_navfn_create(uint32_t nx, uint32_t ny, uint32_t n_plans, int32_t device, navgpu_navfn** out);
+int navgpu_navfn_destroy(navgpu_navfn* nav);
+/* replaces: NavFn::setCostmap(cmap, isROS, allow_unknown) (navfn.cpp:222-283).  cmap = count x ny x nx bytes (or ONE map shared
+ * by all plans when shared != 0).  cost_mode 1: isROS = true (costmap_2d values), 2: isROS = false (a plain PGM, 7-cell
+ * borders stay obstacles), 0: the bytes are costarr itself (navfn/test/path_calc_test.cpp:52) */
+int navgpu_navfn_set_costmap(navgpu_navfn* nav, uint32_t first, uint32_t count, const uint8_t* cmap, int32_t shared, int32_t cost_mode,
+                             int32_t allow_unknown);
+/* the same from the master grids of a fleet on the same GPU (NavfnROS::makePlan hands costmap_->getCharMap() over, navfn_ros.cpp:265-268):
+ * plan first + k takes the master grid of fleet instance fleet_first + k; nothing crosses PCIe */
+int navgpu_navfn_set_costmap_from_fleet(navgpu_navfn* nav, uint32_t first, uint32_t count, navgpu_fleet* fleet, uint32_t fleet_first,
+                                        int32_t allow_unknown);
+/* replaces: NavFn::setGoal / setStart + calcNavFnDijkstra(at_start) | calcNavFnAstar() (navfn.cpp:145-171, 293-345).
+ * goals_xy, starts_xy = count x {x, y} cells.  (NavfnROS passes the robot as "goal" and the goal as "start",
+ * navfn_ros.cpp:270-281: the potential is grown from the robot.) */
+int navgpu_navfn_plan(navgpu_navfn* nav, uint32_t first, uint32_t count, const int32_t* goals_xy, const int32_t* starts_xy, int32_t astar,
+                      int32_t at_start, navgpu_navfn_result* results);
+/* replaces: NavFn::getPathX / getPathY / getPathLen: xy = up to capacity_points x {x, y}; returns the path length */
+int navgpu_navfn_path(navgpu_navfn* nav, uint32_t plan, float* xy, uint32_t capacity_points);
+/* NavFn::potarr of one plan (ny x nx floats, POT_HIGH = 1e10 where unassigned) */
+int navgpu_navfn_potential(navgpu_navfn* nav, uint32_t plan, float* potarr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@ imports the CPU oracle and has no CPU fallback: loading fails loudly when libnav
 from ._lib import (TpConfig, DwaConfig, FleetDesc, InflationParams, NavgpuError, Observation, ObstacleParams, PlanResult,
                    RobotState, build, lib, lib_path)
 from .fleet import Fleet
+from .navfn import NavFn
 
-__all__ = ["Fleet", "TpConfig", "DwaConfig", "FleetDesc", "InflationParams", "ObstacleParams", "Observation", "PlanResult",
+__all__ = ["Fleet", "NavFn", "TpConfig", "DwaConfig", "FleetDesc", "InflationParams", "ObstacleParams", "Observation", "PlanResult",
            "RobotState", "NavgpuError", "build", "lib", "lib_path"]

@@ -158,6 +158,11 @@ class TpSample(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class NavfnResult(C.Structure):
+    """Mirror of navgpu_navfn_result (include/navgpu.h)."""
+    _fields_ = [("found", C.c_int32), ("path_length", C.c_int32), ("cycles", C.c_int32), ("start_potential", C.c_float)]
+
+
 def lib_path():
     return os.path.join(_HERE, "libnavgpu.so")
 
@@ -224,6 +229,13 @@ SYMBOLS = [
     ("navgpu_tp_score_trajectory", C.c_int, [vp, u32, vp, vp, vp, C.POINTER(dbl)]),
     ("navgpu_tp_get_state", C.c_int, [vp, u32, u32, vp]),
     ("navgpu_tp_set_state", C.c_int, [vp, u32, u32, vp]),
+    ("navgpu_navfn_create", C.c_int, [u32, u32, u32, i32, C.POINTER(vp)]),
+    ("navgpu_navfn_destroy", C.c_int, [vp]),
+    ("navgpu_navfn_set_costmap", C.c_int, [vp, u32, u32, vp, i32, i32, i32]),
+    ("navgpu_navfn_set_costmap_from_fleet", C.c_int, [vp, u32, u32, vp, u32, i32]),
+    ("navgpu_navfn_plan", C.c_int, [vp, u32, u32, vp, vp, i32, i32, vp]),
+    ("navgpu_navfn_path", C.c_int, [vp, u32, vp, u32]),
+    ("navgpu_navfn_potential", C.c_int, [vp, u32, vp]),
     ("navgpu_footprint_radii", C.c_int, [vp, u32, C.POINTER(dbl), C.POINTER(dbl)]),
     ("navgpu_footprint_pad", C.c_int, [vp, u32, dbl]),
     ("navgpu_footprint_from_radius", C.c_int, [dbl, vp]),

@@ -237,4 +237,19 @@ __device__ __forceinline__ double hyp2(double x, double y) {
   return h + (r + e) / (2.0 * h);
 }
 
+// navfn::NavFn arrays of a batch of plans (navfn_kernels.hip, navgpu_navfn.cpp)
+struct NavfnDev {
+  int nx, ny, ns;
+  uint32_t ns_padded, path_cap;
+  uint8_t *costarr, *pending;   // [n][ns_padded]
+  float *potarr, *gradx, *grady;  // [n][ns_padded]
+  int* pb;                      // [n][3][PRIORITYBUFSIZE]
+  float* path;                  // [n][2][path_cap]: pathx, pathy
+  navgpu_navfn_result* results; // [n]
+};
+void launch_navfn_costmap(const NavfnDev& nv, uint32_t first, uint32_t count, const uint8_t* cmap, size_t stride, int cost_mode, int allow_unknown,
+                          hipStream_t s);
+void launch_navfn_plan(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* goals, const int32_t* starts, int astar, int at_start,
+                       hipStream_t s);
+
 }  // namespace navgpu

@@ -1,0 +1,159 @@
+// navgpu_navfn_*: host side of the navfn::NavFn batch (see navfn_kernels.hip and include/navgpu.h).
+#include "navgpu_fleet.h"
+
+struct navgpu_navfn {
+  NavfnDev nv{};
+  uint32_t n = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  uint8_t* d_cmap = nullptr;   // staging for host cost maps: [n][ns_padded]
+  int32_t* d_goal = nullptr;   // [n][2]
+  int32_t* d_start = nullptr;  // [n][2]
+  navgpu_navfn_result* h_results = nullptr;  // pinned
+  template <class T>
+  int alloc(T** p, size_t count) {
+    void* q = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    if (hipMalloc(&q, bytes) != hipSuccess) {
+      g_last_error = "hipMalloc failed (navfn)";
+      return NAVGPU_ERR_HIP;
+    }
+    hipMemsetAsync(q, 0, bytes, stream);
+    allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return NAVGPU_OK;
+  }
+};
+
+extern "C" {
+
+int navgpu_navfn_create(uint32_t nx, uint32_t ny, uint32_t n_plans, int32_t device, navgpu_navfn** out) {
+  if (!out || nx < 3 || ny < 3 || nx > 32768 || ny > 32768 || !n_plans) return NAVGPU_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    g_last_error = "no usable HIP device (navgpu has no CPU fallback)";
+    return NAVGPU_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device));
+  navgpu_navfn* h = new navgpu_navfn();
+  h->n = n_plans;
+  h->device = device;
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    g_last_error = "hipStreamCreate failed";
+    return NAVGPU_ERR_HIP;
+  }
+  NavfnDev& nv = h->nv;
+  nv.nx = (int)nx;
+  nv.ny = (int)ny;
+  nv.ns = (int)(nx * ny);
+  nv.ns_padded = (uint32_t)((nv.ns + 63) & ~63);
+  nv.path_cap = (uint32_t)std::max(nv.ns / 2, 4 * nv.nx) + 4;  // calcPath(nx * ny / 2) | calcPath(nx * 4)
+  int rc = 0;
+#define A(ptr, cnt)                                  \
+  if (!rc) rc = h->alloc(&(ptr), (size_t)(cnt));
+  A(nv.costarr, (size_t)n_plans * nv.ns_padded);
+  A(nv.pending, (size_t)n_plans * nv.ns_padded);
+  A(nv.potarr, (size_t)n_plans * nv.ns_padded);
+  A(nv.gradx, (size_t)n_plans * nv.ns_padded);
+  A(nv.grady, (size_t)n_plans * nv.ns_padded);
+  A(nv.pb, (size_t)n_plans * 3 * 10000);
+  A(nv.path, (size_t)n_plans * 2 * nv.path_cap);
+  A(nv.results, n_plans);
+  A(h->d_cmap, (size_t)n_plans * nv.ns_padded);
+  A(h->d_goal, (size_t)n_plans * 2);
+  A(h->d_start, (size_t)n_plans * 2);
+#undef A
+  if (!rc && hipHostMalloc((void**)&h->h_results, sizeof(navgpu_navfn_result) * n_plans, hipHostMallocDefault) != hipSuccess) rc = NAVGPU_ERR_HIP;
+  if (rc) {
+    navgpu_navfn_destroy(h);
+    return rc;
+  }
+  HIP_TRY(waitStream(h->stream));
+  *out = h;
+  return NAVGPU_OK;
+}
+
+int navgpu_navfn_destroy(navgpu_navfn* h) {
+  if (!h) return NAVGPU_ERR_INVALID;
+  if (h->stream) waitStream(h->stream);
+  for (void* p : h->allocs) hipFree(p);
+  if (h->h_results) hipHostFree(h->h_results);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return NAVGPU_OK;
+}
+
+static bool navfnRange(const navgpu_navfn* h, uint32_t first, uint32_t count) { return count > 0 && first < h->n && count <= h->n - first; }
+
+int navgpu_navfn_set_costmap(navgpu_navfn* h, uint32_t first, uint32_t count, const uint8_t* cmap, int32_t shared, int32_t cost_mode,
+                             int32_t allow_unknown) {
+  if (!h || !cmap || !navfnRange(h, first, count) || cost_mode < 0 || cost_mode > 2) return NAVGPU_ERR_INVALID;
+  const NavfnDev& nv = h->nv;
+  HIP_TRY(hipSetDevice(h->device));
+  const uint32_t maps = shared ? 1u : count;
+  for (uint32_t k = 0; k < maps; ++k)
+    HIP_TRY(hipMemcpyAsync(h->d_cmap + (size_t)k * nv.ns_padded, cmap + (size_t)k * nv.ns, (size_t)nv.ns, hipMemcpyHostToDevice, h->stream));
+  launch_navfn_costmap(nv, first, count, h->d_cmap, shared ? 0 : nv.ns_padded, cost_mode, allow_unknown, h->stream);
+  HIP_TRY(waitStream(h->stream));  // the caller's buffer and the staging area are free again
+  return checkLaunch();
+}
+
+int navgpu_navfn_set_costmap_from_fleet(navgpu_navfn* h, uint32_t first, uint32_t count, navgpu_fleet* f, uint32_t fleet_first, int32_t allow_unknown) {
+  if (!h || !f || !navfnRange(h, first, count) || !f->rangeOk(fleet_first, count)) return NAVGPU_ERR_INVALID;
+  if ((int)f->cm.nx != h->nv.nx || (int)f->cm.ny != h->nv.ny || f->desc.device != h->device) return NAVGPU_ERR_INVALID;
+  HIP_TRY(waitStream(f->stream));  // the fleet's last costmap update has landed
+  launch_navfn_costmap(h->nv, first, count, f->cm.master + (size_t)fleet_first * f->cm.cells_padded, f->cm.cells_padded, 1, allow_unknown, h->stream);
+  HIP_TRY(waitStream(h->stream));
+  return checkLaunch();
+}
+
+int navgpu_navfn_plan(navgpu_navfn* h, uint32_t first, uint32_t count, const int32_t* goals, const int32_t* starts, int32_t astar, int32_t at_start,
+                      navgpu_navfn_result* results) {
+  if (!h || !goals || !starts || !navfnRange(h, first, count)) return NAVGPU_ERR_INVALID;
+  const NavfnDev& nv = h->nv;
+  for (uint32_t k = 0; k < count; ++k) {  // the reference indexes its arrays with these without a check: keep them inside the border
+    const int32_t* g = goals + 2 * k;
+    const int32_t* s = starts + 2 * k;
+    if (g[0] < 1 || g[1] < 1 || g[0] > nv.nx - 2 || g[1] > nv.ny - 2 || s[0] < 0 || s[1] < 0 || s[0] >= nv.nx || s[1] >= nv.ny) {
+      g_last_error = "navgpu_navfn_plan: goal / start cell outside the map";
+      return NAVGPU_ERR_INVALID;
+    }
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemcpyAsync(h->d_goal, goals, sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_start, starts, sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, h->stream));
+  launch_navfn_plan(nv, first, count, h->d_goal, h->d_start, astar ? 1 : 0, at_start ? 1 : 0, h->stream);
+  HIP_TRY(hipMemcpyAsync(h->h_results + first, nv.results + first, sizeof(navgpu_navfn_result) * count, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(waitStream(h->stream));
+  if (results) memcpy(results, h->h_results + first, sizeof(navgpu_navfn_result) * count);
+  return checkLaunch();
+}
+
+int navgpu_navfn_path(navgpu_navfn* h, uint32_t plan, float* xy, uint32_t cap) {
+  if (!h || plan >= h->n || (!xy && cap)) return NAVGPU_ERR_INVALID;
+  const NavfnDev& nv = h->nv;
+  const int len = h->h_results[plan].path_length;
+  const uint32_t n = std::min<uint32_t>((uint32_t)std::max(len, 0), cap);
+  if (n) {
+    std::vector<float> px(n), py(n);
+    HIP_TRY(hipMemcpyAsync(px.data(), nv.path + (size_t)plan * 2 * nv.path_cap, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(py.data(), nv.path + (size_t)plan * 2 * nv.path_cap + nv.path_cap, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(waitStream(h->stream));
+    for (uint32_t i = 0; i < n; ++i) {
+      xy[2 * i] = px[i];
+      xy[2 * i + 1] = py[i];
+    }
+  }
+  return len;
+}
+
+int navgpu_navfn_potential(navgpu_navfn* h, uint32_t plan, float* potarr) {
+  if (!h || plan >= h->n || !potarr) return NAVGPU_ERR_INVALID;
+  HIP_TRY(hipMemcpyAsync(potarr, h->nv.potarr + (size_t)plan * h->nv.ns_padded, sizeof(float) * (size_t)h->nv.ns, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(waitStream(h->stream));
+  return NAVGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,302 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement of navfn::NavFn, the potential-field expansion
+// and path extraction behind the navfn / global_planner global planners.  Every function cites the reference lines it
+// follows (navfn/src/navfn.cpp, navfn/include/navfn/navfn.h).  The reference file itself needs <ros/console.h>, which
+// this image lacks, so it is not compiled; the restatement is pinned by the reference's own test
+// (navfn/test/path_calc_test.cpp on navfn/test/willow_costmap.pgm: both searches find a path) and, as everywhere, is
+// only ever the checker: nothing under navigation_amd/ may include it.
+//
+// Arithmetic notes (kept exactly): potentials are float; the interpolation polynomial and the INVSQRT2 products are
+// evaluated in double and narrowed (navfn.cpp:516-533: double literals); `int minp = potarr[stc]` truncates (:895);
+// gradCell reads potarr[nx+1] where potarr[n+nx] is meant (:1020) — reproduced, it is what the reference computes.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace oracle {
+
+struct NavFnOracle {
+  static constexpr int kCostUnknownRos = 255, kCostObs = 254, kCostObsRos = 253, kCostNeutral = 50;  // navfn.h:49-67
+  static constexpr float kPotHigh = 1.0e10f;                                                          // navfn.h:77
+  static constexpr int kPriorityBufSize = 10000;                                                      // navfn.h:80
+  int nx = 0, ny = 0, ns = 0;
+  std::vector<uint8_t> costarr, pending;
+  std::vector<float> potarr, gradx, grady, pathx, pathy;
+  std::vector<int> pb1, pb2, pb3;
+  int *curP = nullptr, *nextP = nullptr, *overP = nullptr;
+  int curPe = 0, nextPe = 0, overPe = 0;
+  float curT = 0, priInc = 2 * kCostNeutral;
+  int goal[2] = {0, 0}, start[2] = {0, 0};
+  int npath = 0, nobs = 0;
+  float pathStep = 0.5f, last_path_cost = 0;
+
+  NavFnOracle(int xs, int ys) { setNavArr(xs, ys); }  // navfn.cpp:110-140
+  void setNavArr(int xs, int ys) {                     // :185-215
+    nx = xs;
+    ny = ys;
+    ns = nx * ny;
+    costarr.assign(ns, 0);
+    potarr.assign(ns, 0.f);
+    pending.assign(ns, 0);
+    gradx.assign(ns, 0.f);
+    grady.assign(ns, 0.f);
+    pb1.assign(kPriorityBufSize, 0);
+    pb2.assign(kPriorityBufSize, 0);
+    pb3.assign(kPriorityBufSize, 0);
+  }
+  // setCostmap (:222-283)
+  void setCostmap(const uint8_t* cmap, bool isROS, bool allow_unknown) {
+    uint8_t* cm = costarr.data();
+    for (int i = 0; i < ny; i++)
+      for (int j = 0; j < nx; j++, cmap++, cm++) {
+        *cm = kCostObs;
+        if (!isROS && (i < 7 || i > ny - 8 || j < 7 || j > nx - 8)) continue;  // "don't do borders" (:262-263)
+        int v = *cmap;
+        if (v < kCostObsRos) {
+          v = kCostNeutral + 0.8 * v;  // COST_FACTOR 0.8, evaluated in double and truncated
+          if (v >= kCostObs) v = kCostObs - 1;
+          *cm = v;
+        } else if (v == kCostUnknownRos && (allow_unknown || !isROS)) {
+          v = kCostObs - 1;
+          *cm = v;
+        }
+      }
+  }
+  void pushCur(int n) {  // :367-369
+    if (n >= 0 && n < ns && !pending[n] && costarr[n] < kCostObs && curPe < kPriorityBufSize) {
+      curP[curPe++] = n;
+      pending[n] = 1;
+    }
+  }
+  void pushNext(int n) {  // :370-372
+    if (n >= 0 && n < ns && !pending[n] && costarr[n] < kCostObs && nextPe < kPriorityBufSize) {
+      nextP[nextPe++] = n;
+      pending[n] = 1;
+    }
+  }
+  void pushOver(int n) {  // :373-375
+    if (n >= 0 && n < ns && !pending[n] && costarr[n] < kCostObs && overPe < kPriorityBufSize) {
+      overP[overPe++] = n;
+      pending[n] = 1;
+    }
+  }
+  // setupNavFn(keepit = true) (:379-440) + initCost (:445-453)
+  void setupNavFn() {
+    for (int i = 0; i < ns; i++) {
+      potarr[i] = kPotHigh;
+      gradx[i] = grady[i] = 0.0f;
+    }
+    for (int i = 0; i < nx; i++) costarr[i] = kCostObs;
+    for (int i = 0; i < nx; i++) costarr[(ny - 1) * nx + i] = kCostObs;
+    for (int i = 0; i < ny; i++) costarr[i * nx] = kCostObs;
+    for (int i = 0; i < ny; i++) costarr[i * nx + nx - 1] = kCostObs;
+    curT = kCostObs;
+    curP = pb1.data();
+    curPe = 0;
+    nextP = pb2.data();
+    nextPe = 0;
+    overP = pb3.data();
+    overPe = 0;
+    std::fill(pending.begin(), pending.end(), 0);
+    const int k = goal[0] + goal[1] * nx;
+    potarr[k] = 0;  // initCost(k, 0)
+    pushCur(k + 1);
+    pushCur(k - 1);
+    pushCur(k - nx);
+    pushCur(k + nx);
+    nobs = 0;
+    for (int i = 0; i < ns; i++) nobs += costarr[i] >= kCostObs;
+  }
+  // updateCell (:466-535) / updateCellAstar (:548-620)
+  template <bool ASTAR>
+  void updateCell(int n) {
+    const float l = potarr[n - 1], r = potarr[n + 1], u = potarr[n - nx], d = potarr[n + nx];
+    float ta, tc;
+    if (l < r) tc = l; else tc = r;
+    if (u < d) ta = u; else ta = d;
+    if (costarr[n] < kCostObs) {
+      const float hf = (float)costarr[n];
+      float dc = tc - ta;
+      if (dc < 0) {
+        dc = -dc;
+        ta = tc;
+      }
+      float pot;
+      if (dc >= hf)
+        pot = ta + hf;
+      else {
+        const float dd = dc / hf;
+        const float v = -0.2301 * dd * dd + 0.5307 * dd + 0.7040;
+        pot = ta + hf * v;
+      }
+      if (pot < potarr[n]) {
+        const float le = 0.707106781 * (float)costarr[n - 1];
+        const float re = 0.707106781 * (float)costarr[n + 1];
+        const float ue = 0.707106781 * (float)costarr[n - nx];
+        const float de = 0.707106781 * (float)costarr[n + nx];
+        potarr[n] = pot;
+        if (ASTAR) {
+          const int x = n % nx, y = n / nx;
+          const float dist = hypot(x - start[0], y - start[1]) * (float)kCostNeutral;
+          pot += dist;
+        }
+        if (pot < curT) {
+          if (l > pot + le) pushNext(n - 1);
+          if (r > pot + re) pushNext(n + 1);
+          if (u > pot + ue) pushNext(n - nx);
+          if (d > pot + de) pushNext(n + nx);
+        } else {
+          if (l > pot + le) pushOver(n - 1);
+          if (r > pot + re) pushOver(n + 1);
+          if (u > pot + ue) pushOver(n - nx);
+          if (d > pot + de) pushOver(n + nx);
+        }
+      }
+    }
+  }
+  // propNavFnDijkstra (:633-701) / propNavFnAstar (:714-791); returns the cycle count through *cycles_used
+  template <bool ASTAR>
+  bool propagate(int cycles, bool atStart, int* cycles_used = nullptr) {
+    int cycle = 0;
+    if (ASTAR) {
+      const float dist = hypot(goal[0] - start[0], goal[1] - start[1]) * (float)kCostNeutral;
+      curT = dist + curT;
+    }
+    const int startCell = start[1] * nx + start[0];
+    for (; cycle < cycles; cycle++) {
+      if (curPe == 0 && nextPe == 0) break;
+      for (int i = 0; i < curPe; i++) pending[curP[i]] = 0;
+      for (int i = 0; i < curPe; i++) updateCell<ASTAR>(curP[i]);
+      curPe = nextPe;
+      nextPe = 0;
+      std::swap(curP, nextP);
+      if (curPe == 0) {
+        curT += priInc;
+        curPe = overPe;
+        overPe = 0;
+        std::swap(curP, overP);
+      }
+      if (ASTAR || atStart)
+        if (potarr[startCell] < kPotHigh) break;
+    }
+    if (cycles_used) *cycles_used = cycle;
+    if (ASTAR) {
+      last_path_cost = potarr[startCell];
+      return potarr[startCell] < kPotHigh;
+    }
+    return cycle < cycles;
+  }
+  // gradCell (:1001-1056)
+  float gradCell(int n) {
+    if (gradx[n] + grady[n] > 0.0) return 1.0;
+    if (n < nx || n > ns - nx) return 0.0;
+    const float cv = potarr[n];
+    float dx = 0.0, dy = 0.0;
+    if (cv >= kPotHigh) {
+      if (potarr[n - 1] < kPotHigh)
+        dx = -kCostObs;
+      else if (potarr[n + 1] < kPotHigh)
+        dx = kCostObs;
+      if (potarr[n - nx] < kPotHigh)
+        dy = -kCostObs;
+      else if (potarr[nx + 1] < kPotHigh)  // sic (:1020)
+        dy = kCostObs;
+    } else {
+      if (potarr[n - 1] < kPotHigh) dx += potarr[n - 1] - cv;
+      if (potarr[n + 1] < kPotHigh) dx += cv - potarr[n + 1];
+      if (potarr[n - nx] < kPotHigh) dy += potarr[n - nx] - cv;
+      if (potarr[n + nx] < kPotHigh) dy += cv - potarr[n + nx];
+    }
+    float norm = hypot(dx, dy);
+    if (norm > 0) {
+      norm = 1.0 / norm;
+      gradx[n] = norm * dx;
+      grady[n] = norm * dy;
+    }
+    return norm;
+  }
+  // calcPath (:811-985)
+  int calcPath(int n) {
+    pathx.assign(n, 0.f);
+    pathy.assign(n, 0.f);
+    int stc = start[1] * nx + start[0];
+    float dx = 0, dy = 0;
+    npath = 0;
+    for (int i = 0; i < n; i++) {
+      const int nearest_point = std::max(0, std::min(nx * ny - 1, stc + (int)round(dx) + (int)(nx * round(dy))));
+      if (potarr[nearest_point] < kCostNeutral) {
+        pathx[npath] = (float)goal[0];
+        pathy[npath] = (float)goal[1];
+        return ++npath;
+      }
+      if (stc < nx || stc > ns - nx) return 0;
+      pathx[npath] = stc % nx + dx;
+      pathy[npath] = stc / nx + dy;
+      npath++;
+      bool oscillation_detected = false;
+      if (npath > 2 && pathx[npath - 1] == pathx[npath - 3] && pathy[npath - 1] == pathy[npath - 3]) oscillation_detected = true;
+      const int stcnx = stc + nx, stcpx = stc - nx;
+      if (potarr[stc] >= kPotHigh || potarr[stc + 1] >= kPotHigh || potarr[stc - 1] >= kPotHigh || potarr[stcnx] >= kPotHigh ||
+          potarr[stcnx + 1] >= kPotHigh || potarr[stcnx - 1] >= kPotHigh || potarr[stcpx] >= kPotHigh || potarr[stcpx + 1] >= kPotHigh ||
+          potarr[stcpx - 1] >= kPotHigh || oscillation_detected) {
+        int minc = stc;
+        int minp = potarr[stc];  // sic: int (:895)
+        int st = stcpx - 1;
+        if (potarr[st] < minp) { minp = potarr[st]; minc = st; }
+        st++;
+        if (potarr[st] < minp) { minp = potarr[st]; minc = st; }
+        st++;
+        if (potarr[st] < minp) { minp = potarr[st]; minc = st; }
+        st = stc - 1;
+        if (potarr[st] < minp) { minp = potarr[st]; minc = st; }
+        st = stc + 1;
+        if (potarr[st] < minp) { minp = potarr[st]; minc = st; }
+        st = stcnx - 1;
+        if (potarr[st] < minp) { minp = potarr[st]; minc = st; }
+        st++;
+        if (potarr[st] < minp) { minp = potarr[st]; minc = st; }
+        st++;
+        if (potarr[st] < minp) { minp = potarr[st]; minc = st; }
+        stc = minc;
+        dx = 0;
+        dy = 0;
+        if (potarr[stc] >= kPotHigh) return 0;
+      } else {
+        gradCell(stc);
+        gradCell(stc + 1);
+        gradCell(stcnx);
+        gradCell(stcnx + 1);
+        const float x1 = (1.0 - dx) * gradx[stc] + dx * gradx[stc + 1];
+        const float x2 = (1.0 - dx) * gradx[stcnx] + dx * gradx[stcnx + 1];
+        const float x = (1.0 - dy) * x1 + dy * x2;
+        const float y1 = (1.0 - dx) * grady[stc] + dx * grady[stc + 1];
+        const float y2 = (1.0 - dx) * grady[stcnx] + dx * grady[stcnx + 1];
+        const float y = (1.0 - dy) * y1 + dy * y2;
+        if (x == 0.0 && y == 0.0) return 0;
+        const float ss = pathStep / hypot(x, y);
+        dx += x * ss;
+        dy += y * ss;
+        if (dx > 1.0) { stc++; dx -= 1.0; }
+        if (dx < -1.0) { stc--; dx += 1.0; }
+        if (dy > 1.0) { stc += nx; dy -= 1.0; }
+        if (dy < -1.0) { stc -= nx; dy += 1.0; }
+      }
+    }
+    return 0;
+  }
+  // calcNavFnDijkstra (:293-316) / calcNavFnAstar (:323-345)
+  bool calcNavFnDijkstra(bool atStart) {
+    setupNavFn();
+    propagate<false>(std::max(nx * ny / 20, nx + ny), atStart);
+    return calcPath(nx * ny / 2) > 0;
+  }
+  bool calcNavFnAstar() {
+    setupNavFn();
+    propagate<true>(std::max(nx * ny / 20, nx + ny), true);
+    return calcPath(nx * 4) > 0;
+  }
+};
+
+}  // namespace oracle

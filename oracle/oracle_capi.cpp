@@ -4,6 +4,7 @@
 
 #include "../include/navgpu.h"  // POD layouts only (navgpu_dwa_config, navgpu_plan_result)
 #include "planner_oracle.hpp"
+#include "navfn_oracle.hpp"
 #include "trajectory_planner_oracle.hpp"
 
 using namespace oracle;
@@ -698,5 +699,36 @@ int orc_tp_footprint_cells(uint32_t sx, uint32_t sy, double res, double ox, doub
     out_xy[2 * i + 1] = c[i].y;
   }
   return (int)c.size();
+}
+// ------------------------------------------------------------------ navfn::NavFn
+// cost_mode: 0 = cmap IS costarr (path_calc_test.cpp:52 memcpy), 1 = setCostmap(cmap, isROS = true, allow_unknown),
+// 2 = setCostmap(cmap, isROS = false).  Returns the path length (0 = none); potarr_out (ns floats) and path_xy optional.
+int orc_navfn_plan(const uint8_t* cmap, int nx, int ny, int cost_mode, int allow_unknown, const int* goal, const int* start, int astar,
+                   int at_start, float* potarr_out, float* path_xy, int path_cap, int* cycles_used) {
+  NavFnOracle nav(nx, ny);
+  if (cost_mode == 0)
+    memcpy(nav.costarr.data(), cmap, (size_t)nx * ny);
+  else
+    nav.setCostmap(cmap, cost_mode == 1, allow_unknown != 0);
+  nav.goal[0] = goal[0];
+  nav.goal[1] = goal[1];
+  nav.start[0] = start[0];
+  nav.start[1] = start[1];
+  nav.setupNavFn();
+  int cyc = 0, len;
+  if (astar) {
+    nav.propagate<true>(std::max(nx * ny / 20, nx + ny), true, &cyc);
+    len = nav.calcPath(nx * 4);
+  } else {
+    nav.propagate<false>(std::max(nx * ny / 20, nx + ny), at_start != 0, &cyc);
+    len = nav.calcPath(nx * ny / 2);
+  }
+  if (cycles_used) *cycles_used = cyc;
+  if (potarr_out) memcpy(potarr_out, nav.potarr.data(), sizeof(float) * (size_t)nx * ny);
+  for (int i = 0; i < len && i < path_cap && path_xy; ++i) {
+    path_xy[2 * i] = nav.pathx[i];
+    path_xy[2 * i + 1] = nav.pathy[i];
+  }
+  return len;
 }
 }  // extern "C"

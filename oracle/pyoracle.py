@@ -155,6 +155,7 @@ def lib():
     sig("orc_tp_get_state", None, vp, C.c_void_p)
     sig("orc_tp_set_state", None, vp, C.c_void_p)
     sig("orc_tp_footprint_cells", i, u, u, d, d, d, f32p, f64p, u, i, C.c_void_p, i)
+    sig("orc_navfn_plan", i, u8p, i, i, i, i, i32p, i32p, i, i, C.c_void_p, C.c_void_p, i, C.POINTER(i))
     sig("orc_bench_dwa", d, u, u, d, u8p, u, C.POINTER(DwaConfig), f32p, f32p, f64p, u, f64p, f64p, u, u, u,
         C.POINTER(C.c_uint64))
     sig("orc_bench_inflate", d, u8p, u, u, u, d, d, d, d, u, u)
@@ -513,3 +514,17 @@ def min_max_distances(footprint):
     mn, mx = C.c_double(), C.c_double()
     L.orc_min_max_distances(fp, len(fp), C.byref(mn), C.byref(mx))
     return mn.value, mx.value
+
+
+def navfn_plan(cmap, goal, start, cost_mode=1, allow_unknown=True, astar=False, at_start=True, want_potential=True):
+    """navfn::NavFn (navfn_oracle.hpp): returns (path (n, 2) float32, potarr (ny, nx) float32 or None, cycles).
+    cost_mode 0: cmap is costarr itself; 1: setCostmap(isROS=true); 2: setCostmap(isROS=false)."""
+    g = np.ascontiguousarray(cmap, np.uint8)
+    ny, nx = g.shape
+    pot = np.zeros((ny, nx), np.float32) if want_potential else None
+    cap = nx * ny // 2 + 4
+    path = np.zeros((cap, 2), np.float32)
+    cyc = C.c_int()
+    n = lib().orc_navfn_plan(g, nx, ny, cost_mode, int(allow_unknown), np.ascontiguousarray(goal, np.int32), np.ascontiguousarray(start, np.int32),
+                             int(astar), int(at_start), pot.ctypes.data if want_potential else None, path.ctypes.data, cap, C.byref(cyc))
+    return path[:n].copy(), pot, cyc.value
