@@ -1,0 +1,5 @@
+// SYNTAX-CHECK STAND-IN for a ROS / Boost / PCL / Eigen header that this image lacks.  Test infrastructure only
+// (tests/test_plugin_syntax.py): it lets g++ -fsyntax-only parse navigation_amd/plugin/*.cpp against the REFERENCE'S OWN
+// headers.  No reference code is built with it, nothing is linked, nothing here is part of the product.
+#pragma once
+namespace costmap_2d { struct VoxelPluginConfig { bool enabled, footprint_clearing_enabled; double max_obstacle_height, origin_z, z_resolution; int z_voxels, unknown_threshold, mark_threshold, combination_method; VoxelPluginConfig() : enabled(true), footprint_clearing_enabled(true), max_obstacle_height(2), origin_z(0), z_resolution(0.2), z_voxels(10), unknown_threshold(15), mark_threshold(0), combination_method(1) {} }; }

@@ -1,0 +1,8 @@
+// SYNTAX-CHECK STAND-IN for a ROS / Boost / PCL / Eigen header that this image lacks.  Test infrastructure only
+// (tests/test_plugin_syntax.py): it lets g++ -fsyntax-only parse navigation_amd/plugin/*.cpp against the REFERENCE'S OWN
+// headers.  No reference code is built with it, nothing is linked, nothing here is part of the product.
+#pragma once
+#include <std_msgs/Header.h>
+#include <geometry_msgs/Pose.h>
+#include <boost/shared_ptr.hpp>
+namespace geometry_msgs { struct PoseStamped { std_msgs::Header header; Pose pose; typedef boost::shared_ptr<PoseStamped const> ConstPtr; }; }

@@ -1,0 +1,8 @@
+// SYNTAX-CHECK STAND-IN for a ROS / Boost / PCL / Eigen header that this image lacks.  Test infrastructure only
+// (tests/test_plugin_syntax.py): it lets g++ -fsyntax-only parse navigation_amd/plugin/*.cpp against the REFERENCE'S OWN
+// headers.  No reference code is built with it, nothing is linked, nothing here is part of the product.
+#pragma once
+#include <string>
+#include <ros/time.h>
+#include <stdint.h>
+namespace std_msgs { struct Header { uint32_t seq; ros::Time stamp; std::string frame_id; Header() : seq(0) {} }; }
