@@ -667,6 +667,10 @@ __global__ __launch_bounds__(256) void k_merge(CostmapDev cm, uint32_t first, co
   // rows touched by this group
   const int row_first = base / cm.nx, row_last = (min(base + 15, cm.cells - 1)) / cm.nx;
   if (row_last < y0 || row_first >= yn) return;
+  if (row_first == row_last) {  // a group inside one row: nothing to do left or right of the box either (3.4x -> 1.3x the box's bytes)
+    const int gx = base - row_first * cm.nx;
+    if (gx + 15 < x0 || gx >= xn) return;
+  }
   const size_t off = (size_t)inst * cm.cells_padded + base;
   uint4 mv = *reinterpret_cast<const uint4*>(cm.master + off);
   const bool has_static = (cm.layers & NAVGPU_LAYER_STATIC) && static_received && !layer_only;
