@@ -1643,6 +1643,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       nf |= o << b;
       fl |= f << b;
     }
+    if (pl.scale_obstacle == 0) nf = fl = 0;  // obstacle critic off (scale 0: skipped, simple_scored_sampling_planner.cpp:55-57): nothing to screen
     s_ba[2 * it] = nf;
     s_ba[2 * it + 1] = fl;
   }
@@ -1681,6 +1682,8 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
         pf = dp == n_obst || dp == n_unreach;
         gf = dg == n_obst || dg == n_unreach;
       }
+      pf = pf && pl.scale_path != 0;  // a critic with scale 0 is never evaluated: its screen stays clear
+      gf = gf && pl.scale_goal != 0;
       const unsigned long long mp = __ballot(pf), mg = __ballot(gf);
       if ((tid & 63u) == 0) {
         const int w = idx >> 5;  // linear word index y * nw + j; a wave covers two words (possibly of two rows)
@@ -1788,19 +1791,23 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   const double inv_res = pl.inv_res;
   // Costmap2D::worldToMap with the two fp64 divisions replaced by a multiply; exact: whenever the
   // product is not clear of an integer by 1e-7 (error bound 5e-10 below 1e6 cells) the division is redone.
-  // Straight-line: the quotient is clamped to [-1, 1e6] first (a point left of / below the origin floors to -1, one
-  // beyond any supported grid - or NaN - to a cell that fails the size test), so the only branch is the rare redo.
+  // Straight-line: the only branch is the rare redo.
   auto w2m = [&](double wx, double wy, uint32_t& mx, uint32_t& my) -> bool {
     const double dx = wx - g.ox, dy = wy - g.oy;
-    const double qx = fmin(fmax(dx * inv_res, -1.0), 1.0e6), qy = fmin(fmax(dy * inv_res, -1.0), 1.0e6);
+    const double qx = dx * inv_res, qy = dy * inv_res;
     double fx = floor(qx), fy = floor(qy);
     const double rx = qx - fx, ry = qy - fy;
     if (__builtin_expect(fmin(rx, ry) < 1.0e-7 || fmax(rx, ry) > 1.0 - 1.0e-7, 0)) {
       fx = !(dx >= 0.0) ? -1.0 : (qx >= 1.0e6 ? 1.0e6 : (double)(int)(dx / g.res));  // wx < origin -> false (costmap_2d.cpp:210)
       fy = !(dy >= 0.0) ? -1.0 : (qy >= 1.0e6 ? 1.0e6 : (double)(int)(dy / g.res));
     }
-    mx = (uint32_t)(int)fx;
-    my = (uint32_t)(int)fy;
+    // v_cvt_i32_f64 saturates (a point left of / below the origin floors to a negative cell, one far beyond the grid to
+    // INT_MAX: both fail the size test as unsigned numbers), which a C++ cast does not promise
+    int ix, iy;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(ix) : "v"(fx));
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(iy) : "v"(fy));
+    mx = (uint32_t)ix;
+    my = (uint32_t)iy;
     return mx < g.nx && my < g.ny;
   };
   const uint8_t fail_span = (pl.cfg.allow_unknown != 0) ? 0 : 1;  // pointCost: 254, and 255 unless allow_unknown
@@ -1911,8 +1918,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       const bool fwd_screen = !(en_gf || en_al) || (2u * fwd_margin < g.nx && 2u * fwd_margin < g.ny);
       const uint32_t fwd_lo = (en_gf || en_al) ? fwd_margin : 0u, fwd_nx = g.nx - 2u * fwd_lo, fwd_ny = g.ny - 2u * fwd_lo;
       // which of the four screens count: obstacle (dilated "not free" with sum_scores, else dilated "can fail"), path, goal
-      const uint32_t scr_x = (en_obs && c.sum_scores) ? ~0u : 0u, scr_y = (en_obs && !c.sum_scores) ? ~0u : 0u,
-                     scr_z = en_path ? ~0u : 0u, scr_w = en_goal ? ~0u : 0u;
+      const bool scr_sum = c.sum_scores != 0;  // the obstacle screen: dilated "not free" with sum_scores, else dilated "can fail"
       const bool screen_on = fwd_screen && (nfp >= 3 || !en_obs);
       if (osc_fail) {
         total = -5.0;
@@ -1939,7 +1945,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
             const int lxw = (int)cx - wx0;
             const uint4 fb = reinterpret_cast<const uint4*>(s_fb)[((int)cy - wy0) * nw + (lxw >> 5)];
             // (a critic that has already failed, or that follows one that has, cannot change the outcome any more)
-            const uint32_t any = (fb.x & scr_x) | (fb.y & scr_y) | (first_fail > 4 ? fb.z & scr_z : 0u) | (first_fail > 5 ? fb.w & scr_w : 0u);
+            const uint32_t any = (scr_sum ? fb.x : fb.y) | (first_fail > 4 ? fb.z : 0u) | (first_fail > 5 ? fb.w : 0u);
             screened = !((any >> (lxw & 31)) & 1u) && (cx - fwd_lo < fwd_nx) && (cy - fwd_lo < fwd_ny);
 #ifdef NAVGPU_SCORE_STATS
             SCORE_STAT(8, (fb.y >> (lxw & 31)) & 1u);
