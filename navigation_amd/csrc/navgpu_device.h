@@ -127,6 +127,7 @@ struct PlannerDev {
   uint32_t fp_chunk;          // cells of the longest footprint edge (+1): picks the k_score<CHUNK> instantiation
   uint32_t use_tables, tab_steps, tab_nfp, tab_nth;
   uint32_t tab_bytes;         // score_table_bytes(): the tables' share of the LDS image (0 without tables)
+  double tab_dt;              // sim_time / tab_steps
   uint8_t* prep;              // [n][prep_stride] LDS image of k_score (window, reach bitmaps, heading tables), built per cycle by k_score_prep*
   uint32_t prep_stride, prep_bytes;
   // k_score<TABLES>: shared per-(v_theta, step) tables in LDS

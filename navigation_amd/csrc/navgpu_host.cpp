@@ -564,6 +564,7 @@ static void updateWindow(navgpu_fleet* f) {
   f->pl.use_tables = 0;
   if (c.use_dwa && c.discretize_by_time && max_nfp <= 8) {
     f->pl.tab_steps = (uint32_t)ceil(c.sim_time / c.sim_granularity);
+    f->pl.tab_dt = c.sim_time / (int)f->pl.tab_steps;
     f->pl.tab_nfp = max_nfp;
     f->pl.tab_nth = (uint32_t)std::max(c.vth_samples, 2) + 1;
     const size_t lds = score_window_bytes(win) + score_table_bytes(f->pl);

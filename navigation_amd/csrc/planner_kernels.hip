@@ -1816,12 +1816,12 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   // index (x-outer, y, theta-inner, as the reference enumerates) is what results are keyed by.
   const int lin = blockIdx.x * blockDim.x + tid;
   bool in_range = lin < n_samples;
-  int sidx = lin, t_ith = 0;
+  int sidx = lin, t_ith = 0, t_r = 0;
   if (TABLES && in_range) {
     const int nxy = cnt[0] * cnt[1];
     t_ith = lin / nxy;
-    const int r = lin - t_ith * nxy;
-    sidx = r * cnt[2] + t_ith;
+    t_r = lin - t_ith * nxy;  // index of the (vx, vy) pair, x-outer
+    sidx = t_r * cnt[2] + t_ith;
   }
   double total = -1.0;
   int status = NAVGPU_SAMPLE_REJECTED;
@@ -1834,8 +1834,17 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       vs[2] = explicit_sample[2];
     } else {
       const int nth = cnt[2], nyv = cnt[1];
-      const int ix = sidx / (nyv * nth), rem = sidx - ix * (nyv * nth);
-      const int iy = rem / nth, ith = rem - iy * nth;
+      int ix, iy, ith;
+      if (TABLES) {  // sidx = (ix * nyv + iy) * nth + ith with ith = t_ith: one division instead of two
+        ix = t_r / nyv;
+        iy = t_r - ix * nyv;
+        ith = t_ith;
+      } else {
+        ix = sidx / (nyv * nth);
+        const int rem = sidx - ix * (nyv * nth);
+        iy = rem / nth;
+        ith = rem - iy * nth;
+      }
       vs[0] = s_axis[0][ix];
       vs[1] = s_axis[1][iy];
       vs[2] = s_axis[2][ith];
@@ -1849,7 +1858,9 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     int num_steps = 0;
     if (!reject) {
       double ns;
-      if (c.discretize_by_time) {
+      if (TABLES) {
+        ns = (double)K;  // = ceil(sim_time / sim_granularity), evaluated once on the host (the tables exist for discretize_by_time only)
+      } else if (c.discretize_by_time) {
         ns = ceil(c.sim_time / c.sim_granularity);
       } else {
         double sim_time_distance = vmag * c.sim_time;
@@ -1868,7 +1879,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     }
     if (!reject) {
       status = NAVGPU_SAMPLE_SCORED;
-      const double dt = c.sim_time / num_steps;
+      const double dt = TABLES ? pl.tab_dt : c.sim_time / num_steps;  // (tab_dt = sim_time / tab_steps, the same division, once on the host)
       const bool continued = TABLES ? false : !c.use_dwa;  // (the tables exist for use_dwa only)
       float px = st.pos[0], py = st.pos[1], pth = st.pos[2];
       float lv[3] = {vs[0], vs[1], vs[2]};
