@@ -61,3 +61,33 @@ def test_gloo_world2_counter_allreduce():
         assert abs(o[3] - 0.02) < 1e-12                     # MAX over ranks
         assert o[4] == sum(1000 + i for i in range(n_total))  # SUM over ranks
         assert o[5] == n_total
+
+
+@pytest.mark.timeout(240)
+def test_gloo_world8_configs3_shape():
+    """configs[3]'s shape on CPU: 2048 robots over 8 ranks (gloo), every rank 256, counters summed, MAX elapsed."""
+    import torch.multiprocessing as mp
+    world, n_total = 8, 2048
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=200) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [o[2] for o in out] == [256] * 8 and [o[1] for o in out] == [256 * r for r in range(8)]
+    for o in out:
+        assert abs(o[3] - 0.08) < 1e-12 and o[4] == sum(1000 + i for i in range(n_total)) and o[5] == n_total
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    """`bench.py --gpus N` under a launcher with a different WORLD_SIZE must fail loudly, before it touches torch or HIP."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr and r.stdout.strip() == ""
