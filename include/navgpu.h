@@ -548,6 +548,28 @@ int navgpu_navfn_path(navgpu_navfn* nav, uint32_t plan, float* xy, uint32_t capa
 /* NavFn::potarr of one plan (ny x nx floats, POT_HIGH = 1e10 where unassigned) */
 int navgpu_navfn_potential(navgpu_navfn* nav, uint32_t plan, float* potarr);
 
+/* global_planner::GlobalPlanner's expansion and traceback on the same arrays (the other half of SURVEY 8 f-4).
+ * Parameters as planner_core.cpp:105-152 reads them and GlobalPlanner.cfg sets them. */
+typedef struct {
+  int32_t use_dijkstra;       /* 1: DijkstraExpansion (dijkstra.cpp), 0: AStarExpansion (astar.cpp)                          */
+  int32_t use_quadratic;      /* 1: QuadraticCalculator, 0: PotentialCalculator                                              */
+  int32_t use_grid_path;      /* 1: GridPath, 0: GradientPath                                                                */
+  int32_t old_navfn_behavior; /* 1: integer start / goal, no precise start, no clearEndpoint (planner_core.cpp:108-127,299)  */
+  int32_t allow_unknown;      /* Expander::setHasUnknown                                                                     */
+  int32_t lethal_cost, neutral_cost; /* GlobalPlanner.cfg: 253, 50                                                           */
+  float cost_factor;          /* GlobalPlanner.cfg: 3.0                                                                      */
+  int32_t outline_map;        /* 1: GlobalPlanner::outlineMap(costs, nx, ny, LETHAL_OBSTACLE) first, as makePlan does (:296) */
+  int32_t reserved;
+} navgpu_global_planner_params;
+/* replaces: the body of GlobalPlanner::makePlan between worldToMap and the plan assembly (planner_core.cpp:250-311):
+ * outlineMap, planner_->calculatePotentials(costs, start, goal, nx * ny * 2, potential), clearEndpoint, path_maker_->getPath.
+ * The cost bytes are those of navgpu_navfn_set_costmap with cost_mode 0 (the costmap itself: getCost translates on the fly).
+ * starts_xy / goals_xy = count x {x, y} MAP coordinates as makePlan computes them (the cell index, or (w - origin) / resolution
+ * - 0.5 without old_navfn_behavior); goal_cells_xy = count x {goal_x_i, goal_y_i}.  navgpu_navfn_path then returns the
+ * traceback's own point list (goal first; getPlanFromPotential reverses it), navgpu_navfn_potential the potential array. */
+int navgpu_global_planner_plan(navgpu_navfn* nav, uint32_t first, uint32_t count, const navgpu_global_planner_params* params,
+                               const double* starts_xy, const double* goals_xy, const int32_t* goal_cells_xy, navgpu_navfn_result* results);
+
 #ifdef __cplusplus
 }
 #endif

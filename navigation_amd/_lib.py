@@ -163,6 +163,21 @@ class NavfnResult(C.Structure):
     _fields_ = [("found", C.c_int32), ("path_length", C.c_int32), ("cycles", C.c_int32), ("start_potential", C.c_float)]
 
 
+class GlobalPlannerParams(C.Structure):
+    """Mirror of navgpu_global_planner_params (include/navgpu.h); defaults = GlobalPlanner.cfg / planner_core.cpp:105-152."""
+    _fields_ = [("use_dijkstra", C.c_int32), ("use_quadratic", C.c_int32), ("use_grid_path", C.c_int32), ("old_navfn_behavior", C.c_int32),
+                ("allow_unknown", C.c_int32), ("lethal_cost", C.c_int32), ("neutral_cost", C.c_int32), ("cost_factor", C.c_float),
+                ("outline_map", C.c_int32), ("reserved", C.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        d = dict(use_dijkstra=1, use_quadratic=1, use_grid_path=0, old_navfn_behavior=0, allow_unknown=1, lethal_cost=253, neutral_cost=50,
+                 cost_factor=3.0, outline_map=1, reserved=0)
+        d.update(kw)
+        for k, v in d.items():
+            setattr(self, k, v)
+
+
 def lib_path():
     return os.path.join(_HERE, "libnavgpu.so")
 
@@ -234,6 +249,7 @@ SYMBOLS = [
     ("navgpu_navfn_set_costmap", C.c_int, [vp, u32, u32, vp, i32, i32, i32]),
     ("navgpu_navfn_set_costmap_from_fleet", C.c_int, [vp, u32, u32, vp, u32, i32]),
     ("navgpu_navfn_plan", C.c_int, [vp, u32, u32, vp, vp, i32, i32, vp]),
+    ("navgpu_global_planner_plan", C.c_int, [vp, u32, u32, C.POINTER(GlobalPlannerParams), vp, vp, vp, vp]),
     ("navgpu_navfn_path", C.c_int, [vp, u32, vp, u32]),
     ("navgpu_navfn_potential", C.c_int, [vp, u32, vp]),
     ("navgpu_footprint_radii", C.c_int, [vp, u32, C.POINTER(dbl), C.POINTER(dbl)]),

@@ -22,6 +22,10 @@ namespace navgpu {
 namespace {
 constexpr int kCostUnknownRos = 255, kCostObs = 254, kCostObsRos = 253, kCostNeutral = 50;  // navfn.h:49-67
 constexpr float kPotHigh = 1.0e10f;                                                          // navfn.h:77
+// `int minp = potarr[stc]` (navfn.cpp:895, gradient_path.cpp:119) with potarr[stc] == POT_HIGH is out of int range; the
+// amd64 builds of the reference get cvttss2si's 0x80000000 there (so no neighbour is lower and the trace ends with "high
+// potential"); v_cvt_i32_f32 would saturate to INT_MAX and walk on, so the amd64 value is restated.
+__device__ __forceinline__ int truncX86(float v) { return (v >= -2147483648.f && v < 2147483648.f) ? (int)v : (int)0x80000000; }
 constexpr int kPriorityBufSize = 10000;                                                      // navfn.h:80
 }  // namespace
 
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void k_navfn_plan(NavfnDev nv, uint32_t first,
         potarr[stcpx - 1] >= kPotHigh || oscillation_detected) {
       // potential-function boundary: follow the grid to the lowest of the eight neighbours (:893-925; minp is an int there)
       int minc = stc;
-      int minp = (int)potarr[stc];
+      int minp = truncX86(potarr[stc]);
       const int nb[8] = {stcpx - 1, stcpx, stcpx + 1, stc - 1, stc + 1, stcnx - 1, stcnx, stcnx + 1};
       for (int q = 0; q < 8; ++q)
         if (potarr[nb[q]] < (float)minp) {
@@ -278,6 +282,376 @@ __global__ __launch_bounds__(256) void k_navfn_plan(NavfnDev nv, uint32_t first,
   nv.results[plan] = r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// global_planner (the other half of SURVEY 8 f-4): what GlobalPlanner::makePlan runs between worldToMap and the plan
+// assembly (global_planner/src/planner_core.cpp:250-306) -
+//   outlineMap (:62-76), DijkstraExpansion::calculatePotentials / updateCell / getCost (dijkstra.cpp:71-229, dijkstra.h:78-87)
+//   or AStarExpansion::calculatePotentials / add (astar.cpp:46-95: std::push_heap / pop_heap with greater1),
+//   PotentialCalculator / QuadraticCalculator::calculatePotential (potential_calculator.h:50-59, quadratic_calculator.cpp:41-77),
+//   Expander::clearEndpoint (expander.h:76-89), GradientPath::getPath / gradCell (gradient_path.cpp:68-313) or
+//   GridPath::getPath (grid_path.cpp:44-82).
+// Same kind of process as NavFn's (priority buffers in buffer order, early stop at the goal cell), same treatment: one
+// lane per plan, bit for bit.  costarr holds the raw costmap bytes (navgpu_navfn_set_costmap with cost_mode 0).
+// ------------------------------------------------------------------------------------------------
+struct GpHeapEntry {  // astar.h:47-55 Index
+  int i;
+  float cost;
+};
+__global__ __launch_bounds__(256) void k_gp_plan(NavfnDev nv, uint32_t first, navgpu_global_planner_params gp, const double* starts, const double* goals,
+                                                 const int32_t* goal_cells, GpHeapEntry* heaps) {
+  const uint32_t plan = first + blockIdx.x;
+  const int nx = nv.nx, ny = nv.ny, ns = nv.ns;
+  uint8_t* costs = nv.costarr + (size_t)plan * nv.ns_padded;
+  uint8_t* pending = nv.pending + (size_t)plan * nv.ns_padded;
+  float* potential = nv.potarr + (size_t)plan * nv.ns_padded;
+  float* gradx = nv.gradx + (size_t)plan * nv.ns_padded;
+  float* grady = nv.grady + (size_t)plan * nv.ns_padded;
+  float* pathx = nv.path + (size_t)plan * 2 * nv.path_cap;
+  float* pathy = pathx + nv.path_cap;
+  const double start_x = starts[2 * blockIdx.x], start_y = starts[2 * blockIdx.x + 1];
+  const double goal_x = goals[2 * blockIdx.x], goal_y = goals[2 * blockIdx.x + 1];
+  const int lethal = gp.lethal_cost, neutral = gp.neutral_cost;
+  const float factor = gp.cost_factor;
+  const bool unknown = gp.allow_unknown != 0, quadratic = gp.use_quadratic != 0;
+  constexpr float kHigh = 1.0e10f;
+  // all lanes: the arrays every expansion starts from, and GlobalPlanner::outlineMap
+  for (int i = threadIdx.x; i < ns; i += blockDim.x) {
+    potential[i] = kHigh;
+    gradx[i] = 0.0f;
+    grady[i] = 0.0f;
+    pending[i] = 0;
+    const int y = i / nx, x = i - y * nx;
+    if (gp.outline_map && (y == 0 || y == ny - 1 || x == 0 || x == nx - 1)) costs[i] = 254;  // costmap_2d::LETHAL_OBSTACLE
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+
+  auto calculatePotential = [&](uint8_t cost, int n, float prev_potential) -> float {
+    if (!quadratic) {
+      if (prev_potential < 0) {
+        const float min_h = fminf(potential[n - 1], potential[n + 1]), min_v = fminf(potential[n - nx], potential[n + nx]);
+        prev_potential = fminf(min_h, min_v);
+      }
+      return prev_potential + cost;
+    }
+    const float l = potential[n - 1], r = potential[n + 1], u = potential[n - nx], d = potential[n + nx];
+    float ta, tc;
+    if (l < r) tc = l; else tc = r;
+    if (u < d) ta = u; else ta = d;
+    const float hf = cost;
+    float dc = tc - ta;
+    if (dc < 0) {
+      dc = -dc;
+      ta = tc;
+    }
+    if (dc >= hf) return ta + hf;
+    const float dd = dc / hf;
+    const float v = (float)(-0.2301 * dd * dd + 0.5307 * dd + 0.7040);
+    return ta + hf * v;
+  };
+  auto getCost = [&](int n) -> float {
+    float c = costs[n];
+    if (c < lethal - 1 || (unknown && c == 255)) {
+      c = c * factor + neutral;
+      if (c >= lethal) c = lethal - 1;
+      return c;
+    }
+    return lethal;
+  };
+  const int cycles = nx * ny * 2;
+  int cycle = 0;
+  bool found_legal = false;
+  const int endCell = (int)goal_x + nx * (int)goal_y;
+  if (gp.use_dijkstra) {
+    int* cur = nv.pb + (size_t)plan * 3 * kPriorityBufSize;
+    int* nxt = cur + kPriorityBufSize;
+    int* ovr = nxt + kPriorityBufSize;
+    int curE = 0, nxtE = 0, ovrE = 0;
+    float threshold = lethal;
+    const float priorityIncrement = 2 * neutral;
+    auto push = [&](int* buf, int& end, int n) {
+      if (n >= 0 && n < ns && !pending[n] && getCost(n) < lethal && end < kPriorityBufSize) {
+        buf[end++] = n;
+        pending[n] = 1;
+      }
+    };
+    const int k = (int)start_x + nx * (int)start_y;
+    if (!gp.old_navfn_behavior) {  // setPreciseStart(true) (planner_core.cpp:124-127)
+      double dx = start_x - (int)start_x, dy = start_y - (int)start_y;
+      dx = floorf((float)(dx * 100 + 0.5)) / 100;
+      dy = floorf((float)(dy * 100 + 0.5)) / 100;
+      potential[k] = (float)(neutral * 2 * dx * dy);
+      potential[k + 1] = (float)(neutral * 2 * (1 - dx) * dy);
+      potential[k + nx] = (float)(neutral * 2 * dx * (1 - dy));
+      potential[k + nx + 1] = (float)(neutral * 2 * (1 - dx) * (1 - dy));
+      push(cur, curE, k + 2);
+      push(cur, curE, k - 1);
+      push(cur, curE, k + nx - 1);
+      push(cur, curE, k + nx + 2);
+      push(cur, curE, k - nx);
+      push(cur, curE, k - nx + 1);
+      push(cur, curE, k + nx * 2);
+      push(cur, curE, k + nx * 2 + 1);
+    } else {
+      potential[k] = 0;
+      push(cur, curE, k + 1);
+      push(cur, curE, k - 1);
+      push(cur, curE, k - nx);
+      push(cur, curE, k + nx);
+    }
+    bool ran_dry = false;
+    for (; cycle < cycles; cycle++) {
+      if (curE == 0 && nxtE == 0) {
+        ran_dry = true;
+        break;
+      }
+      for (int i = 0; i < curE; i++) pending[cur[i]] = 0;
+      for (int i = 0; i < curE; i++) {  // updateCell
+        const int n = cur[i];
+        const float c = getCost(n);
+        if (c >= lethal) continue;
+        const float pot = calculatePotential((uint8_t)c, n, -1.0f);
+        if (pot < potential[n]) {
+          const float le = (float)(0.707106781 * (float)getCost(n - 1));
+          const float re = (float)(0.707106781 * (float)getCost(n + 1));
+          const float ue = (float)(0.707106781 * (float)getCost(n - nx));
+          const float de = (float)(0.707106781 * (float)getCost(n + nx));
+          potential[n] = pot;
+          if (pot < threshold) {
+            if (potential[n - 1] > pot + le) push(nxt, nxtE, n - 1);
+            if (potential[n + 1] > pot + re) push(nxt, nxtE, n + 1);
+            if (potential[n - nx] > pot + ue) push(nxt, nxtE, n - nx);
+            if (potential[n + nx] > pot + de) push(nxt, nxtE, n + nx);
+          } else {
+            if (potential[n - 1] > pot + le) push(ovr, ovrE, n - 1);
+            if (potential[n + 1] > pot + re) push(ovr, ovrE, n + 1);
+            if (potential[n - nx] > pot + ue) push(ovr, ovrE, n - nx);
+            if (potential[n + nx] > pot + de) push(ovr, ovrE, n + nx);
+          }
+        }
+      }
+      curE = nxtE;
+      nxtE = 0;
+      int* t = cur;
+      cur = nxt;
+      nxt = t;
+      if (curE == 0) {
+        threshold += priorityIncrement;
+        curE = ovrE;
+        ovrE = 0;
+        t = cur;
+        cur = ovr;
+        ovr = t;
+      }
+      if (potential[endCell] < kHigh) break;
+    }
+    found_legal = !ran_dry && cycle < cycles;
+  } else {
+    GpHeapEntry* heap = heaps + (size_t)plan * nv.ns_padded;
+    long len = 0;
+    auto pushHeap = [&](long hole, const GpHeapEntry value) {  // std::__push_heap with greater1: parent.cost > value.cost moves down
+      long parent = (hole - 1) / 2;
+      while (hole > 0 && heap[parent].cost > value.cost) {
+        heap[hole] = heap[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+      }
+      heap[hole] = value;
+    };
+    const int start_i = (int)start_x + nx * (int)start_y;
+    heap[len++] = GpHeapEntry{start_i, 0.0f};  // queue_.push_back(Index(start_i, 0)) - no push_heap on the first element
+    potential[start_i] = 0;
+    const int ex = (int)goal_x, ey = (int)goal_y;
+    auto add = [&](float prev_potential, int next_i) {
+      if (next_i < 0 || next_i >= ns) return;
+      if (potential[next_i] < kHigh) return;
+      if (costs[next_i] >= lethal && !(unknown && costs[next_i] == 255)) return;
+      potential[next_i] = calculatePotential((uint8_t)(costs[next_i] + neutral), next_i, prev_potential);
+      const int x = next_i % nx, y = next_i / nx;
+      const float distance = (float)(abs(ex - x) + abs(ey - y));
+      pushHeap(len, GpHeapEntry{next_i, potential[next_i] + distance * neutral});
+      ++len;
+    };
+    while (len > 0 && cycle < cycles) {
+      const GpHeapEntry top = heap[0];
+      if (len > 1) {  // std::pop_heap: __adjust_heap(first, 0, len - 1, value = last element)
+        const GpHeapEntry value = heap[len - 1];
+        const long l = len - 1;
+        long hole = 0, child = 0;
+        while (child < (l - 1) / 2) {
+          child = 2 * (child + 1);
+          if (heap[child].cost > heap[child - 1].cost) child--;
+          heap[hole] = heap[child];
+          hole = child;
+        }
+        if ((l & 1) == 0 && child == (l - 2) / 2) {
+          child = 2 * (child + 1);
+          heap[hole] = heap[child - 1];
+          hole = child - 1;
+        }
+        pushHeap(hole, value);
+      }
+      --len;
+      const int i = top.i;
+      if (i == endCell) {
+        found_legal = true;
+        break;
+      }
+      add(potential[i], i + 1);
+      add(potential[i], i - 1);
+      add(potential[i], i + nx);
+      add(potential[i], i - nx);
+      cycle++;
+    }
+  }
+  if (!gp.old_navfn_behavior) {  // Expander::clearEndpoint(costs, potential, goal_x_i, goal_y_i, 2) (expander.h:76-89)
+    const int startCell = goal_cells[2 * blockIdx.x] + nx * goal_cells[2 * blockIdx.x + 1];
+    for (int i = -2; i <= 2; i++)
+      for (int j = -2; j <= 2; j++) {
+        const int n = startCell + i + nx * j;
+        if (n < nx + 1 || n >= ns - nx - 1) continue;  // (the reference reads outside its arrays for a goal this close to the border)
+        if (potential[n] < kHigh) continue;
+        const float c = (float)(costs[n] + neutral);
+        potential[n] = calculatePotential((uint8_t)c, n, -1.0f);
+      }
+  }
+  // ---- traceback (only when a legal potential was found, planner_core.cpp:303-311)
+  int npath = 0, found = 0;
+  float last3x[3] = {0, 0, 0}, last3y[3] = {0, 0, 0};  // the path's last three points (all of it may not fit the buffer)
+  auto pushPoint = [&](float x, float y) {
+    if (npath < (int)nv.path_cap) {
+      pathx[npath] = x;
+      pathy[npath] = y;
+    }
+    last3x[0] = last3x[1];
+    last3y[0] = last3y[1];
+    last3x[1] = last3x[2];
+    last3y[1] = last3y[2];
+    last3x[2] = x;
+    last3y[2] = y;
+    ++npath;
+  };
+  if (found_legal && !gp.use_grid_path) {  // GradientPath::getPath (gradient_path.cpp:68-248)
+    auto gradCell = [&](int n) {
+      if (gradx[n] + grady[n] > 0.0) return;
+      if (n < nx || n > nx * ny - nx) return;
+      const float cv = potential[n];
+      float dx = 0.0f, dy = 0.0f;
+      if (cv >= kHigh) {
+        if (potential[n - 1] < kHigh)
+          dx = -lethal;
+        else if (potential[n + 1] < kHigh)
+          dx = lethal;
+        if (potential[n - nx] < kHigh)
+          dy = -lethal;
+        else if (potential[nx + 1] < kHigh)  // as written in the reference (:287)
+          dy = lethal;
+      } else {
+        if (potential[n - 1] < kHigh) dx += potential[n - 1] - cv;
+        if (potential[n + 1] < kHigh) dx += cv - potential[n + 1];
+        if (potential[n - nx] < kHigh) dy += potential[n - nx] - cv;
+        if (potential[n + nx] < kHigh) dy += cv - potential[n + nx];
+      }
+      float norm = (float)hypot((double)dx, (double)dy);
+      if (norm > 0) {
+        norm = (float)(1.0 / norm);
+        gradx[n] = norm * dx;
+        grady[n] = norm * dy;
+      }
+    };
+    int stc = (int)goal_x + nx * (int)goal_y;
+    float dx = (float)(goal_x - (int)goal_x), dy = (float)(goal_y - (int)goal_y);
+    const long lim = (long)ns * 4;
+    long c = 0;
+    while (c++ < lim) {
+      const double px = stc % nx + dx, py = stc / nx + dy;
+      if (fabs(px - start_x) < .5 && fabs(py - start_y) < .5) {
+        pushPoint((float)start_x, (float)start_y);
+        found = 1;
+        break;
+      }
+      if (stc < nx || stc > nx * ny - nx) break;
+      pushPoint((float)px, (float)py);
+      const bool oscillation_detected = npath > 2 && last3x[2] == last3x[0] && last3y[2] == last3y[0];
+      const int stcnx = stc + nx, stcpx = stc - nx;
+      if (potential[stc] >= kHigh || potential[stc + 1] >= kHigh || potential[stc - 1] >= kHigh || potential[stcnx] >= kHigh ||
+          potential[stcnx + 1] >= kHigh || potential[stcnx - 1] >= kHigh || potential[stcpx] >= kHigh || potential[stcpx + 1] >= kHigh ||
+          potential[stcpx - 1] >= kHigh || oscillation_detected) {
+        int minc = stc;
+        int minp = truncX86(potential[stc]);
+        const int nb[8] = {stcpx - 1, stcpx, stcpx + 1, stc - 1, stc + 1, stcnx - 1, stcnx, stcnx + 1};
+        for (int q = 0; q < 8; ++q)
+          if (potential[nb[q]] < (float)minp) {
+            minp = (int)potential[nb[q]];
+            minc = nb[q];
+          }
+        stc = minc;
+        dx = 0;
+        dy = 0;
+        if (potential[stc] >= kHigh) break;
+      } else {
+        gradCell(stc);
+        gradCell(stc + 1);
+        gradCell(stcnx);
+        gradCell(stcnx + 1);
+        const float x1 = (float)((1.0 - dx) * gradx[stc] + dx * gradx[stc + 1]);
+        const float x2 = (float)((1.0 - dx) * gradx[stcnx] + dx * gradx[stcnx + 1]);
+        const float x = (float)((1.0 - dy) * x1 + dy * x2);
+        const float y1 = (float)((1.0 - dx) * grady[stc] + dx * grady[stc + 1]);
+        const float y2 = (float)((1.0 - dx) * grady[stcnx] + dx * grady[stcnx + 1]);
+        const float y = (float)((1.0 - dy) * y1 + dy * y2);
+        if (x == 0.0 && y == 0.0) break;
+        const float ss = (float)(0.5f / hypot((double)x, (double)y));  // pathStep_ = 0.5 (:47)
+        dx += x * ss;
+        dy += y * ss;
+        if (dx > 1.0) { stc++; dx = (float)(dx - 1.0); }
+        if (dx < -1.0) { stc--; dx = (float)(dx + 1.0); }
+        if (dy > 1.0) { stc += nx; dy = (float)(dy - 1.0); }
+        if (dy < -1.0) { stc -= nx; dy = (float)(dy + 1.0); }
+      }
+    }
+  } else if (found_legal) {  // GridPath::getPath (grid_path.cpp:44-82)
+    float cx = (float)goal_x, cy = (float)goal_y;
+    const int start_index = (int)start_x + nx * (int)start_y;
+    pushPoint(cx, cy);
+    long c = 0;
+    found = 1;
+    while ((int)cx + nx * (int)cy != start_index) {
+      float min_val = 1e10f;
+      int min_x = 0, min_y = 0;
+      for (int xd = -1; xd <= 1; xd++)
+        for (int yd = -1; yd <= 1; yd++) {
+          if (xd == 0 && yd == 0) continue;
+          const int x = (int)(cx + xd), y = (int)(cy + yd);
+          const int index = x + nx * y;
+          if (index < 0 || index >= ns) continue;  // (the reference reads outside its array here)
+          if (potential[index] < min_val) {
+            min_val = potential[index];
+            min_x = x;
+            min_y = y;
+          }
+        }
+      if (min_x == 0 && min_y == 0) {
+        found = 0;
+        break;
+      }
+      cx = (float)min_x;
+      cy = (float)min_y;
+      pushPoint(cx, cy);
+      if (c++ > (long)ns * 4) {
+        found = 0;
+        break;
+      }
+    }
+  }
+  navgpu_navfn_result r;
+  r.found = (found && npath <= (int)nv.path_cap) ? 1 : 0;
+  r.path_length = r.found ? npath : 0;
+  r.cycles = cycle;
+  r.start_potential = potential[endCell];
+  nv.results[plan] = r;
+}
+
 void launch_navfn_costmap(const NavfnDev& nv, uint32_t first, uint32_t count, const uint8_t* cmap, size_t stride, int cost_mode, int allow_unknown,
                           hipStream_t s) {
   hipLaunchKernelGGL(k_navfn_costmap, dim3((nv.ns + 255) / 256, count), dim3(256), 0, s, nv, first, cmap, stride, cost_mode, allow_unknown);
@@ -285,6 +659,11 @@ void launch_navfn_costmap(const NavfnDev& nv, uint32_t first, uint32_t count, co
 void launch_navfn_plan(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* goals, const int32_t* starts, int astar, int at_start,
                        hipStream_t s) {
   hipLaunchKernelGGL(k_navfn_plan, dim3(count), dim3(256), 0, s, nv, first, goals, starts, astar, at_start);
+}
+
+void launch_gp_plan(const NavfnDev& nv, uint32_t first, uint32_t count, const navgpu_global_planner_params& gp, const double* starts,
+                    const double* goals, const int32_t* goal_cells, void* heaps, hipStream_t s) {
+  hipLaunchKernelGGL(k_gp_plan, dim3(count), dim3(256), 0, s, nv, first, gp, starts, goals, goal_cells, static_cast<GpHeapEntry*>(heaps));
 }
 
 }  // namespace navgpu

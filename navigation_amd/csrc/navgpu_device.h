@@ -250,6 +250,8 @@ struct NavfnDev {
 };
 void launch_navfn_costmap(const NavfnDev& nv, uint32_t first, uint32_t count, const uint8_t* cmap, size_t stride, int cost_mode, int allow_unknown,
                           hipStream_t s);
+void launch_gp_plan(const NavfnDev& nv, uint32_t first, uint32_t count, const navgpu_global_planner_params& gp, const double* starts,
+                    const double* goals, const int32_t* goal_cells, void* heaps, hipStream_t s);
 void launch_navfn_plan(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* goals, const int32_t* starts, int astar, int at_start,
                        hipStream_t s);
 

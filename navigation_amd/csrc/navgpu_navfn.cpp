@@ -11,6 +11,8 @@ struct navgpu_navfn {
   int32_t* d_goal = nullptr;   // [n][2]
   int32_t* d_start = nullptr;  // [n][2]
   navgpu_navfn_result* h_results = nullptr;  // pinned
+  double* d_xy = nullptr;      // [n][2][2] start / goal map coordinates (global_planner)
+  void* d_heap = nullptr;      // [n][ns_padded] AStarExpansion's queue_, allocated when A* is first asked for
   template <class T>
   int alloc(T** p, size_t count) {
     void* q = nullptr;
@@ -64,6 +66,7 @@ int navgpu_navfn_create(uint32_t nx, uint32_t ny, uint32_t n_plans, int32_t devi
   A(h->d_cmap, (size_t)n_plans * nv.ns_padded);
   A(h->d_goal, (size_t)n_plans * 2);
   A(h->d_start, (size_t)n_plans * 2);
+  A(h->d_xy, (size_t)n_plans * 4);
 #undef A
   if (!rc && hipHostMalloc((void**)&h->h_results, sizeof(navgpu_navfn_result) * n_plans, hipHostMallocDefault) != hipSuccess) rc = NAVGPU_ERR_HIP;
   if (rc) {
@@ -125,6 +128,37 @@ int navgpu_navfn_plan(navgpu_navfn* h, uint32_t first, uint32_t count, const int
   HIP_TRY(hipMemcpyAsync(h->d_goal, goals, sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_start, starts, sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, h->stream));
   launch_navfn_plan(nv, first, count, h->d_goal, h->d_start, astar ? 1 : 0, at_start ? 1 : 0, h->stream);
+  HIP_TRY(hipMemcpyAsync(h->h_results + first, nv.results + first, sizeof(navgpu_navfn_result) * count, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(waitStream(h->stream));
+  if (results) memcpy(results, h->h_results + first, sizeof(navgpu_navfn_result) * count);
+  return checkLaunch();
+}
+
+int navgpu_global_planner_plan(navgpu_navfn* h, uint32_t first, uint32_t count, const navgpu_global_planner_params* gp, const double* starts,
+                               const double* goals, const int32_t* goal_cells, navgpu_navfn_result* results) {
+  if (!h || !gp || !starts || !goals || !goal_cells || !navfnRange(h, first, count)) return NAVGPU_ERR_INVALID;
+  const NavfnDev& nv = h->nv;
+  if (gp->lethal_cost < 2 || gp->lethal_cost > 255 || gp->neutral_cost < 0 || gp->neutral_cost > 255) return NAVGPU_ERR_INVALID;
+  for (uint32_t k = 0; k < count; ++k) {  // the reference indexes its arrays with these without a check: keep them inside the outline
+    const double sx = starts[2 * k], sy = starts[2 * k + 1], gx = goals[2 * k], gy = goals[2 * k + 1];
+    const int32_t gi = goal_cells[2 * k], gj = goal_cells[2 * k + 1];
+    if (!(sx >= 2 && sy >= 2 && sx < nv.nx - 3 && sy < nv.ny - 3 && gx >= 1 && gy >= 1 && gx < nv.nx - 1 && gy < nv.ny - 1) || gi < 0 || gj < 0 ||
+        gi >= nv.nx || gj >= nv.ny) {
+      g_last_error = "navgpu_global_planner_plan: start / goal too close to the map border";
+      return NAVGPU_ERR_INVALID;
+    }
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  if (!gp->use_dijkstra && !h->d_heap) {
+    uint64_t* q = nullptr;  // 8 bytes per entry (int index, float cost); a cell enters the queue at most once
+    int rc = h->alloc(&q, (size_t)h->n * nv.ns_padded);
+    if (rc) return rc;
+    h->d_heap = q;
+  }
+  HIP_TRY(hipMemcpyAsync(h->d_xy, starts, sizeof(double) * 2 * count, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_xy + (size_t)2 * h->n, goals, sizeof(double) * 2 * count, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_goal, goal_cells, sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, h->stream));
+  launch_gp_plan(nv, first, count, *gp, h->d_xy, h->d_xy + (size_t)2 * h->n, h->d_goal, h->d_heap, h->stream);
   HIP_TRY(hipMemcpyAsync(h->h_results + first, nv.results + first, sizeof(navgpu_navfn_result) * count, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(waitStream(h->stream));
   if (results) memcpy(results, h->h_results + first, sizeof(navgpu_navfn_result) * count);

@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import NavfnResult, check, lib
+from ._lib import GlobalPlannerParams, NavfnResult, check, lib
 
 
 class NavFn:
@@ -55,6 +55,17 @@ class NavFn:
         res = (NavfnResult * len(g))()
         check(self.L.navgpu_navfn_plan(self.h, first, len(g), g.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), int(astar), int(at_start),
                                        C.cast(res, C.c_void_p)), "navfn_plan")
+        return list(res)
+
+    def global_planner_plan(self, starts_xy, goals_xy, goal_cells, first=0, **params):
+        """GlobalPlanner::makePlan's expansion + traceback (map coordinates; costs set with cost_mode=0)."""
+        st = np.ascontiguousarray(starts_xy, np.float64).reshape(-1, 2)
+        gl = np.ascontiguousarray(goals_xy, np.float64).reshape(-1, 2)
+        gc = np.ascontiguousarray(goal_cells, np.int32).reshape(-1, 2)
+        gp = GlobalPlannerParams(**params)
+        res = (NavfnResult * len(st))()
+        check(self.L.navgpu_global_planner_plan(self.h, first, len(st), C.byref(gp), st.ctypes.data_as(C.c_void_p), gl.ctypes.data_as(C.c_void_p),
+                                                gc.ctypes.data_as(C.c_void_p), C.cast(res, C.c_void_p)), "global_planner_plan")
         return list(res)
 
     def path(self, plan=0):

@@ -16,6 +16,13 @@
 #include <vector>
 
 namespace oracle {
+#ifndef ORACLE_TRUNC_X86
+#define ORACLE_TRUNC_X86
+// `int minp = potarr[stc]` with potarr[stc] == POT_HIGH (1e10) is out of int range: undefined in C++, and on every amd64
+// build of the reference it is cvttss2si's "integer indefinite" 0x80000000.  Stated explicitly so the oracle does not
+// depend on how this compiler folds the conversion; the HIP path restates the same value (its own cvt saturates).
+static inline int truncX86(float v) { return (v >= -2147483648.f && v < 2147483648.f) ? (int)v : (int)0x80000000; }
+#endif
 
 struct NavFnOracle {
   static constexpr int kCostUnknownRos = 255, kCostObs = 254, kCostObsRos = 253, kCostNeutral = 50;  // navfn.h:49-67
@@ -242,7 +249,7 @@ struct NavFnOracle {
           potarr[stcnx + 1] >= kPotHigh || potarr[stcnx - 1] >= kPotHigh || potarr[stcpx] >= kPotHigh || potarr[stcpx + 1] >= kPotHigh ||
           potarr[stcpx - 1] >= kPotHigh || oscillation_detected) {
         int minc = stc;
-        int minp = potarr[stc];  // sic: int (:895)
+        int minp = truncX86(potarr[stc]);  // sic: int (:895)
         int st = stcpx - 1;
         if (potarr[st] < minp) { minp = potarr[st]; minc = st; }
         st++;

@@ -4,6 +4,7 @@
 
 #include "../include/navgpu.h"  // POD layouts only (navgpu_dwa_config, navgpu_plan_result)
 #include "planner_oracle.hpp"
+#include "global_planner_oracle.hpp"
 #include "navfn_oracle.hpp"
 #include "trajectory_planner_oracle.hpp"
 
@@ -730,5 +731,53 @@ int orc_navfn_plan(const uint8_t* cmap, int nx, int ny, int cost_mode, int allow
     path_xy[2 * i + 1] = nav.pathy[i];
   }
   return len;
+}
+// ------------------------------------------------------------------ global_planner (second half)
+// params = {use_dijkstra, use_quadratic, use_grid_path, old_navfn_behavior, allow_unknown, lethal_cost, neutral_cost, outline_map}
+int orc_global_planner_plan(const uint8_t* cmap, int nx, int ny, const int* params, float cost_factor, const double* start_xy, const double* goal_xy,
+                            const int* goal_cell, float* potential_out, float* path_xy, int path_cap, int* found_legal, int* cycles_used) {
+  GlobalPlannerParams p;
+  p.use_dijkstra = params[0];
+  p.use_quadratic = params[1];
+  p.use_grid_path = params[2];
+  p.old_navfn_behavior = params[3];
+  p.allow_unknown = params[4];
+  p.lethal_cost = params[5];
+  p.neutral_cost = params[6];
+  p.outline_map = params[7];
+  p.cost_factor = cost_factor;
+  GlobalPlannerOracle gp(nx, ny, p);
+  bool legal = false;
+  const bool ok = gp.plan(cmap, start_xy[0], start_xy[1], goal_xy[0], goal_xy[1], goal_cell[0], goal_cell[1], &legal);
+  if (found_legal) *found_legal = legal;
+  if (cycles_used) *cycles_used = gp.cycles_used;
+  if (potential_out) memcpy(potential_out, gp.potential.data(), sizeof(float) * (size_t)nx * ny);
+  const int len = ok ? (int)gp.path.size() : 0;
+  for (int i = 0; i < len && i < path_cap && path_xy; ++i) {
+    path_xy[2 * i] = gp.path[i].first;
+    path_xy[2 * i + 1] = gp.path[i].second;
+  }
+  return len;
+}
+// the two pieces of the global_planner oracle that oracle/_ref/libref_gp.so can check directly
+void orc_gp_calculate_potential(int quadratic, const float* potential, int nx, int ny, const uint8_t* cost, const int* cells, const float* prev,
+                                int count, float* out) {
+  GlobalPlannerParams p;
+  p.use_quadratic = quadratic;
+  GlobalPlannerOracle gp(nx, ny, p);
+  memcpy(gp.potential.data(), potential, sizeof(float) * (size_t)nx * ny);
+  for (int i = 0; i < count; ++i) out[i] = gp.calculatePotential(cost[i], cells[i], prev[i]);
+}
+int orc_gp_grid_path(const float* potential, int nx, int ny, double start_x, double start_y, double end_x, double end_y, float* path_xy, int cap) {
+  GlobalPlannerParams p;
+  GlobalPlannerOracle gp(nx, ny, p);
+  memcpy(gp.potential.data(), potential, sizeof(float) * (size_t)nx * ny);
+  if (!gp.gridPath(start_x, start_y, end_x, end_y)) return 0;
+  const int n = (int)gp.path.size();
+  for (int i = 0; i < n && i < cap; ++i) {
+    path_xy[2 * i] = gp.path[i].first;
+    path_xy[2 * i + 1] = gp.path[i].second;
+  }
+  return n;
 }
 }  // extern "C"

@@ -155,6 +155,9 @@ def lib():
     sig("orc_tp_get_state", None, vp, C.c_void_p)
     sig("orc_tp_set_state", None, vp, C.c_void_p)
     sig("orc_tp_footprint_cells", i, u, u, d, d, d, f32p, f64p, u, i, C.c_void_p, i)
+    sig("orc_gp_calculate_potential", None, i, f32p, i, i, u8p, i32p, f32p, i, f32p)
+    sig("orc_gp_grid_path", i, f32p, i, i, C.c_double, C.c_double, C.c_double, C.c_double, f32p, i)
+    sig("orc_global_planner_plan", i, u8p, i, i, i32p, C.c_float, f64p, f64p, i32p, C.c_void_p, C.c_void_p, i, C.POINTER(i), C.POINTER(i))
     sig("orc_navfn_plan", i, u8p, i, i, i, i, i32p, i32p, i, i, C.c_void_p, C.c_void_p, i, C.POINTER(i))
     sig("orc_bench_dwa", d, u, u, d, u8p, u, C.POINTER(DwaConfig), f32p, f32p, f64p, u, f64p, f64p, u, u, u,
         C.POINTER(C.c_uint64))
@@ -179,6 +182,26 @@ def ref():
     R.ref_cost_values.restype = None
     R.ref_cost_values.argtypes = [u8p]
     _REF = R
+    return R
+
+
+_REF_GP = None
+
+
+def ref_gp():
+    """The reference's own QuadraticCalculator / PotentialCalculator / GridPath (oracle/_ref/libref_gp.so), or None when not built."""
+    global _REF_GP
+    if _REF_GP is not None:
+        return _REF_GP
+    path = os.path.join(_HERE, "_ref", "libref_gp.so")
+    if not os.path.exists(path):
+        return None
+    R = C.CDLL(path)
+    R.ref_gp_calculate_potential.restype = None
+    R.ref_gp_calculate_potential.argtypes = [C.c_int, f32p, C.c_int, C.c_int, u8p, i32p, f32p, C.c_int, f32p]
+    R.ref_gp_grid_path.restype = C.c_int
+    R.ref_gp_grid_path.argtypes = [f32p, C.c_int, C.c_int] + [C.c_double] * 4 + [f32p, C.c_int]
+    _REF_GP = R
     return R
 
 
@@ -528,3 +551,26 @@ def navfn_plan(cmap, goal, start, cost_mode=1, allow_unknown=True, astar=False, 
     n = lib().orc_navfn_plan(g, nx, ny, cost_mode, int(allow_unknown), np.ascontiguousarray(goal, np.int32), np.ascontiguousarray(start, np.int32),
                              int(astar), int(at_start), pot.ctypes.data if want_potential else None, path.ctypes.data, cap, C.byref(cyc))
     return path[:n].copy(), pot, cyc.value
+
+
+GP_DEFAULTS = dict(use_dijkstra=1, use_quadratic=1, use_grid_path=0, old_navfn_behavior=0, allow_unknown=1, lethal_cost=253, neutral_cost=50,
+                   outline_map=1, cost_factor=3.0)
+
+
+def global_planner_plan(cmap, start_xy, goal_xy, goal_cell, **params):
+    """global_planner (global_planner_oracle.hpp): the expansion + traceback of GlobalPlanner::makePlan on map coordinates.
+    Returns (path (n, 2) float32 goal first, potential (ny, nx) float32, found_legal, cycles)."""
+    pr = dict(GP_DEFAULTS)
+    pr.update(params)
+    g = np.ascontiguousarray(cmap, np.uint8)
+    ny, nx = g.shape
+    pot = np.zeros((ny, nx), np.float32)
+    cap = 4 * nx * ny + 4
+    path = np.zeros((min(cap, 1 << 22), 2), np.float32)
+    legal, cyc = C.c_int(), C.c_int()
+    ints = np.array([pr[k] for k in ("use_dijkstra", "use_quadratic", "use_grid_path", "old_navfn_behavior", "allow_unknown", "lethal_cost",
+                                     "neutral_cost", "outline_map")], np.int32)
+    n = lib().orc_global_planner_plan(g, nx, ny, ints, float(pr["cost_factor"]), np.ascontiguousarray(start_xy, np.float64),
+                                      np.ascontiguousarray(goal_xy, np.float64), np.ascontiguousarray(goal_cell, np.int32), pot.ctypes.data,
+                                      path.ctypes.data, len(path), C.byref(legal), C.byref(cyc))
+    return path[:n].copy(), pot, bool(legal.value), cyc.value

@@ -133,3 +133,129 @@ def test_navfn_costmap_from_fleet(orc):
         assert np.array_equal(nf.path(k).view(np.uint32), path.view(np.uint32))
     nf.close()
     fl.close()
+
+
+# ------------------------------------------------------------------------------------------------ global_planner
+GP_VARIANTS = [dict(), dict(use_quadratic=0), dict(use_grid_path=1), dict(old_navfn_behavior=1), dict(use_dijkstra=0),
+               dict(use_dijkstra=0, use_quadratic=0, use_grid_path=1), dict(allow_unknown=0, cost_factor=0.55, neutral_cost=66)]
+
+
+def _gp_case(rs, n):
+    cm = _random_costmap(rs, n, 0.03)
+    start = rs.uniform(8, n - 9, 2)
+    goal = rs.uniform(8, n - 9, 2)
+    for x, y in (start, goal):
+        cm[int(y) - 1:int(y) + 3, int(x) - 1:int(x) + 3] = 0
+    return cm, start, goal
+
+
+def test_oracle_global_planner_basic_properties(orc):
+    """Open field: every variant reaches the goal; the traceback starts at the goal and ends at the start."""
+    n = 60
+    cm = np.zeros((n, n), np.uint8)
+    for kw in GP_VARIANTS:
+        start, goal = (12.3, 40.7), (47.6, 15.2)
+        if kw.get("old_navfn_behavior"):
+            start, goal = (12.0, 40.0), (47.0, 15.0)
+        path, pot, legal, cyc = orc.global_planner_plan(cm, start, goal, (int(goal[0]), int(goal[1])), **kw)
+        assert legal, kw
+        if not kw.get("use_dijkstra", 1) and not kw.get("use_grid_path"):
+            # A*'s narrow corridor + the interpolated gradient descent: the descent steps onto a cell A* never reached and
+            # `int minp = potential[stc]` (gradient_path.cpp:119) ends the trace -- the reference's known A*/gradient failure
+            assert len(path) == 0
+            continue
+        assert len(path) > 1, kw
+        assert abs(path[0][0] - goal[0]) < 1.01 and abs(path[0][1] - goal[1]) < 1.01
+        assert abs(path[-1][0] - start[0]) < 1.01 and abs(path[-1][1] - start[1]) < 1.01
+        assert pot[0, 0] >= 1e9  # the outline is lethal: never assigned
+    cm[:, 30] = 254
+    path, pot, legal, cyc = orc.global_planner_plan(cm, (12.3, 40.7), (47.6, 15.2), (47, 15))
+    assert not legal and len(path) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", GP_VARIANTS)
+def test_global_planner_batch_matches_oracle(orc, kw):
+    import navigation_amd as nav
+    rs = np.random.RandomState(21)
+    n, nI = 110, 5
+    cases = [_gp_case(rs, n) for _ in range(nI)]
+    nf = nav.NavFn(n, n, nI)
+    nf.set_costmap(np.stack([c[0] for c in cases]), cost_mode=0)
+    starts = np.array([c[1] for c in cases])
+    goals = np.array([c[2] for c in cases])
+    if kw.get("old_navfn_behavior"):
+        starts, goals = np.floor(starts), np.floor(goals)
+    cells = goals.astype(np.int32)
+    res = nf.global_planner_plan(starts, goals, cells, **kw)
+    n_found = 0
+    for k in range(nI):
+        path, pot, legal, cyc = orc.global_planner_plan(cases[k][0], starts[k], goals[k], cells[k], **kw)
+        assert res[k].cycles == cyc, (k, res[k].cycles, cyc)
+        assert np.array_equal(nf.potential(k).view(np.uint32), pot.view(np.uint32)), f"plan {k}: potential arrays differ"
+        assert bool(res[k].found) == (len(path) > 0) and res[k].path_length == len(path)
+        assert np.array_equal(nf.path(k).view(np.uint32), path.view(np.uint32)), f"plan {k}: paths differ"
+        n_found += len(path) > 0
+    assert n_found >= 2
+    nf.close()
+
+
+@pytest.mark.gpu
+def test_global_planner_on_willow(orc, willow):
+    """The reference's willow map (as a costmap: 254 obstacles) through both expanders and both tracebacks."""
+    import navigation_amd as nav
+    ny, nx = willow.shape
+    nf = nav.NavFn(nx, ny, 2)
+    nf.set_costmap(willow, cost_mode=0)
+    starts, goals = [[428.3, 746.6], [350.5, 400.5]], [[350.4, 450.2], [350.5, 450.5]]
+    # the pinch point is a corridor of 253s: passable for navfn's tests (obstacles >= 254), for global_planner only with
+    # lethal_cost 255 (dijkstra.h:80-92: c < lethal_cost - 1 is traversable)
+    for kw in (dict(lethal_cost=255), dict(lethal_cost=255, use_dijkstra=0, use_grid_path=1), dict(lethal_cost=255, cost_factor=0.2, use_quadratic=0)):
+        res = nf.global_planner_plan(starts, goals, np.floor(goals).astype(np.int32), **kw)
+        for k in range(2):
+            path, pot, legal, cyc = orc.global_planner_plan(willow, starts[k], goals[k], [int(goals[k][0]), int(goals[k][1])], **kw)
+            assert legal and res[k].found and res[k].cycles == cyc
+            assert np.array_equal(nf.potential(k).view(np.uint32), pot.view(np.uint32))
+            assert np.array_equal(nf.path(k).view(np.uint32), path.view(np.uint32))
+    nf.close()
+
+
+# ------------------------------------------------------------------------------------------------ oracle/_ref: global_planner pieces
+def test_ref_potential_calculators_match_oracle(orc):
+    """The reference's own PotentialCalculator / QuadraticCalculator (compiled in place into oracle/_ref/libref_gp.so)
+    against the oracle's calculatePotential, bit for bit, over random neighbourhoods incl. POT_HIGH neighbours."""
+    R = orc.ref_gp()
+    if R is None:
+        pytest.skip("oracle/_ref/libref_gp.so not built (reference tree absent)")
+    rs = np.random.RandomState(3)
+    nx, ny = 40, 30
+    pot = rs.uniform(0, 4000, (ny, nx)).astype(np.float32)
+    pot[rs.rand(ny, nx) < 0.3] = 1e10
+    cells = (rs.randint(1, ny - 1, 5000) * nx + rs.randint(1, nx - 1, 5000)).astype(np.int32)
+    cost = rs.randint(1, 255, 5000).astype(np.uint8)
+    prev = np.where(rs.rand(5000) < 0.5, -1.0, rs.uniform(0, 4000, 5000)).astype(np.float32)
+    for quadratic in (0, 1):
+        a, b = np.zeros(5000, np.float32), np.zeros(5000, np.float32)
+        R.ref_gp_calculate_potential(quadratic, pot.copy().reshape(-1), nx, ny, cost, cells, prev, 5000, a)
+        orc.lib().orc_gp_calculate_potential(quadratic, pot.reshape(-1), nx, ny, cost, cells, prev, 5000, b)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), quadratic
+
+
+def test_ref_grid_path_matches_oracle(orc):
+    """The reference's own GridPath::getPath over potentials the oracle's expanders produced (Dijkstra and A*)."""
+    R = orc.ref_gp()
+    if R is None:
+        pytest.skip("oracle/_ref/libref_gp.so not built (reference tree absent)")
+    rs = np.random.RandomState(8)
+    n, n_paths = 90, 0
+    for it in range(12):
+        cm, start, goal = _gp_case(rs, n)
+        _, pot, legal, _ = orc.global_planner_plan(cm, start, goal, goal.astype(np.int32), use_dijkstra=it % 2, use_grid_path=1)
+        if not legal:
+            continue
+        a, b = np.zeros((4 * n * n, 2), np.float32), np.zeros((4 * n * n, 2), np.float32)
+        na = R.ref_gp_grid_path(pot.copy().reshape(-1), n, n, start[0], start[1], goal[0], goal[1], a.reshape(-1), len(a))
+        nb = orc.lib().orc_gp_grid_path(pot.reshape(-1), n, n, start[0], start[1], goal[0], goal[1], b.reshape(-1), len(b))
+        assert na == nb and np.array_equal(a[:na].view(np.uint32), b[:nb].view(np.uint32))
+        n_paths += na > 0
+    assert n_paths >= 4
