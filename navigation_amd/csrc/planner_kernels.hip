@@ -1418,6 +1418,295 @@ __global__ __launch_bounds__(1024) void k_bfs_global(PlannerDev pl, uint32_t fir
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_bfs_big: the register-resident sweep of k_bfs_wave for maps beyond its reach, up to 1023 x 1024 cells (configs[4]'s
+// 1000 x 1000: 32 bitmap words per row).  Lanes: two strips per wave, 32 lanes each, lane = word of the row; 32 strips
+// of RPT = 24 or 32 rows.  No separator lane is needed between the two strips of a wave: either lanes W..31 are idle
+// (frontier 0, everything blocked) or, with W = 32, the top bit of a row's last word lies beyond nx (hence nx = 1024 is
+// left to k_bfs_global) and is blocked, so nothing crosses from lane 31 to lane 32 or back.  `blocked` and the frontier
+// take 2 x RPT registers; there is no room for level planes, so every search stores distances directly (the DIRECT
+// scheme of k_bfs_wave: the lane that owns a word writes a cell's distance the moment the wavefront reaches it; a bounded
+// search only inside the robot's region).  The seed bitmap lives in global scratch (one per workgroup), read with
+// agent-scope loads; LDS holds only the strips' edge rows.  One workgroup per CU takes items off a counter.
+// ------------------------------------------------------------------------------------------------
+template <int RPT>
+__device__ __forceinline__ void bfsBigGrid(const PlannerDev& pl, const uint32_t inst, const int which, uint32_t* seedw) {
+  constexpr uint32_t WS = 32;                  // lanes (= word slots) per strip
+  constexpr uint32_t kEdgeWords = (32 + 2) * 2 * WS;  // [strip + 1][first, last][word], a zero strip on either side
+  __shared__ uint32_t s_edge[2 * kEdgeWords];
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_flag[3];
+  __shared__ uint32_t s_open[3];
+  __shared__ uint32_t s_prog[18];
+  int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, care_ok = 0;  // the robot's region (box + 2 cells), see bfsWaveGrid
+  if (pl.bfs_bounded) {
+    const int4 bb = reinterpret_cast<const int4*>(pl.bfs_box)[2 * inst];
+    bx0 = __builtin_amdgcn_readfirstlane(bb.x);
+    bx1 = __builtin_amdgcn_readfirstlane(bb.y);
+    by0 = __builtin_amdgcn_readfirstlane(bb.z);
+    by1 = __builtin_amdgcn_readfirstlane(bb.w);
+    care_ok = __builtin_amdgcn_readfirstlane(pl.bfs_box[8 * inst + 4]);
+  }
+  const bool bounded = bx1 >= bx0 && by1 >= by0;
+  uint32_t tid_ = threadIdx.x, nx_ = pl.nx, ny_ = pl.ny;
+  asm volatile("" : "+v"(tid_), "+s"(nx_), "+s"(ny_));  // (as bfsWaveGrid: nothing of the set-up is kept across the items)
+  const uint32_t tid = tid_;
+  const Geom g = geomOf(pl, inst);
+  const uint32_t nx = nx_, ny = ny_, W = (nx + 31) >> 5;
+  const uint32_t lane = tid & 63u, wave_id = tid >> 6, wi = lane & 31u;
+  const uint32_t strip = wave_id * 2 + (lane >> 5);
+  const uint32_t r0 = strip * RPT;
+  const bool owner = wi < W && r0 < ny;
+  const uint8_t* master = pl.master + (size_t)inst * pl.cells_padded;
+  const uint32_t* freew = pl.bfs_free + (size_t)inst * ny * W;
+  uint32_t* dist = (which == 0 ? pl.path : (which == 1 ? pl.goal : pl.goal_front)) + (size_t)inst * pl.cells;
+  const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
+  const uint32_t last_mask = (nx & 31) ? ((1u << (nx & 31)) - 1u) : 0xFFFFFFFFu;
+  const uint32_t col_mask = (wi + 1 == W) ? last_mask : 0xFFFFFFFFu;
+
+  for (uint32_t i = tid; i < 2 * kEdgeWords; i += blockDim.x) s_edge[i] = 0;
+  for (uint32_t i = tid; i < ny * W; i += blockDim.x) seedw[i] = 0;
+  if (tid < 3) s_flag[tid] = s_open[tid] = 0;
+  __syncthreads();
+  // --- seeds from the plan (as k_bfs)
+  {
+    const uint32_t n = pl.plan_count[inst];
+    const double* P = pl.plan + (size_t)inst * pl.max_plan * 2;
+    const bool ovr = which == 2;
+    const double lx = pl.front_last[2 * inst], ly = pl.front_last[2 * inst + 1];
+    const uint32_t chunk = (n + blockDim.x - 1) / blockDim.x;
+    const uint32_t i0 = min(n, tid * chunk), i1 = min(n, i0 + chunk);
+    uint32_t mine = 0;
+    for (uint32_t i = i0; i < i1; ++i) mine += adjustedPoints(P, i, lx, ly, ovr, n, g.res, true, [](uint32_t, double, double) {});
+    uint32_t total;
+    const uint32_t base = blockExclusiveScan1024(mine, s_wave, &total);
+    auto valid = [&](double x, double y, uint32_t& cell) {
+      uint32_t mx, my;
+      if (!worldToMap(g, x, y, mx, my)) return false;
+      cell = my * nx + mx;
+      return master[cell] != kNoInfo;
+    };
+    uint32_t fmin_ = 0xFFFFFFFFu, b = base;
+    for (uint32_t i = i0; i < i1; ++i)
+      b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+        uint32_t cell;
+        if (valid(x, y, cell)) fmin_ = min(fmin_, b + k);
+      });
+    const uint32_t f = blockMin1024(fmin_, s_wave);
+    if (f != 0xFFFFFFFFu) {
+      uint32_t emin = total;
+      b = base;
+      for (uint32_t i = i0; i < i1; ++i)
+        b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+          uint32_t cell;
+          if (b + k > f && !valid(x, y, cell)) emin = min(emin, b + k);
+        });
+      const uint32_t e = blockMin1024(emin, s_wave);
+      b = base;
+      for (uint32_t i = i0; i < i1; ++i)
+        b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+          const uint32_t idx = b + k;
+          const bool seed = (which == 0) ? (idx >= f && idx < e) : (idx == e - 1);
+          if (!seed) return;
+          uint32_t cell;
+          if (!valid(x, y, cell)) return;
+          const uint32_t my = cell / nx, mx = cell - my * nx;
+          atomicOr(&seedw[my * W + (mx >> 5)], 1u << (mx & 31));
+        });
+    }
+  }
+  __syncthreads();
+  // the seed words were zeroed and set by other lanes of this workgroup (and read by an earlier item): read them past the L1
+  auto seedWord = [&](uint32_t i) { return __hip_atomic_load(seedw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+
+  uint32_t blocked[RPT], fr[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    blocked[k] = 0xFFFFFFFFu;
+    fr[k] = 0;
+    const uint32_t row = r0 + k;
+    if (owner && row < ny) {
+      fr[k] = seedWord(row * W + wi);  // seeds expand whatever their cost (map_grid.cpp:160-187)
+      blocked[k] = ~(freew[row * W + wi] & col_mask) | fr[k];
+    }
+  }
+  const uint32_t e_mine = (strip + 1) * 2 * WS + wi;
+  const uint32_t e_top = strip * 2 * WS + WS + wi;    // last row of the strip above
+  const uint32_t e_bot = (strip + 2) * 2 * WS + wi;   // first row of the strip below
+  uint32_t* ecur = s_edge;
+  uint32_t* enxt = s_edge + kEdgeWords;
+  ecur[e_mine] = fr[0];
+  ecur[e_mine + WS] = fr[RPT - 1];
+  if (tid < 18) s_prog[tid] = (tid == 0 || tid == 17) ? 0xFFFFFFFFu : 1u;
+  __syncthreads();
+
+  auto expandRow = [&](int k, uint32_t fc, uint32_t up, uint32_t down) -> uint32_t {
+    const uint32_t lwv = fromLaneBelow(fc), rwv = fromLaneAbove(fc);
+    const uint32_t x = __builtin_amdgcn_alignbit(fc, lwv, 31) | __builtin_amdgcn_alignbit(rwv, fc, 1) | up;
+    const uint32_t cand = (x | down) & ~blocked[k];
+    uint32_t nb;
+    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(nb) : "v"(blocked[k]), "v"(x), "v"(down));
+    blocked[k] = nb;
+    return cand;
+  };
+  typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
+  lds_vu32* vprog = (lds_vu32*)s_prog;
+  // rows / words whose distances are stored: the robot's region, or the whole grid
+  const int sy0 = bounded ? by0 : 0, sy1 = bounded ? by1 : (int)ny - 1;
+  const bool wave_in_box = bounded && (int)(wave_id * 2 * RPT) <= by1 && (int)((wave_id + 1) * 2 * RPT) > by0;
+  const bool store_wave = bounded ? wave_in_box : true;  // wave-uniform
+  const bool region_lane = owner && store_wave && (!bounded || ((int)wi >= (bx0 >> 5) && (int)wi <= (bx1 >> 5)));
+  // (row and word are made opaque at every use: otherwise 2 x RPT row pointers are computed once and kept live - or
+  // spilled - across the whole search)
+  auto storeCells = [&](int k, uint32_t cells, uint32_t value) {
+    if (cells == 0) return;
+    uint32_t row = r0 + k, word = wi;
+    asm volatile("" : "+v"(row), "+v"(word));
+    if ((int)row < sy0 || (int)row > sy1) return;
+    uint32_t* drow = dist + row * nx + word * 32;
+    while (cells) {
+      const uint32_t bpos = (uint32_t)__ffs(cells) - 1u;
+      cells &= cells - 1;
+      drow[bpos] = value;
+    }
+  };
+  uint32_t had = 0;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) had |= fr[k];
+  if (region_lane && had) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) storeCells(k, fr[k], 0u);  // the seeds: distance 0
+  }
+  uint32_t level = 0, group = 0, any_grp = 0;
+  while (true) {
+    // a level needs the edge rows of the two neighbouring waves only (see bfsWaveGrid)
+    for (uint32_t spins = 0; spins < (1u << 20); ++spins) {  // bounded: a wave is never left spinning
+      const uint32_t pa = vprog[wave_id], pb = vprog[wave_id + 2];
+      if (__builtin_amdgcn_readfirstlane(min(pa, pb)) >= level + 1) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+    const uint32_t top = ecur[e_top], bot = ecur[e_bot];
+    if (__builtin_amdgcn_ballot_w64((had | top | bot) != 0) != 0) {
+      asm volatile("" ::: "memory");
+      const uint32_t old_first = fr[0], old_second = fr[1], old_before_last = fr[RPT - 2];
+      uint32_t prev = old_first, held = 0;
+#pragma unroll
+      for (int k = 1; k < RPT - 1; ++k) {
+        const uint32_t fc = fr[k];
+        const uint32_t cand = expandRow(k, fc, prev, fr[k + 1]);
+        prev = fc;
+        if (k > 1) fr[k - 1] = held;
+        held = cand;
+      }
+      fr[RPT - 2] = held;
+      fr[0] = expandRow(0, old_first, top, old_second);
+      fr[RPT - 1] = expandRow(RPT - 1, fr[RPT - 1], old_before_last, bot);
+      had = 0;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) had |= fr[k];
+      any_grp |= had;
+      if (store_wave) {  // wave-uniform
+        if (region_lane && had) {
+#pragma unroll
+          for (int k = 0; k < RPT; ++k) storeCells(k, fr[k], level + 1);
+        }
+      }
+    }
+    enxt[e_mine] = fr[0];
+    enxt[e_mine + WS] = fr[RPT - 1];
+    asm volatile("" ::: "memory");
+    if (lane == 0) vprog[wave_id + 1] = level + 2;
+    const bool group_end = ((level + 1) & 7u) == 7u;  // termination is checked once per block of 8 levels
+    if (group_end) {
+      if (any_grp) s_flag[group % 3] = 1;
+      if (wave_in_box) {  // wave-uniform: is any cell of the robot's box that still counts open, or a frontier cell inside the region?
+        uint32_t wi_v = wi, r0_v = r0;
+        asm volatile("" : "+v"(wi_v), "+v"(r0_v));
+        const int c_lo = max(bx0 - (int)(wi_v * 32), 0), c_hi = min(bx1 - (int)(wi_v * 32), 31);
+        const uint32_t cw_i = wi_v - (uint32_t)(bx0 >> 5);
+        const uint32_t* care = pl.bfs_care + (size_t)inst * kCareRows * kCareWords + cw_i;
+        const bool has_care = care_ok != 0 && cw_i < (uint32_t)kCareWords;
+        uint32_t open = 0;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          const uint32_t rr = (uint32_t)((int)(r0_v + k) - by0);
+          if (rr <= (uint32_t)(by1 - by0)) open |= (~blocked[k] & (has_care ? care[rr * kCareWords] : (care_ok ? 0u : 0xFFFFFFFFu))) | fr[k];
+        }
+        if (owner && c_hi >= c_lo && (open & (0xFFFFFFFFu >> (31 - c_hi)) & (0xFFFFFFFFu << c_lo)) != 0) s_open[group % 3] = 1;
+      }
+      if (tid == 0) {
+        s_flag[(group + 1) % 3] = 0;
+        s_open[(group + 1) % 3] = 0;
+      }
+      __syncthreads();
+    }
+    uint32_t* t = ecur;
+    ecur = enxt;
+    enxt = t;
+    ++level;
+    if (group_end) {
+      const bool done = !s_flag[group % 3] || (bounded && !s_open[group % 3]);
+      ++group;
+      any_grp = 0;
+      if (done) break;
+    }
+  }
+  // --- expanded set (reached free cells + seeds) into blocked[]; its obstacle neighbours were touched -> obstacleCosts(),
+  // the rest of what is stored -> unreachableCellCosts()
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const uint32_t row = r0 + k;
+    const bool in = owner && row < ny;
+    blocked[k] = in ? ((blocked[k] & freew[row * W + wi] & col_mask) | seedWord(row * W + wi)) : 0u;
+  }
+  __syncthreads();  // every wave is past its last level: the edge buffers are free
+  enxt[e_mine] = blocked[0];
+  enxt[e_mine + WS] = blocked[RPT - 1];
+  __syncthreads();
+  {
+    uint32_t prev = enxt[e_top];
+    const uint32_t bot = enxt[e_bot];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {  // (the lane shifts need every lane of the wave: no divergence around them)
+      const uint32_t fc = blocked[k];
+      const uint32_t lwv = fromLaneBelow(fc), rwv = fromLaneAbove(fc);
+      const uint32_t d = k + 1 < RPT ? blocked[k + 1 < RPT ? k + 1 : 0] : bot;
+      const uint32_t nb = (fc << 1) | (lwv >> 31) | (fc >> 1) | (rwv << 31) | prev | d;
+      prev = fc;
+      const uint32_t row = r0 + k;
+      if (region_lane && row < ny) {
+        const uint32_t touched = nb & ~(freew[row * W + wi] & col_mask) & ~fc & col_mask;
+        storeCells(k, touched, N_obst);
+        storeCells(k, ~fc & ~touched & col_mask, N_unreach);
+      }
+    }
+  }
+  if (tid == 0) pl.bfs_levels[(size_t)inst * 3 + which] = level;  // next cycle's dispatch order
+}
+template <int RPT>
+__global__ __launch_bounds__(1024, 4) void k_bfs_big(PlannerDev pl, uint32_t first, uint32_t count, uint32_t* next_item, const uint32_t* order, uint32_t* scratch) {
+  __shared__ uint32_t s_item;
+  const uint32_t total = count * 3u;
+  uint32_t* seedw = scratch + (size_t)blockIdx.x * pl.ny * ((pl.nx + 31) >> 5);  // this workgroup's seed bitmap
+  for (;;) {
+    if (threadIdx.x == 0) s_item = atomicAdd(next_item, 1u);
+    __syncthreads();
+    const uint32_t slot = s_item;
+    if (slot >= total) break;  // every workgroup leaves as soon as the counter has passed the last item
+    const uint32_t item = order ? order[slot] : slot;
+    const uint32_t g = item / count;
+    bfsBigGrid<RPT>(pl, first + (item - g * count), 2 - (int)g, seedw);
+    __syncthreads();
+  }
+}
+// 24 or 32 rows per lane; 0 = the map is not k_bfs_big's
+static int bfs_big_rows(uint32_t nx, uint32_t ny) {
+  const uint32_t W = (nx + 31) / 32;
+  if (W > 32 || (W == 32 && (nx & 31) == 0) || ny > 32 * 32) return 0;
+  return ny <= 32 * 24 ? 24 : 32;
+}
+
 // rows per thread needed so that ceil(ny/RPT) * W strips fit one 1024-thread workgroup
 static int bfs_rows_per_thread(uint32_t nx, uint32_t ny) {
   const uint32_t W = (nx + 31) / 32;
@@ -1504,6 +1793,15 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
     return;
   }
   if (!free_ready) hipLaunchKernelGGL(k_free_bits, dim3((pl.ny * ((pl.nx + 31) / 32) + 255) / 256, count), dim3(256), 0, s, pl, first);
+  static const bool force_global_kernel = getenv("NAVGPU_DEBUG_BFS_GLOBAL") != nullptr;  // A/B timing only
+  const int big = pl.bfs_grids == 3 && !force_global_kernel ? bfs_big_rows(pl.nx, pl.ny) : 0;
+  if (big) {  // (the scratch holds 12 bitmaps per robot of the fleet; a workgroup uses one)
+    hipMemsetAsync(pl.bfs_next_item, 0, 2 * sizeof(uint32_t), s);
+    const dim3 wgs(std::min(count * 3u, bfs_cu_count()));
+    if (big == 24) hipLaunchKernelGGL(k_bfs_big<24>, wgs, dim3(1024), 0, s, pl, first, count, pl.bfs_next_item, order, pl.bfs_scratch);
+    else hipLaunchKernelGGL(k_bfs_big<32>, wgs, dim3(1024), 0, s, pl, first, count, pl.bfs_next_item, order, pl.bfs_scratch);
+    return;
+  }
   hipLaunchKernelGGL(k_bfs_global, grid, dim3(1024), 0, s, pl, first, pl.bfs_scratch);
 }
 

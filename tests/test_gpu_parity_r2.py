@@ -533,3 +533,93 @@ def test_layered_cycles_reference_priority_queue_order(nav, orc):
         for i in range(nI):
             assert np.array_equal(m[i], oracles[i].master()), (cyc, i)
     fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# k_bfs_big: the register-resident wavefront for maps beyond k_bfs_wave's reach (up to 1023 x 1024; configs[4]'s
+# 1000 x 1000).  Sizes pick its corner cases: 32 words per row with a ragged last word (no separator lane between the
+# two strips of a wave), 31 words (an idle lane separates them), 24 and 32 rows per lane, a partial last strip.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nx,ny", [(1000, 1000), (1023, 1024), (992, 800), (700, 650), (993, 641)])
+def test_big_map_wavefronts_match_oracle(nav, orc, nx, ny):
+    from navigation_amd import synth
+    from test_gpu_parity import _mapgrid_case
+    res = synth.RES
+    rs = np.random.RandomState(nx + ny)
+    m = np.zeros((ny, nx), np.uint8)
+    for _ in range(nx * ny // 2500):
+        cx, cy, r = rs.randint(0, nx), rs.randint(0, ny), rs.randint(1, 6)
+        m[max(0, cy - r):cy + r + 1, max(0, cx - r):cx + r + 1] = LETHAL
+    # walls with gaps, also across the seams between the 32-cell words and at the last column / row
+    for x in (31, 32, 511, 512, nx - 1):
+        m[5:ny - 5, x] = LETHAL
+        m[rs.randint(5, ny - 5, 6), x] = 0
+    m[ny - 1, 3:nx // 2] = LETHAL
+    m[rs.random_sample(m.shape) < 0.005] = NOINFO
+    sx, sy = nx * res, ny * res
+    plan = np.stack([np.linspace(0.1 * sx, 0.9 * sx, 60), np.linspace(0.2 * sy, 0.85 * sy, 60)], 1)
+    for px, py in plan:
+        m[int(py / res), int(px / res)] = 0
+    levels = _mapgrid_case(nav, orc, m, plan, [0.3 * sx, 0.4 * sy, 0.3])
+    assert levels > 300
+
+
+def test_big_map_long_search(nav, orc):
+    """A serpentine over a 1000 x 600 map: > 60 000 levels through every strip and both halves of every wave."""
+    from test_gpu_parity import _mapgrid_case
+    nx, ny = 1000, 600
+    m = np.zeros((ny, nx), np.uint8)
+    for k, row in enumerate(range(8, ny - 2, 8)):
+        m[row, :] = LETHAL
+        if k % 2:
+            m[row, 1:3] = 0
+        else:
+            m[row, nx - 3:nx - 1] = 0
+    plan = np.stack([np.linspace(0.1, 0.6, 12), np.full(12, 0.12)], 1)
+    levels = _mapgrid_case(nav, orc, m, plan, [0.3, 0.12, 0.0])
+    assert levels > 60000, levels
+
+
+def test_big_map_bounded_equals_complete(nav, orc):
+    """1000 x 1000, three robots: bounded searches (stores inside the robot's region only) give every sample the cost
+    and status the whole-grid searches give, the completed grids are equal, robot 0 equals the oracle."""
+    from navigation_amd import synth
+    from test_gpu_parity import _inflated_instance
+    N = L(nav)
+    n, n_inst = 1000, 3
+    cfg = nav.DwaConfig(vx_samples=8, vy_samples=5, vth_samples=9, sim_time=1.7, sim_granularity=0.085, discretize_by_time=1)
+    insts = [_inflated_instance(orc, n, 60 + i, synth) for i in range(n_inst)]
+    masters = np.stack([i["master"] for i in insts])
+    pos = np.stack([i["pos"] for i in insts])
+    vel = np.stack([i["vel"] for i in insts])
+    plans = np.stack([i["plan"] for i in insts])
+    out = {}
+    for bounded in (1, 0):
+        fl = nav.Fleet(n_inst, n, n, synth.RES, layers=N.LAYER_OBSTACLE, keep_sample_costs=True, max_sim_steps=32, max_plan=256)
+        fl.configure_planner(cfg)
+        fl.set_footprint(synth.FOOTPRINT5)
+        fl.set_bounded_map_grids(bounded)
+        fl.upload(N.GRID_MASTER, masters)
+        fl.set_plan()
+        for _ in range(2):  # the second cycle runs in last cycle's longest-first order, on reused seed scratch
+            res = fl.find_best_path(pos, vel, plans)
+        lv = fl.wavefront_levels()
+        samples = [fl.samples(k) for k in range(n_inst)]
+        grids = [fl.download(g) for g in (N.GRID_PATH, N.GRID_GOAL, N.GRID_GOAL_FRONT)]
+        out[bounded] = (res, lv, samples, grids)
+        fl.close()
+    (rb, lb, sb, gb), (rc, lc, sc, gc) = out[1], out[0]
+    assert (lb < lc).sum() >= 2 * n_inst, (lb, lc)
+    for k in range(n_inst):
+        assert (rb[k].best_index, rb[k].n_valid, rb[k].n_scored, rb[k].cost) == (rc[k].best_index, rc[k].n_valid, rc[k].n_scored, rc[k].cost)
+        assert np.array_equal(sb[k][0], sc[k][0]) and np.array_equal(sb[k][1], sc[k][1])
+    for a, b in zip(gb, gc):
+        assert np.array_equal(a, b)
+    p = orc.DwaPlanner(masters[0], synth.RES, 0.0, 0.0, orc.DwaConfig(**cfg.as_dict()))
+    p.set_plan()
+    o, _, _, cfull, ost = p.cycle(pos[0], vel[0], plans[0], synth.FOOTPRINT5)
+    scored = ost == 1
+    assert np.array_equal(sb[0][1], ost)
+    assert np.allclose(sb[0][0][scored], cfull[scored], rtol=0, atol=1e-5)
+    for which in range(3):
+        assert np.array_equal(gb[which][0].astype(np.float64).reshape(-1), p.grid(which).reshape(-1))
