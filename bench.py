@@ -145,6 +145,47 @@ def legacy_leg(nav, insts, n_cells, masters, with_cpu, device):
     return out
 
 
+def configs4_leg(nav, device, n_robots=64, n_cells=1000, steps=10):
+    """BASELINE configs[4] on one GPU: 1000 x 1000 costmaps, voxel_grid obstacle layer (10 z-voxels) + inflation, the
+    5-vertex polygon footprint, 64 x 64 x 32 samples, 20 steps; scans and plans resident.  A supplementary figure (the
+    headline is configs[2]); 64 robots keep the leg to a few seconds, the rate per robot does not depend on the count."""
+    from navigation_amd import _lib as N, synth
+    fl = nav.Fleet(n_robots, n_cells, n_cells, synth.RES, layers=N.LAYER_VOXEL | N.LAYER_INFLATION, track_unknown=False, max_points=1440,
+                   max_observations=1, max_sim_steps=24, max_plan=256, max_footprint=8, device=device)
+    fl.configure_obstacle(z_voxels=10, origin_z=0.0, z_resolution=0.2, unknown_threshold=15, mark_threshold=0, max_obstacle_height=2.0)
+    fl.set_footprint(synth.FOOTPRINT5)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, synth.inscribed_radius(synth.FOOTPRINT5))
+    fl.configure_planner(nav.DwaConfig(vx_samples=64, vy_samples=64, vth_samples=32, sim_time=2.0, sim_granularity=0.1, discretize_by_time=1))
+    insts = [synth.make_instance(n_cells, 700 + i) for i in range(n_robots)]
+    fl.upload(N.GRID_MASTER, np.stack([i["cells"] for i in insts]))
+    poses = np.array([[float(v) for v in i["pos"]] for i in insts])
+    obs = [dict(instance=k, points=synth.laser_scan(i, 0, z=0.3, z_jitter=1.5), origin=(poses[k][0], poses[k][1], 0.3), obstacle_range=2.5,
+                raytrace_range=3.0) for k, i in enumerate(insts)]
+    fl.stage_observations(poses, obs)
+    fl.stage_planner(np.stack([i["pos"] for i in insts]), np.stack([i["vel"] for i in insts]), np.stack([i["plan"] for i in insts]))
+    fl.set_plan()
+    for _ in range(2):
+        step(fl)
+    fl.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(fl)
+    fl.sync()
+    dt = (time.perf_counter() - t0) / steps
+    fl.profile(True)
+    fl.profile_reset()
+    for _ in range(3):
+        step(fl)
+    fl.sync()
+    pr = fl.profile_read()
+    fl.profile(False)
+    scored = sum(r.n_scored for r in fl.results())
+    fl.close()
+    return {"workload": f"{n_robots} robots, {n_cells}x{n_cells}, voxel layer (10 z-voxels) + inflation, 5-vertex footprint, 64x64x32 samples, 20 steps",
+            "ms_per_step": dt * 1e3, "trajectories_per_s": scored / dt, "per_instance_trajectories_per_s": scored / dt / n_robots,
+            "kernel_ms": {k: round(v[0] / v[1], 4) for k, v in pr.items() if v[1]}}
+
+
 def step(fl, poses=None, k=0):
     """One pass of the hot path over the fleet.  With `poses` (a PoseSchedule) the cycle first stages its own pose and
     velocity (24 B per robot, navgpu_planner_stage_poses) - everything else (costmaps, scans, plans) is resident in HBM."""
@@ -558,6 +599,7 @@ def main():
             f1.close()
         if not args.no_single:
             out["legacy_trajectory_planner"] = legacy_leg(nav, insts, n_cells, masters, not args.no_cpu_baseline, local_rank)
+            out["configs4_one_gpu_share"] = configs4_leg(nav, local_rank)
         if not args.no_cpu_baseline:
             ns = min(n_inst, 32)
             out["cpu_baseline"] = cpu_baseline(insts[:ns], cfg, n_cells, masters[:ns])

@@ -126,6 +126,7 @@ struct PlannerDev {
   uint32_t fp_rcells;         // Chebyshev radius (cells) that contains every footprint cell around the centre cell
   uint32_t fp_chunk;          // cells of the longest footprint edge (+1): picks the k_score<CHUNK> instantiation
   uint32_t use_tables, tab_steps, tab_nfp, tab_nth;
+  uint32_t tab_rows;          // v_theta rows per row group = rows of the tables a k_score_tab workgroup keeps in LDS
   uint32_t tab_bytes;         // score_table_bytes(): the tables' share of the LDS image (0 without tables)
   double tab_dt;              // sim_time / tab_steps
   uint8_t* prep;              // [n][prep_stride] LDS image of k_score (window, reach bitmaps, heading tables), built per cycle by k_score_prep*
@@ -207,6 +208,7 @@ size_t score_window_bytes(uint32_t win);
 size_t score_prep_bytes(const PlannerDev& pl);
 bool bfs_lds_resident(uint32_t nx, uint32_t ny);
 size_t bfs_scratch_words(uint32_t nx, uint32_t ny);
+uint32_t score_table_rows(const PlannerDev& pl, uint32_t win);
 
 // ---- device helpers ---------------------------------------------------------------------------
 struct Geom {

@@ -567,8 +567,8 @@ static void updateWindow(navgpu_fleet* f) {
     f->pl.tab_dt = c.sim_time / (int)f->pl.tab_steps;
     f->pl.tab_nfp = max_nfp;
     f->pl.tab_nth = (uint32_t)std::max(c.vth_samples, 2) + 1;
-    const size_t lds = score_window_bytes(win) + score_table_bytes(f->pl);
-    if (f->pl.tab_steps >= 1 && f->pl.tab_steps <= f->pl.max_sim_steps && lds <= 60 * 1024) f->pl.use_tables = 1;
+    f->pl.tab_rows = f->pl.tab_steps >= 1 && f->pl.tab_steps <= f->pl.max_sim_steps ? score_table_rows(f->pl, win) : 0;
+    if (f->pl.tab_rows >= 1) f->pl.use_tables = 1;
   }
 }
 
@@ -896,7 +896,9 @@ int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
   const uint32_t ax = (uint32_t)(std::max(cfg.vx_samples, 2) + 1), ay = (uint32_t)(std::max(cfg.vy_samples, 2) + 1),
                  at = (uint32_t)(std::max(cfg.vth_samples, 2) + 1);
   const uint32_t max_samples = ax * ay * at;
-  const uint32_t score_blocks = (max_samples + kScoreThreads - 1) / kScoreThreads;
+  // capacity of the per-workgroup partial results: the 256-thread launch, and the table launch's row groups (each
+  // rounds its share up to whole workgroups: at most one more per v_theta value, planner_kernels.hip launch_score)
+  const uint32_t score_blocks = (max_samples + kScoreThreads - 1) / kScoreThreads + at + 2;
   if (max_axis != pl.max_axis || max_samples != pl.max_samples) {
     HIP_TRY(waitStream(f->stream));
     f->release(pl.axis_samples);

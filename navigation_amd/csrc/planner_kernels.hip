@@ -2011,9 +2011,24 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   const int K = TABLES ? (int)pl.tab_steps : 0;
   const int tnfp = TABLES ? (int)pl.tab_nfp : 0;
   const int nth_s = TABLES ? cnt[2] : 0;
-  double* s_trig = reinterpret_cast<double*>(s_dyn + win_bytes + score_bits_bytes(win));  // [nth][K][4] cs, sn, cs2, sn2
-  double* s_rot = s_trig + (size_t)pl.tab_nth * K * 4;                            // [nth][K][tnfp][2]
-  float* s_th = reinterpret_cast<float*>(s_rot + (size_t)pl.tab_nth * K * tnfp * 2);  // [nth][K]
+  // rows of the tables in LDS: all tab_nth where they are built (PREP 1); the scoring launch (PREP 2) keeps only the
+  // tab_rows v_theta rows of its workgroup's row group (see the lane mapping below)
+  const int lrows = TABLES ? (PREP == 2 ? (int)pl.tab_rows : (int)pl.tab_nth) : 0;
+  double* s_trig = reinterpret_cast<double*>(s_dyn + win_bytes + score_bits_bytes(win));  // [rows][K][4] cs, sn, cs2, sn2
+  double* s_rot = s_trig + (size_t)lrows * K * 4;                                 // [rows][K][tnfp][2]
+  float* s_th = reinterpret_cast<float*>(s_rot + (size_t)lrows * K * tnfp * 2);       // [rows][K]
+  // TABLES lane mapping.  Lanes are v_theta-major so that a wave shares one heading sequence.  The v_theta rows are cut
+  // into groups of tab_rows (what the LDS budget holds: all of them for configs[2]'s 17, 17 of configs[4]'s 33); a
+  // group takes bpg consecutive workgroups, which enumerate its rows x (vx, vy) pairs.  Blocks past the last group idle.
+  int t_row_base = 0, t_rows = 0, t_li0 = 0;
+  if (TABLES && PREP == 2) {
+    const int nxy = max(cnt[0] * cnt[1], 1), R = (int)pl.tab_rows;
+    const int bpg = (nxy * R + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int gi = (int)blockIdx.x / bpg;
+    t_row_base = gi * R;
+    t_rows = min(max(cnt[2] - t_row_base, 0), R);
+    t_li0 = ((int)blockIdx.x - gi * bpg) * (int)blockDim.x;
+  }
   if (TABLES && PREP != 2) {
     __syncthreads();  // s_axis, s_fp staged
     const double dt_t = c.sim_time / K;
@@ -2056,18 +2071,22 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     } else {
       // window + screens, and of the tables only the v_theta rows this workgroup's samples use (lanes are
       // v_theta-major: 512 lanes of a 33 x 33 (vx, vy) grid span two of the 17 rows), at their usual place
-      const int nxy = max(cnt[0] * cnt[1], 1), nth_all = max(cnt[2], 1);
-      const int r0 = min((int)(blockIdx.x * blockDim.x) / nxy, nth_all - 1);
-      const int r1 = min((int)(blockIdx.x * blockDim.x + blockDim.x - 1) / nxy, nth_all - 1);
+      // r0..r1: rows of the group (relative to its first) that this workgroup's lanes use
+      const int nxy = max(cnt[0] * cnt[1], 1), last = max(t_rows, 1) - 1;
+      const int r0 = min(t_li0 / nxy, last);
+      const int r1 = min((t_li0 + (int)blockDim.x - 1) / nxy, last);
       const int n16w = (int)((win_bytes + score_bits_bytes(win)) >> 4);
-      const int o_trig = n16w + r0 * K * 2, n_trig = (r1 - r0 + 1) * K * 2;                             // 32 B per entry
-      const int o_rot = n16w + (int)pl.tab_nth * K * 2 + r0 * K * tnfp, n_rot = (r1 - r0 + 1) * K * tnfp;  // 16 B per vertex
+      const int ncopy = t_rows > 0 ? r1 - r0 + 1 : 0;                // (a workgroup past the last row group has no rows)
+      const int n_trig = ncopy * K * 2, n_rot = ncopy * K * tnfp;  // 32 B per entry, 16 B per vertex
+      const int l_trig = n16w + r0 * K * 2, g_trig = n16w + (t_row_base + r0) * K * 2;
+      const int l_rot = n16w + lrows * K * 2 + r0 * K * tnfp, g_rot = n16w + (int)pl.tab_nth * K * 2 + (t_row_base + r0) * K * tnfp;
       for (int i = tid; i < n16w + n_trig + n_rot; i += blockDim.x) {
-        const int j = i < n16w ? i : i < n16w + n_trig ? o_trig + (i - n16w) : o_rot + (i - n16w - n_trig);
-        lds[j] = img[j];
+        if (i < n16w) lds[i] = img[i];
+        else if (i < n16w + n_trig) lds[l_trig + (i - n16w)] = img[g_trig + (i - n16w)];
+        else lds[l_rot + (i - n16w - n_trig)] = img[g_rot + (i - n16w - n_trig)];
       }
-      const float* g_th = reinterpret_cast<const float*>(img + n16w + (size_t)pl.tab_nth * K * (2 + tnfp));
-      for (int i = r0 * K + (int)tid; i < (r1 + 1) * K; i += blockDim.x) s_th[i] = g_th[i];
+      const float* g_th = reinterpret_cast<const float*>(img + n16w + (size_t)pl.tab_nth * K * (2 + tnfp)) + t_row_base * K;
+      for (int i = r0 * K + (int)tid; i < (r0 + ncopy) * K; i += blockDim.x) s_th[i] = g_th[i];
     }
     __syncthreads();
   }
@@ -2114,11 +2133,14 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   // index (x-outer, y, theta-inner, as the reference enumerates) is what results are keyed by.
   const int lin = blockIdx.x * blockDim.x + tid;
   bool in_range = lin < n_samples;
-  int sidx = lin, t_ith = 0, t_r = 0;
-  if (TABLES && in_range) {
-    const int nxy = cnt[0] * cnt[1];
-    t_ith = lin / nxy;
-    t_r = lin - t_ith * nxy;  // index of the (vx, vy) pair, x-outer
+  int sidx = lin, t_ith = 0, t_r = 0, t_row = 0;
+  if (TABLES) {
+    const int nxy = max(cnt[0] * cnt[1], 1);
+    const int li = t_li0 + (int)tid;
+    t_row = li / nxy;            // row within the group = row of the tables in LDS
+    t_r = li - t_row * nxy;      // index of the (vx, vy) pair, x-outer
+    t_ith = t_row_base + t_row;
+    in_range = n_samples > 0 && t_row < t_rows;
     sidx = t_r * cnt[2] + t_ith;
   }
   double total = -1.0;
@@ -2234,7 +2256,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       } else {
         for (int step = 0; step < num_steps; ++step) {
           if (first_fail <= min_order) break;
-          const int te = TABLES ? t_ith * K + step : 0;
+          const int te = TABLES ? t_row * K + step : 0;
           if (TABLES) pth = s_th[te];
           const double x = px, y = py, th = pth;
           double sn, cs;
@@ -2609,8 +2631,25 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_explicit(PlannerDev pl,
 size_t score_window_bytes(uint32_t win) {  // costmap window + the four per-cell screens
   return (((size_t)win * win + 15) & ~(size_t)15) + score_bits_bytes((int)win);
 }
-size_t score_table_bytes(const PlannerDev& pl) {
-  return ((size_t)pl.tab_nth * pl.tab_steps * ((4 + 2 * pl.tab_nfp) * sizeof(double) + sizeof(float)) + 15) & ~(size_t)15;
+size_t score_table_row_bytes(const PlannerDev& pl) { return (size_t)pl.tab_steps * ((4 + 2 * pl.tab_nfp) * sizeof(double) + sizeof(float)); }
+size_t score_table_bytes(const PlannerDev& pl) {  // all v_theta rows: the image k_score_prep_tab builds
+  return ((size_t)pl.tab_nth * score_table_row_bytes(pl) + 15) & ~(size_t)15;
+}
+size_t score_table_lds_bytes(const PlannerDev& pl) {  // the tab_rows rows of one row group: what a k_score_tab workgroup holds
+  return ((size_t)pl.tab_rows * score_table_row_bytes(pl) + 15) & ~(size_t)15;
+}
+// v_theta rows per row group and the LDS budget they were sized for; 0 = no tables.  A workgroup's image (window +
+// screens + rows) should leave room for three workgroups per CU (52 KB each), else two (78 KB); the image of ALL
+// rows has to fit the one workgroup that builds it.
+uint32_t score_table_rows(const PlannerDev& pl, uint32_t win) {
+  const size_t wb = score_window_bytes(win), row = score_table_row_bytes(pl);
+  if (row == 0 || wb + score_table_bytes(pl) + score_scratch_bytes((int)win) > 150u * 1024u) return 0;
+  for (size_t budget : {(size_t)52 * 1024, (size_t)78 * 1024}) {
+    if (wb + 16 >= budget) continue;
+    const size_t r = (budget - wb - 16) / row;
+    if (r >= 1) return (uint32_t)std::min<size_t>(r, pl.tab_nth);
+  }
+  return 0;
 }
 size_t score_prep_bytes(const PlannerDev& pl) {  // the LDS image k_score_prep* stores per robot
   return score_window_bytes(pl.win) + (pl.use_tables ? score_table_bytes(pl) : 0);
@@ -2631,11 +2670,16 @@ uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, c
   }
   pl.prep_bytes = (uint32_t)score_prep_bytes(pl);  // (after the debug override of use_tables)
   if (pl.use_tables) {
+    // the prep launch builds all rows (its LDS holds the whole image); a scoring workgroup holds one row group
     pl.tab_bytes = (uint32_t)score_table_bytes(pl);
-    const size_t lds = win_bytes + score_table_bytes(pl);
-    const uint32_t blocks = (pl.max_samples + kScoreThreadsTab - 1) / kScoreThreadsTab;
-    if (lds + scratch > 48 * 1024) hipFuncSetAttribute((const void*)k_score_prep_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + scratch));
-    hipLaunchKernelGGL(k_score_prep_tab, dim3(1, count), dim3(kScoreThreadsTab), lds + scratch, s, pl, first);
+    const size_t lds_prep = win_bytes + score_table_bytes(pl) + scratch;
+    if (lds_prep > 48 * 1024) hipFuncSetAttribute((const void*)k_score_prep_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
+    hipLaunchKernelGGL(k_score_prep_tab, dim3(1, count), dim3(kScoreThreadsTab), lds_prep, s, pl, first);
+    pl.tab_bytes = (uint32_t)score_table_lds_bytes(pl);
+    const size_t lds = win_bytes + score_table_lds_bytes(pl);
+    // row groups x workgroups per group, for the largest (vx, vy) grid the configuration can produce
+    const uint32_t max_nxy = pl.max_samples / std::max(pl.tab_nth, 1u), groups = (pl.tab_nth + pl.tab_rows - 1) / pl.tab_rows;
+    const uint32_t blocks = std::min(groups * ((max_nxy * pl.tab_rows + kScoreThreadsTab - 1) / kScoreThreadsTab), pl.score_blocks);
 #define NAVGPU_SCORE_TAB(C)                                                                                              \
   {                                                                                                                      \
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_score_tab<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -2648,19 +2692,20 @@ uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, c
 #undef NAVGPU_SCORE_TAB
     return blocks;
   }
+  const uint32_t gen_blocks = (pl.max_samples + kScoreThreads - 1) / kScoreThreads;  // (score_blocks is the capacity of the partial results)
   if (win_bytes + scratch > 48 * 1024) hipFuncSetAttribute((const void*)k_score_prep_gen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(win_bytes + scratch));
   hipLaunchKernelGGL(k_score_prep_gen, dim3(1, count), dim3(kScoreThreads), win_bytes + scratch, s, pl, first);
 #define NAVGPU_SCORE_GEN(C)                                                                                                    \
   {                                                                                                                            \
     if (win_bytes > 48 * 1024) hipFuncSetAttribute((const void*)k_score_gen<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes); \
-    hipLaunchKernelGGL(k_score_gen<C>, dim3(pl.score_blocks, count), dim3(kScoreThreads), win_bytes, s, pl, first, explicit_sample);          \
+    hipLaunchKernelGGL(k_score_gen<C>, dim3(gen_blocks, count), dim3(kScoreThreads), win_bytes, s, pl, first, explicit_sample);          \
   }
   if (pl.fp_chunk <= 6) NAVGPU_SCORE_GEN(6)
   else if (pl.fp_chunk <= 9) NAVGPU_SCORE_GEN(9)
   else if (pl.fp_chunk <= 12) NAVGPU_SCORE_GEN(12)
   else NAVGPU_SCORE_GEN(16)
 #undef NAVGPU_SCORE_GEN
-  return pl.score_blocks;
+  return gen_blocks;
 }
 
 // ------------------------------------------------------------------------------------------------

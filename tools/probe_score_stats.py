@@ -7,9 +7,27 @@ import bench
 import navigation_amd as nav
 L = nav.lib()
 fn = C.CDLL(nav.lib_path()).navgpu_debug_score_stats
-fl, insts, cfg = bench.build_fleet(nav, 256, 400, 0)
-_, _, pos_h, vel_h, plans_h = fl._bench_host_inputs
-poses = bench.PoseSchedule(pos_h, vel_h, 64, 1)
+if len(sys.argv) > 1 and sys.argv[1] == "c5":  # configs[4]: 1000 x 1000, 5-vertex footprint, 64 x 64 x 32 samples
+    from navigation_amd import _lib as N, synth
+    R, n = 32, 1000
+    fl = nav.Fleet(R, n, n, synth.RES, layers=N.LAYER_OBSTACLE | N.LAYER_INFLATION, max_points=1440, max_observations=1, max_sim_steps=24,
+                   max_plan=256, max_footprint=8)
+    fl.configure_obstacle()
+    fl.set_footprint(synth.FOOTPRINT5)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, synth.inscribed_radius(synth.FOOTPRINT5))
+    fl.configure_planner(nav.DwaConfig(vx_samples=64, vy_samples=64, vth_samples=32, sim_time=2.0, sim_granularity=0.1, discretize_by_time=1))
+    insts = [synth.make_instance(n, 700 + i) for i in range(R)]
+    fl.upload(N.GRID_MASTER, np.stack([i["cells"] for i in insts]))
+    p5 = np.array([[float(v) for v in i["pos"]] for i in insts])
+    fl.stage_observations(p5, [dict(instance=k, points=synth.laser_scan(i, 0), origin=(p5[k][0], p5[k][1], 0.3), obstacle_range=2.5,
+                                    raytrace_range=3.0) for k, i in enumerate(insts)])
+    fl.stage_planner(np.stack([i["pos"] for i in insts]), np.stack([i["vel"] for i in insts]), np.stack([i["plan"] for i in insts]))
+    fl.set_plan()
+    poses = None
+else:
+    fl, insts, cfg = bench.build_fleet(nav, 256, 400, 0)
+    _, _, pos_h, vel_h, plans_h = fl._bench_host_inputs
+    poses = bench.PoseSchedule(pos_h, vel_h, 64, 1)
 for k in range(3):
     bench.step(fl, poses, k)
 fl.sync()
