@@ -229,6 +229,17 @@ int navgpu_static_set_map(navgpu_fleet* fleet, uint32_t first, uint32_t count, c
                           int32_t track_unknown_space, int32_t use_maximum, int32_t trinary_costmap,
                           int32_t lethal_cost_threshold, int32_t unknown_cost_value);
 
+/* replaces: StaticLayer under a rolling window (plugins/static_layer.cpp:187-193 incomingMap resizes the layer only;
+ * :262-283 updateBounds adds the layer's extent every cycle; :300-333 updateCosts maps every master cell of the update
+ * window to world, through the map_frame <- global_frame transform, into the static map).  One static map (its own
+ * size, resolution and origin) is shared by all robots of a rolling_window fleet created with NAVGPU_LAYER_STATIC. */
+int navgpu_static_set_rolling_map(navgpu_fleet* fleet, const int8_t* occupancy, uint32_t size_x, uint32_t size_y, double resolution,
+                                  double origin_x, double origin_y, int32_t track_unknown_space, int32_t use_maximum,
+                                  int32_t trinary_costmap, int32_t lethal_cost_threshold, int32_t unknown_cost_value);
+/* replaces: tf_->lookupTransform(map_frame_, global_frame_, ...) (static_layer.cpp:311): per robot 12 doubles, the
+ * tf::Transform's 3x3 basis row-major followed by its origin.  Identity until set. */
+int navgpu_static_set_transform(navgpu_fleet* fleet, uint32_t first, uint32_t count, const double* basis_origin);
+
 /* replaces: ObstacleLayer::reconfigureCB / VoxelLayer::reconfigureCB */
 int navgpu_obstacle_configure(navgpu_fleet* fleet, const navgpu_obstacle_params* params);
 /* replaces: InflationLayer::setInflationParameters + onFootprintChanged + computeCaches

@@ -303,6 +303,17 @@ __global__ __launch_bounds__(256) void k_obstacle(CostmapDev cm, uint32_t first,
       b.max_y = (b.max_y < wy) ? wy : b.max_y;
       st->static_has_updated_data = 0;
     }
+    if (!only_bounds && cm.stat_roll) {
+      // rolling window: StaticLayer::updateBounds has no early return (static_layer.cpp:265-268) and adds the extent
+      // of the LAYER's grid - the static map's own geometry - every cycle
+      double wx = cm.stat_ox + (0 + 0.5) * cm.stat_res, wy = cm.stat_oy + (0 + 0.5) * cm.stat_res;
+      b.min_x = (wx < b.min_x) ? wx : b.min_x;
+      b.min_y = (wy < b.min_y) ? wy : b.min_y;
+      wx = cm.stat_ox + (cm.stat_nx + 0.5) * cm.stat_res;
+      wy = cm.stat_oy + (cm.stat_ny + 0.5) * cm.stat_res;
+      b.max_x = (b.max_x < wx) ? wx : b.max_x;
+      b.max_y = (b.max_y < wy) ? wy : b.max_y;
+    }
   }
 
   const bool has_obs_layer = (cm.layers & (NAVGPU_LAYER_OBSTACLE | NAVGPU_LAYER_VOXEL)) && cm.obs_enabled;
@@ -673,7 +684,17 @@ __global__ __launch_bounds__(256) void k_merge(CostmapDev cm, uint32_t first, co
   }
   const size_t off = (size_t)inst * cm.cells_padded + base;
   uint4 mv = *reinterpret_cast<const uint4*>(cm.master + off);
-  const bool has_static = (cm.layers & NAVGPU_LAYER_STATIC) && static_received && !layer_only;
+  const bool has_static = (cm.layers & NAVGPU_LAYER_STATIC) && static_received && !layer_only && !cm.stat_roll && cm.stat;
+  const bool roll_static = cm.stat_roll != nullptr && !layer_only;
+  double tfm[8] = {1, 0, 0, 0, 0, 1, 0, 0};  // rows x and y of the transform: basis[0..2], origin.x, basis[3..5], origin.y
+  double m_ox = 0, m_oy = 0;
+  if (roll_static) {
+    const double* T = cm.stat_tf + (size_t)inst * 12;
+    tfm[0] = T[0]; tfm[1] = T[1]; tfm[2] = T[2]; tfm[3] = T[9];
+    tfm[4] = T[3]; tfm[5] = T[4]; tfm[6] = T[5]; tfm[7] = T[10];
+    m_ox = cm.origin[2 * inst];
+    m_oy = cm.origin[2 * inst + 1];
+  }
   const bool has_obst = (cm.layers & (NAVGPU_LAYER_OBSTACLE | NAVGPU_LAYER_VOXEL)) && cm.obs_enabled;
   uint4 sv = has_static ? *reinterpret_cast<const uint4*>(cm.stat + off) : make_uint4(0, 0, 0, 0);
   uint4 lv = has_obst ? *reinterpret_cast<const uint4*>(cm.obst + off) : make_uint4(0, 0, 0, 0);
@@ -692,6 +713,20 @@ __global__ __launch_bounds__(256) void k_merge(CostmapDev cm, uint32_t first, co
           m = sc;
         else if (sc != kNoInfo && (m == kNoInfo || m < sc))
           m = sc;
+      }
+      if (roll_static) {
+        // static_layer.cpp:318-330: mapToWorld(i, j) of the master, tf::Transform::operator() (basis row . point + origin,
+        // z = 0), the static map's own worldToMap; plain max with use_maximum, plain copy without
+        const double wx = m_ox + (x + 0.5) * cm.res, wy = m_oy + (y + 0.5) * cm.res;
+        const double px = tfm[0] * wx + tfm[1] * wy + tfm[2] * 0.0 + tfm[3];
+        const double py = tfm[4] * wx + tfm[5] * wy + tfm[6] * 0.0 + tfm[7];
+        if (!(px < cm.stat_ox || py < cm.stat_oy)) {
+          const uint32_t smx = (uint32_t)(int)((px - cm.stat_ox) / cm.stat_res), smy = (uint32_t)(int)((py - cm.stat_oy) / cm.stat_res);
+          if (smx < cm.stat_nx && smy < cm.stat_ny) {
+            const uint8_t sc = cm.stat_roll[(size_t)smy * cm.stat_nx + smx];
+            m = cm.static_use_maximum ? (sc > m ? sc : m) : sc;
+          }
+        }
       }
       if (has_obst) {
         uint8_t lc = (lw[k >> 2] >> sh) & 0xFF;

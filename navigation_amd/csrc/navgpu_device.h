@@ -72,6 +72,11 @@ struct CostmapDev {
   uint8_t* pq_seen;    // [n][cells] seen_
   PqCell* pq_heap;     // [n][pq_cap] the binary heap std::priority_queue<CellData> keeps
   uint64_t pq_cap;
+  // StaticLayer of a rolling-window costmap: one static map with its own geometry, a transform per robot
+  uint8_t* stat_roll;   // [stat_ny][stat_nx] interpreted costs (nullptr: not a rolling static layer / no map yet)
+  uint32_t stat_nx, stat_ny;
+  double stat_res, stat_ox, stat_oy;
+  double* stat_tf;      // [n][12] tf::Transform map_frame <- global_frame: basis row-major, origin
   InstCostmapState* state;  // [n]
   // staged cycle inputs
   double* pose;        // [n][3]

@@ -89,7 +89,7 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   }
   A(cm.origin, (size_t)n * 2);
   A(cm.master, (size_t)n * cm.cells_padded);
-  if (d->layers & NAVGPU_LAYER_STATIC) A(cm.stat, (size_t)n * cm.cells_padded);
+  if ((d->layers & NAVGPU_LAYER_STATIC) && !d->rolling_window) A(cm.stat, (size_t)n * cm.cells_padded);  // (rolling: navgpu_static_set_rolling_map)
   if (d->layers & (NAVGPU_LAYER_OBSTACLE | NAVGPU_LAYER_VOXEL)) A(cm.obst, (size_t)n * cm.cells_padded);
   if (d->layers & NAVGPU_LAYER_VOXEL) A(cm.voxel, (size_t)n * cm.cells_padded);
   A(cm.lut, 66 * 66);
@@ -103,10 +103,14 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   A(cm.points, (size_t)n * cm.max_points * 3);
   A(cm.shift, (size_t)n * 2);
   if (d->rolling_window) {
-    if (d->layers & NAVGPU_LAYER_STATIC) {
-      g_last_error = "rolling_window with a static layer needs tf (StaticLayer::updateCosts rolling branch) and is not supported";
-      navgpu_fleet_destroy(f);
-      return NAVGPU_ERR_INVALID;
+    if (d->layers & NAVGPU_LAYER_STATIC) {  // StaticLayer::updateCosts' rolling branch: a transform per robot, identity until set
+      A(cm.stat_tf, (size_t)n * 12);
+      std::vector<double> ident((size_t)n * 12, 0.0);
+      for (uint32_t i = 0; i < n; ++i) ident[(size_t)i * 12 + 0] = ident[(size_t)i * 12 + 4] = ident[(size_t)i * 12 + 8] = 1.0;
+      if (hipMemcpy(cm.stat_tf, ident.data(), sizeof(double) * ident.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        navgpu_fleet_destroy(f);
+        return NAVGPU_ERR_HIP;
+      }
     }
     A(cm.master_alt, (size_t)n * cm.cells_padded);
     if (cm.obst) A(cm.obst_alt, (size_t)n * cm.cells_padded);
@@ -414,6 +418,53 @@ int navgpu_static_set_map(navgpu_fleet* f, uint32_t first, uint32_t count, const
   HIP_TRY(hipMemcpyAsync(cm.state + first, st.data(), sizeof(InstCostmapState) * count, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(waitStream(f->stream));
   return checkLaunch();
+}
+
+int navgpu_static_set_rolling_map(navgpu_fleet* f, const int8_t* occ, uint32_t size_x, uint32_t size_y, double resolution, double origin_x,
+                                  double origin_y, int32_t track_unknown_space, int32_t use_maximum, int32_t trinary, int32_t lethal_cost_threshold,
+                                  int32_t unknown_cost_value) {
+  if (!f || !occ || size_x == 0 || size_y == 0 || !(resolution > 0)) return NAVGPU_ERR_INVALID;
+  CostmapDev& cm = f->cm;
+  if (!f->desc.rolling_window || !(cm.layers & NAVGPU_LAYER_STATIC) || !cm.stat_tf) {
+    g_last_error = "navgpu_static_set_rolling_map needs a rolling_window fleet with NAVGPU_LAYER_STATIC (else: navgpu_static_set_map)";
+    return NAVGPU_ERR_STATE;
+  }
+  const size_t cells = (size_t)size_x * size_y;
+  if (cells > 0xFFFFFFFFull) return NAVGPU_ERR_CAPACITY;
+  HIP_TRY(waitStream(f->stream));
+  int8_t* d_in = nullptr;
+  uint8_t* d_map = nullptr;
+  int rc = f->alloc(&d_in, cells);
+  if (rc) return rc;
+  if ((rc = f->alloc(&d_map, cells))) {
+    f->release(d_in);
+    return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(d_in, occ, cells, hipMemcpyHostToDevice, f->stream));
+  const int lethal = std::max(std::min(lethal_cost_threshold, 100), 0);  // static_layer.cpp:80
+  launch_static_interpret(d_map, d_in, (uint32_t)cells, (uint32_t)cells, 1, track_unknown_space, trinary, lethal, unknown_cost_value, f->stream);
+  HIP_TRY(waitStream(f->stream));
+  f->release(d_in);
+  if (cm.stat_roll) f->release(cm.stat_roll);
+  cm.stat_roll = d_map;
+  cm.stat_nx = size_x;
+  cm.stat_ny = size_y;
+  cm.stat_res = resolution;
+  cm.stat_ox = origin_x;
+  cm.stat_oy = origin_y;
+  cm.static_use_maximum = use_maximum;
+  cm.static_received = 1;
+  f->touchInputs(0, f->desc.n_instances);
+  return checkLaunch();
+}
+
+int navgpu_static_set_transform(navgpu_fleet* f, uint32_t first, uint32_t count, const double* m) {
+  if (!f || !m || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  if (!f->cm.stat_tf) return NAVGPU_ERR_STATE;
+  HIP_TRY(hipMemcpyAsync(f->cm.stat_tf + (size_t)first * 12, m, sizeof(double) * 12 * count, hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(waitStream(f->stream));  // the caller's buffer is free on return
+  f->touchInputs(first, count);
+  return NAVGPU_OK;
 }
 
 int navgpu_obstacle_configure(navgpu_fleet* f, const navgpu_obstacle_params* p) {

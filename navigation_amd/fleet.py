@@ -109,6 +109,23 @@ class Fleet:
                                            int(trinary_costmap), lethal_cost_threshold, unknown_cost_value),
               "static_set_map")
 
+    def set_rolling_static_map(self, occupancy, resolution, origin_x, origin_y, track_unknown_space=True, use_maximum=False,
+                               trinary_costmap=True, lethal_cost_threshold=100, unknown_cost_value=-1):
+        """StaticLayer of a rolling-window fleet: one static map with its own geometry (static_layer.cpp:300-333)."""
+        occ = np.ascontiguousarray(occupancy, np.int8)
+        sy, sx = occ.shape
+        check(self.L.navgpu_static_set_rolling_map(self.h, _ptr(occ), sx, sy, float(resolution), float(origin_x), float(origin_y),
+                                                   int(track_unknown_space), int(use_maximum), int(trinary_costmap), lethal_cost_threshold,
+                                                   unknown_cost_value), "static_set_rolling_map")
+
+    def set_static_transform(self, basis, origin, first=0, count=None):
+        """map_frame <- global_frame per robot: 3x3 basis (row-major) and origin, broadcast when a single one is given."""
+        first, count = self._range(first, count)
+        b = np.asarray(basis, np.float64).reshape(-1, 9)
+        o = np.asarray(origin, np.float64).reshape(-1, 3)
+        m = np.ascontiguousarray(np.broadcast_to(np.concatenate([b, o], 1), (count, 12)))
+        check(self.L.navgpu_static_set_transform(self.h, first, count, _ptr(m)), "static_set_transform")
+
     def configure_obstacle(self, enabled=True, footprint_clearing_enabled=True, combination_method=1,
                            max_obstacle_height=2.0, z_voxels=10, origin_z=0.0, z_resolution=0.2,
                            unknown_threshold=15, mark_threshold=0):

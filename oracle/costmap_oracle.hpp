@@ -351,8 +351,12 @@ struct StaticLayerOracle {
     map_received = true;
     has_updated_data = true;
   }
+  // rolling window (static_layer.cpp:265-268: the early return is for non-rolling costmaps only): the layer's own
+  // extent joins the bounds every cycle, so LayeredCostmap::updateMap rewrites the whole window
+  bool rolling = false;
+  double tf_basis[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tf_origin[3] = {0, 0, 0};  // map_frame <- global_frame (tf::StampedTransform)
   void updateBounds(Bounds& b) {
-    if (!map_received || !has_updated_data) return;
+    if (!rolling && (!map_received || !has_updated_data)) return;
     double wx, wy;
     grid.mapToWorld(x_, y_, wx, wy);
     b.min_x = std::min(wx, b.min_x);
@@ -364,10 +368,30 @@ struct StaticLayerOracle {
   }
   void updateCosts(Grid2D& master, int min_i, int min_j, int max_i, int max_j) const {
     if (!map_received) return;
-    if (!use_maximum)
-      updateWithTrueOverwrite(grid, master, min_i, min_j, max_i, max_j);
-    else
-      updateWithMax(grid, master, min_i, min_j, max_i, max_j);
+    if (!rolling) {
+      if (!use_maximum)
+        updateWithTrueOverwrite(grid, master, min_i, min_j, max_i, max_j);
+      else
+        updateWithMax(grid, master, min_i, min_j, max_i, max_j);
+      return;
+    }
+    // rolling branch (static_layer.cpp:300-333): every master cell of the window -> world -> map frame -> static cell.
+    // tf::Transform::operator() (LinearMath, not in the reference tree; its published form): basis row . point + origin
+    for (unsigned int i = min_i; i < (unsigned int)max_i; ++i) {
+      for (unsigned int j = min_j; j < (unsigned int)max_j; ++j) {
+        double wx, wy;
+        master.mapToWorld(i, j, wx, wy);
+        const double px = tf_basis[0] * wx + tf_basis[1] * wy + tf_basis[2] * 0.0 + tf_origin[0];
+        const double py = tf_basis[3] * wx + tf_basis[4] * wy + tf_basis[5] * 0.0 + tf_origin[1];
+        unsigned int mx, my;
+        if (grid.worldToMap(px, py, mx, my)) {
+          if (!use_maximum)
+            master.cells[master.index(i, j)] = grid.cost(mx, my);
+          else
+            master.cells[master.index(i, j)] = std::max(grid.cost(mx, my), master.cost(i, j));
+        }
+      }
+    }
   }
 };
 

@@ -88,6 +88,24 @@ void orc_lc_add_static(void* h, const int8_t* occ, uint32_t sx, uint32_t sy, dou
     lc->resizeMap(sx, sy, res, ox, oy);
   lc->slayer.incomingMap(occ, sx, sy, res, ox, oy);
 }
+// StaticLayer under a rolling window: incomingMap resizes the LAYER only (static_layer.cpp:187-193), the master keeps its geometry
+void orc_lc_add_static_rolling(void* h, const int8_t* occ, uint32_t sx, uint32_t sy, double res, double ox, double oy, int track_unknown_space,
+                               int use_maximum, int trinary, int lethal_threshold, int unknown_cost_value) {
+  auto* lc = static_cast<LayeredCostmapOracle*>(h);
+  lc->has_static = true;
+  lc->slayer.rolling = true;
+  lc->slayer.track_unknown_space = track_unknown_space != 0;
+  lc->slayer.use_maximum = use_maximum != 0;
+  lc->slayer.trinary_costmap = trinary != 0;
+  lc->slayer.lethal_threshold = (uint8_t)std::max(std::min(lethal_threshold, 100), 0);
+  lc->slayer.unknown_cost_value = (uint8_t)unknown_cost_value;
+  lc->slayer.incomingMap(occ, sx, sy, res, ox, oy);
+}
+void orc_lc_set_static_transform(void* h, const double* m12) {
+  auto* lc = static_cast<LayeredCostmapOracle*>(h);
+  for (int i = 0; i < 9; ++i) lc->slayer.tf_basis[i] = m12[i];
+  for (int i = 0; i < 3; ++i) lc->slayer.tf_origin[i] = m12[9 + i];
+}
 void orc_lc_add_obstacle(void* h, int combination_method, int footprint_clearing, double max_obstacle_height) {
   auto* lc = static_cast<LayeredCostmapOracle*>(h);
   lc->has_obstacle = true;

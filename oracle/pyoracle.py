@@ -89,6 +89,8 @@ def lib():
     sig("orc_lc_get_origin", None, vp, f64p)
     sig("orc_lc_resize", None, vp, u, u, d, d, d)
     sig("orc_lc_add_static", None, vp, i8p, u, u, d, d, d, i, i)
+    sig("orc_lc_add_static_rolling", None, vp, i8p, u, u, d, d, d, i, i, i, i, i)
+    sig("orc_lc_set_static_transform", None, vp, f64p)
     sig("orc_lc_add_obstacle", None, vp, i, i, d)
     sig("orc_lc_add_voxel", None, vp, i, i, d, u, d, d, u, u)
     sig("orc_lc_add_inflation", None, vp, d, d, i)
@@ -242,6 +244,19 @@ class LayeredCostmap:
         occ = np.ascontiguousarray(occ, dtype=np.int8)
         sy, sx = occ.shape
         self.L.orc_lc_add_static(self.h, occ, sx, sy, res, ox, oy, int(track_unknown_space), int(use_maximum))
+
+    def add_static_rolling(self, occ, res, ox, oy, track_unknown_space=True, use_maximum=False, trinary=True, lethal_threshold=100,
+                           unknown_cost_value=-1):
+        """StaticLayer of a rolling-window costmap: the static map keeps its own geometry (static_layer.cpp:187-193)."""
+        occ = np.ascontiguousarray(occ, dtype=np.int8)
+        sy, sx = occ.shape
+        self.L.orc_lc_add_static_rolling(self.h, occ, sx, sy, res, ox, oy, int(track_unknown_space), int(use_maximum), int(trinary),
+                                         int(lethal_threshold), int(unknown_cost_value) & 0xFF)
+
+    def set_static_transform(self, basis, origin):
+        """map_frame <- global_frame as tf::Transform: 3x3 basis (row-major) and origin."""
+        m = np.concatenate([np.asarray(basis, np.float64).reshape(9), np.asarray(origin, np.float64).reshape(3)])
+        self.L.orc_lc_set_static_transform(self.h, np.ascontiguousarray(m))
 
     def add_obstacle(self, combination_method=1, footprint_clearing=True, max_obstacle_height=2.0):
         self.L.orc_lc_add_obstacle(self.h, combination_method, int(footprint_clearing), max_obstacle_height)

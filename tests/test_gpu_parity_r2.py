@@ -623,3 +623,74 @@ def test_big_map_bounded_equals_complete(nav, orc):
     assert np.allclose(sb[0][0][scored], cfull[scored], rtol=0, atol=1e-5)
     for which in range(3):
         assert np.array_equal(gb[which][0].astype(np.float64).reshape(-1), p.grid(which).reshape(-1))
+
+
+# ----------------------------------------------------------------------------------------------
+# StaticLayer under a rolling window (static_layer.cpp:262-333): a static map with its own geometry is looked up per
+# master cell through a map_frame <- global_frame transform; the layer's extent joins the bounds every cycle.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("use_maximum,track_unknown", [(False, True), (True, True), (False, False), (True, False)])
+def test_rolling_static_layer_cycles(nav, orc, use_maximum, track_unknown):
+    from navigation_amd import synth
+    N = L(nav)
+    n, nI = 120, 3
+    insc = synth.inscribed_radius(synth.FOOTPRINT)
+    fl = nav.Fleet(nI, n, n, synth.RES, layers=N.LAYER_STATIC | N.LAYER_OBSTACLE | N.LAYER_INFLATION, track_unknown=track_unknown,
+                   max_points=720, max_observations=1, rolling_window=True)
+    fl.configure_obstacle()
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, insc)
+    # the static map: 260 x 200 cells of 0.1 m (coarser than the 0.05 m costmap), origin (-3, -2), walls, free space, unknown
+    rs = np.random.RandomState(11)
+    occ = np.zeros((200, 260), np.int8)
+    occ[rs.random_sample(occ.shape) < 0.01] = 100
+    occ[40:44, 20:200] = 100
+    occ[:, 120:122] = 100
+    occ[rs.random_sample(occ.shape) < 0.05] = -1
+    occ[rs.random_sample(occ.shape) < 0.02] = 60  # below the lethal threshold: free in a trinary map
+    kw = dict(track_unknown_space=track_unknown, use_maximum=use_maximum)
+    fl.set_rolling_static_map(occ, 0.1, -3.0, -2.0, **kw)
+    world = synth.make_instance(400, 78)
+    oracles = []
+    for i in range(nI):
+        o = orc.LayeredCostmap(track_unknown)
+        o.resize(n, n, synth.RES, 0, 0)
+        o.set_rolling(True)
+        o.set_footprint(synth.FOOTPRINT)
+        o.add_static_rolling(occ, 0.1, -3.0, -2.0, **kw)
+        o.add_obstacle()
+        o.add_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, exact=True)
+        o.set_footprint(synth.FOOTPRINT)
+        oracles.append(o)
+    starts = rs.uniform(2.0, 4.0, (nI, 2))
+    for cyc in range(5):
+        poses, obs = [], []
+        for i in range(nI):
+            # odom drifts against the map: a rotation + translation that changes every cycle (robot 0 keeps the identity)
+            a = 0.0 if i == 0 else 0.07 * cyc * i - 0.2
+            basis = [np.cos(a), -np.sin(a), 0, np.sin(a), np.cos(a), 0, 0, 0, 1]
+            origin = [0.0, 0.0, 0.0] if i == 0 else [0.31 * i - 0.05 * cyc, -0.4 + 0.03 * cyc, 0.0]
+            fl.set_static_transform(basis, origin, first=i, count=1)
+            oracles[i].set_static_transform(basis, origin)
+            x = starts[i, 0] + 0.41 * cyc * (1 if i != 1 else -1) + (14.0 if (cyc == 3 and i == 2) else 0.0)  # robot 2 leaves the static map
+            y = starts[i, 1] + 0.23 * cyc
+            yaw = 0.3 * cyc - 0.5 * i
+            inst = dict(world)
+            inst["pos"] = np.array([x, y, yaw], np.float32)
+            pts = synth.laser_scan(inst, cyc, max_range=4.0)
+            org = (float(x), float(y), 0.3)
+            poses.append([float(x), float(y), float(yaw)])
+            obs.append(dict(instance=i, points=pts, origin=org, obstacle_range=2.5, raytrace_range=3.0))
+            oracles[i].clear_observations()
+            oracles[i].add_observation(pts, origin=org, obstacle_range=2.5, raytrace_range=3.0)
+            oracles[i].update_map(*poses[-1])
+        fl.stage_observations(poses, obs)
+        fl.update_map()
+        m, b, org_g = fl.master(), fl.bounds(), fl.origins()
+        for i in range(nI):
+            assert np.array_equal(org_g[i], oracles[i].origin()), ("origin", cyc, i)
+            assert np.array_equal(b[i], oracles[i].bounds()), ("box", cyc, i)
+            assert np.array_equal(m[i], oracles[i].master()), ("master", cyc, i)
+        # (use_maximum over a NO_INFORMATION default: the rolling branch's plain std::max keeps 255 everywhere, static_layer.cpp:328)
+        assert use_maximum or ((m[0] == LETHAL).sum() > 50 and (not track_unknown or (m[0] == NOINFO).sum() > 50))
+    fl.close()

@@ -405,3 +405,24 @@ def test_trajectory_planner_footprint_obstacles(orc):
     tp.set_costmap(np.zeros((10, 10), np.uint8))
     tp.update_plan([[4.5, 8.5]], compute_dists=True)
     assert tp.generate([4.5, 4.5, math.pi / 2], [0, 0, 0], [0, 0, math.pi / 2], [0, 0, math.pi / 4], 100) >= 0
+
+
+def test_oracle_rolling_static_layer_identity_equals_shifted_copy(orc):
+    """StaticLayer's rolling branch (static_layer.cpp:300-333) with the identity transform and a static map of the
+    costmap's own resolution: the window is the static map's cells under it, the rest stays at the default."""
+    occ = np.zeros((60, 80), np.int8)
+    occ[10:20, 30:50] = 100
+    occ[40, :] = -1
+    o = orc.LayeredCostmap(True)
+    o.resize(40, 40, 0.5, 0, 0)
+    o.set_rolling(True)
+    o.add_static_rolling(occ, 0.5, -5.0, -5.0)
+    o.update_map(4.0, 3.0, 0.0)  # sizeInMeters = 19.75: the origin snaps to (-5.5, -6.5); cells left of / below the static map keep 255
+    m = o.master()
+    ox, oy = o.origin()
+    assert (ox, oy) == (-5.5, -6.5)
+    want = np.full((40, 40), 255, np.uint8)
+    interp = np.where(occ == 100, 254, np.where(occ == -1, 255, 0)).astype(np.uint8)
+    want[3:, 1:] = interp[:37, :39]  # master cell (i, j) <-> static cell (i - 1, j - 3)
+    assert np.array_equal(m, want)
+    assert np.array_equal(o.bounds(), [1, 40, 3, 40])  # the static map's extent (from its cell (0, 0) centre), clipped to the window, every cycle
