@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate the golden vectors of SURVEY 8(c) (G1-G6) under tests/golden/ from the CPU oracle.
+"""Generate the golden vectors of SURVEY 8(c) (G1-G6; G7 navfn and G8 global_planner for row f-4) under tests/golden/ from the CPU oracle.
 
 The reference itself cannot be built in this image (its hot-path sources need ROS, Boost, Eigen and PCL headers), so these
 vectors come from oracle/ - the restatement that IS pinned by every fixture the reference's own tests hold
@@ -143,8 +143,59 @@ def g6_voxel():
     np.savez_compressed(os.path.join(OUT, "g6_voxel.npz"), **out)
 
 
+def planner_map(rs, n):
+    """A costmap as the global planners see one: lethal blobs with an inscribed ring and a cost gradient around them."""
+    g = np.zeros((n, n), np.uint8)
+    for _ in range(n // 6):
+        cx, cy, r = rs.randint(4, n - 4), rs.randint(4, n - 4), rs.randint(1, 4)
+        g[cy - r:cy + r + 1, cx - r:cx + r + 1] = 254
+    return orc.inflate(g, 0.05, 0.4, 6.0, 0.1, exact=True)
+
+
+def g7_navfn():
+    """navfn::NavFn (SURVEY 8 f-4): Dijkstra and A* potentials, cycle counts and gradient paths on 96 x 96 costmaps."""
+    rs = np.random.RandomState(107)
+    out = dict(seed=107)
+    for k in range(3):
+        cm = planner_map(rs, 96)
+        start, goal = (rs.randint(6, 40), rs.randint(6, 90)), (rs.randint(56, 90), rs.randint(6, 90))
+        for cell in (start, goal):
+            cm[cell[1] - 1:cell[1] + 2, cell[0] - 1:cell[0] + 2] = 0
+        out[f"costmap{k}"] = cm
+        out[f"start{k}"] = np.array(start, np.int32)
+        out[f"goal{k}"] = np.array(goal, np.int32)
+        for astar in (0, 1):
+            path, pot, cyc = orc.navfn_plan(cm, goal, start, astar=bool(astar), allow_unknown=True)
+            out[f"path{k}_{astar}"] = path
+            out[f"potential{k}_{astar}"] = pot
+            out[f"cycles{k}_{astar}"] = np.int32(cyc)
+    np.savez_compressed(os.path.join(OUT, "g7_navfn.npz"), **out)
+
+
+G8_VARIANTS = [dict(), dict(use_quadratic=0, use_grid_path=1), dict(use_dijkstra=0, use_grid_path=1), dict(old_navfn_behavior=1),
+               dict(use_dijkstra=0), dict(allow_unknown=0, cost_factor=0.55, neutral_cost=66)]
+
+
+def g8_global_planner():
+    """global_planner's expanders and tracebacks on a 96 x 96 costmap, fractional start / goal."""
+    rs = np.random.RandomState(108)
+    cm = planner_map(rs, 96)
+    start, goal = np.array([14.3, 20.7]), np.array([80.6, 71.2])
+    for x, y in (start, goal):
+        cm[int(y) - 1:int(y) + 3, int(x) - 1:int(x) + 3] = 0
+    out = dict(seed=108, costmap=cm, start=start, goal=goal, n_variants=len(G8_VARIANTS))
+    for k, kw in enumerate(G8_VARIANTS):
+        s, g = (np.floor(start), np.floor(goal)) if kw.get("old_navfn_behavior") else (start, goal)
+        path, pot, legal, cyc = orc.global_planner_plan(cm, s, g, g.astype(np.int32), **kw)
+        out[f"path{k}"] = path
+        out[f"potential{k}"] = pot
+        out[f"legal{k}"] = np.int32(legal)
+        out[f"cycles{k}"] = np.int32(cyc)
+    np.savez_compressed(os.path.join(OUT, "g8_global_planner.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    for fn in (g1_inflation, g2_mapgrid, g3_rollout, g4_footprint, g5_velocity_iterator, g6_voxel):
+    for fn in (g1_inflation, g2_mapgrid, g3_rollout, g4_footprint, g5_velocity_iterator, g6_voxel, g7_navfn, g8_global_planner):
         fn()
         print("wrote", fn.__name__)
