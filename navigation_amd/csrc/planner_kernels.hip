@@ -23,45 +23,112 @@ __device__ __forceinline__ Geom geomOf(const PlannerDev& pl, uint32_t inst) {
 // One lane per axis: `next += step_size` is a sequential fp64 accumulation and must stay one.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t bfsFreeWord(const uint8_t* master, uint32_t row, uint32_t nx, uint32_t wi, uint32_t unknown_is_obstacle);
-__global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first, uint32_t count) {
-  const uint32_t tid = threadIdx.x;
-  if (blockIdx.x >= count) {
-    // the blocks behind the per-robot ones build the traversable-cell bitmaps of the launch (what k_free_bits does on its
-    // own for the other callers of launch_bfs): throughput work that fills the CUs while the per-robot waves wait on memory
-    const uint32_t W = (pl.nx + 31) >> 5, words = pl.ny * W, per = (words + 63) / 64;
-    const uint32_t b = blockIdx.x - count, r = b / per, i = (b - r * per) * 64 + tid;
+// Three kinds of 128-thread blocks, all latency-bound and independent of each other, side by side:
+//   [0, count)          one robot's wavefront region, pocket floods and care words (wave 0: the region's flood, wave 1: the
+//                       large area's), 
+//   [count, 2 count)    wave 0: the robot's three items ranked for the longest-first dispatch; wave 1: its velocity samples,
+//   behind them         the traversable-cell bitmaps of the launch, 128 words per block.
+constexpr int kSamplesThreads = 128;
+__global__ __launch_bounds__(kSamplesThreads) void k_samples(PlannerDev pl, uint32_t first, uint32_t count) {
+  const uint32_t tid = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  if (blockIdx.x >= 2 * count) {
+    // the traversable-cell bitmaps of the launch (what k_free_bits does on its own for the other callers of launch_bfs):
+    // throughput work that fills the CUs while the per-robot waves wait on memory
+    const uint32_t W = (pl.nx + 31) >> 5, words = pl.ny * W, per = (words + kSamplesThreads - 1) / kSamplesThreads;
+    const uint32_t b = blockIdx.x - 2 * count, r = b / per, i = (b - r * per) * kSamplesThreads + threadIdx.x;
     if (i < words) {
       const uint32_t row = i / W, wi = i - row * W;
       pl.bfs_free[(size_t)(first + r) * words + i] = bfsFreeWord(pl.master + (size_t)(first + r) * pl.cells_padded, row, pl.nx, wi, pl.cfg.allow_unknown != 0 ? 0u : 1u);
     }
     return;
   }
-  const uint32_t inst = first + blockIdx.x;
   const navgpu_dwa_config& c = pl.cfg;
-  const navgpu_robot_state st = pl.state[inst];
-  // dispatch order of this launch's wavefronts (k_bfs_wave takes items off a counter): longest first, predicted by
-  // the level count of the robot's previous cycle.  item = g * count + robot, g = 0 goal_front, 1 goal, 2 path;
-  // every robot ranks its three items among all of them (count * 3 keys: a dozen loads per lane, issued before anything
-  // is stored so that they overlap the other loads of this kernel - its time is all memory latency)
-  uint32_t rank[3];
-  {
-    const uint32_t total = 3 * count;
-    uint32_t key[3], before[3] = {0, 0, 0};
+  if (blockIdx.x >= count) {
+    const uint32_t robot = blockIdx.x - count, inst = first + robot;
+    if (wv == 0) {
+      // dispatch order of this launch's wavefronts (k_bfs_wave takes items off a counter): longest first, predicted by
+      // the level count of the robot's previous cycle.  item = g * count + robot, g = 0 goal_front, 1 goal, 2 path;
+      // every robot ranks its three items among all of them (count * 3 keys: a dozen loads per lane)
+      const uint32_t total = 3 * count;
+      uint32_t key[3], before[3] = {0, 0, 0};
 #pragma unroll
-    for (uint32_t g = 0; g < 3; ++g) key[g] = pl.bfs_levels[(size_t)inst * 3 + (2 - g)];
+      for (uint32_t g = 0; g < 3; ++g) key[g] = pl.bfs_levels[(size_t)inst * 3 + (2 - g)];
 #pragma unroll 4
-    for (uint32_t j = tid; j < total; j += 64) {
-      const uint32_t gj = j / count, rj = j - gj * count;
-      const uint32_t kj = pl.bfs_levels[(size_t)(first + rj) * 3 + (2 - gj)];
+      for (uint32_t j = tid; j < total; j += 64) {
+        const uint32_t gj = j / count, rj = j - gj * count;
+        const uint32_t kj = pl.bfs_levels[(size_t)(first + rj) * 3 + (2 - gj)];
 #pragma unroll
-      for (uint32_t g = 0; g < 3; ++g) before[g] += (kj > key[g] || (kj == key[g] && j < g * count + blockIdx.x)) ? 1u : 0u;
-    }
+        for (uint32_t g = 0; g < 3; ++g) before[g] += (kj > key[g] || (kj == key[g] && j < g * count + robot)) ? 1u : 0u;
+      }
 #pragma unroll
-    for (uint32_t g = 0; g < 3; ++g) {
-      for (int o = 32; o > 0; o >>= 1) before[g] += __shfl_xor(before[g], o);
-      rank[g] = before[g];
+      for (uint32_t g = 0; g < 3; ++g)
+        for (int o = 32; o > 0; o >>= 1) before[g] += __shfl_xor(before[g], o);
+      if (tid < 3) pl.bfs_order[(size_t)first * 3 + (tid == 0 ? before[0] : (tid == 1 ? before[1] : before[2]))] = tid * count + robot;
+      if (robot == 0 && tid < 2) pl.bfs_next_item[tid] = 0;  // the work counters of the launch_bfs that follows
+      return;
     }
+    // ---- velocity samples, one lane per axis: `next += step_size` is a sequential fp64 accumulation and must stay one
+    const navgpu_robot_state st = pl.state[inst];
+    int32_t* cnt = pl.axis_count + 4 * inst;
+    int n = 0;
+    if (tid < 3) {
+      const int a = tid;
+      const float vsamp = a == 0 ? (float)c.vx_samples : (a == 1 ? (float)c.vy_samples : (float)c.vth_samples);
+      const double max_vel_th = c.max_rot_vel, min_vel_th = -1.0 * max_vel_th;
+      double lim_min = a == 0 ? c.min_vel_x : (a == 1 ? c.min_vel_y : min_vel_th);
+      double lim_max = a == 0 ? c.max_vel_x : (a == 1 ? c.max_vel_y : max_vel_th);
+      const float acc = a == 0 ? (float)c.acc_lim_x : (a == 1 ? (float)c.acc_lim_y : (float)c.acc_lim_theta);
+      const float v = st.vel[a];
+      float maxv, minv;
+      if (!c.use_dwa) {
+        // goal = last pose of the plan narrowed to float (dwa_planner.cpp:305-306)
+        const double* P = pl.plan + (size_t)inst * pl.max_plan * 2;
+        const uint32_t np = pl.plan_count[inst];
+        const float gx = (float)P[2 * (np - 1)], gy = (float)P[2 * (np - 1) + 1];
+        double dist = hyp2((double)(gx - st.pos[0]), (double)(gy - st.pos[1]));
+        if (a < 2) lim_max = fmax(fmin(lim_max, dist / c.sim_time), lim_min);
+        maxv = (float)fmin(lim_max, v + acc * c.sim_time);
+        minv = (float)fmax(lim_min, v - acc * c.sim_time);
+      } else {
+        maxv = (float)fmin(lim_max, v + acc * c.sim_period);
+        minv = (float)fmax(lim_min, v - acc * c.sim_period);
+      }
+      float* out = pl.axis_samples + ((size_t)inst * 3 + a) * pl.max_axis;
+      const double mn = minv, mx = maxv;
+      if (mn == mx) {
+        out[n++] = (float)mn;
+      } else {
+        int num_samples = (int)vsamp;
+        num_samples = num_samples > 2 ? num_samples : 2;
+        double step_size = (mx - mn) / double(num_samples - 1 > 1 ? num_samples - 1 : 1);
+        double current, next = mn;
+        for (int j = 0; j < num_samples - 1; ++j) {
+          current = next;
+          next += step_size;
+          if (n < (int)pl.max_axis) out[n] = (float)current;
+          ++n;
+          if ((current < 0) && (next > 0)) {
+            if (n < (int)pl.max_axis) out[n] = 0.0f;
+            ++n;
+          }
+        }
+        if (n < (int)pl.max_axis) out[n] = (float)mx;
+        ++n;
+      }
+      n = n < (int)pl.max_axis ? n : (int)pl.max_axis;
+      cnt[a] = n;
+    }
+    const int n0 = __shfl(n, 0), n1 = __shfl(n, 1), n2 = __shfl(n, 2);
+    if (tid == 0) {
+      float prod = (float)c.vx_samples * (float)c.vy_samples * (float)c.vth_samples;
+      cnt[3] = prod > 0 ? n0 * n1 * n2 : 0;
+      pl.counters[2 * inst] = 0;
+      pl.counters[2 * inst + 1] = 0;
+    }
+    return;
   }
+  const uint32_t inst = first + blockIdx.x;
+  const navgpu_robot_state st = pl.state[inst];
   // Bounded wavefronts (k_bfs_wave).  The box = every cell a MapGrid look-up of this robot's samples can fall in: the
   // staged reach around the robot's cell.  The region = the box grown by two cells, clipped to the map.  A search may
   // stop when (a) no cell of the box that it could still reach is open and (b) no frontier cell is inside the region.
@@ -69,16 +136,18 @@ __global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first, u
   // the area looked at (one cell enclosed by inflated obstacles is enough to keep a search going over the whole map
   // otherwise).  A wavefront gets into a pocket only from a seed next to it, which (b) waits for - so the region has
   // to contain every pocket that counts.  Two areas are flooded from their rims, bit-parallel, two rows per lane, whole
-  // words filled along a row with an add-carry, neighbour rows by lane shuffles: the region, and the largest area the
-  // mask can hold around it (128 rows x 4 words).  When the large one finds pockets in the box that the region alone
-  // does not (a pocket that straddles the region's rim), the large area becomes this robot's region.
+  // words filled along a row with an add-carry, neighbour rows by lane shuffles: the region (wave 0), and the largest
+  // area the mask can hold around it (128 rows x 4 words; wave 1).  When the large one finds pockets in the box that
+  // the region alone does not (a pocket that straddles the region's rim), the large area becomes this robot's region.
+  __shared__ uint32_t s_pocket[2][2][kCareWords][64];  // [region | large][row half][word][lane]
+  __shared__ int s_ok[2];
   {
     int4 region = make_int4(0, -1, 0, -1);
     int care_ok = 0;
     const uint32_t reach = pl.bfs_reach[inst];
     const Geom g = geomOf(pl, inst);
     uint32_t mx = 0, my = 0;
-    if (reach && worldToMap(g, (double)st.pos[0], (double)st.pos[1], mx, my)) {
+    if (reach && worldToMap(g, (double)st.pos[0], (double)st.pos[1], mx, my)) {  // (uniform over the block)
       const int R = (int)reach + 2, nxi = (int)pl.nx, nyi = (int)pl.ny, Wm = (nxi + 31) >> 5;
       region.x = max((int)mx - R, 0);
       region.y = min((int)mx + R, nxi - 1);
@@ -98,61 +167,67 @@ __global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first, u
           const int lo = max(x0 - (fw0 + w) * 32, 0), hi = min(x1 - (fw0 + w) * 32, 31);
           return hi >= lo ? ((0xFFFFFFFFu >> (31 - hi)) & (0xFFFFFFFFu << lo)) : 0u;
         };
-        uint32_t fmL[2][kCareWords], fmR[2][kCareWords], FL[2][kCareWords], FR[2][kCareWords];
+        // this wave's area: x0..x1, y0..y1 (wave 0: the region, wave 1: the large area)
+        const int ax0 = wv ? fx0 : region.x, ax1 = wv ? fx1 : region.y, ay0 = wv ? fy0 : region.z, ay1 = wv ? fy1 : region.w;
+        uint32_t fm[2][kCareWords], F[2][kCareWords];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int row = fy0 + 2 * (int)tid + h;
-          const bool in_r = row >= region.z && row <= region.w;
+          const bool in_a = row >= ay0 && row <= ay1;
 #pragma unroll
           for (int w = 0; w < kCareWords; ++w) {
-            fmL[h][w] = fmR[h][w] = FL[h][w] = FR[h][w] = 0;
+            fm[h][w] = F[h][w] = 0;
             if (row <= fy1 && fw0 + w <= fw1) {
-              const uint32_t cmL = colMask(w, fx0, fx1), cmR = in_r ? colMask(w, region.x, region.y) : 0u;
+              const uint32_t cm = in_a ? colMask(w, ax0, ax1) : 0u;
               const uint32_t fw_ = bfsFreeWord(master, (uint32_t)row, pl.nx, (uint32_t)(fw0 + w), unknown_is_obstacle);
-              fmL[h][w] = fw_ & cmL;
-              fmR[h][w] = fw_ & cmR;
-              const uint32_t rimL = (row == fy0 || row == fy1) ? cmL : (colMask(w, fx0, fx0) | colMask(w, fx1, fx1));
-              const uint32_t rimR = (row == region.z || row == region.w) ? cmR : (colMask(w, region.x, region.x) | colMask(w, region.y, region.y));
-              FL[h][w] = fmL[h][w] & rimL;
-              FR[h][w] = fmR[h][w] & rimR;
+              fm[h][w] = fw_ & cm;
+              const uint32_t rim = (row == ay0 || row == ay1) ? cm : (colMask(w, ax0, ax0) | colMask(w, ax1, ax1));
+              F[h][w] = fm[h][w] & rim;
             }
           }
         }
-        auto flood = [&](uint32_t (&F)[2][kCareWords], const uint32_t (&fm)[2][kCareWords]) -> bool {
-          for (int it = 0; it < 256; ++it) {
-            uint32_t changed = 0;
+        bool ok = false;
+        for (int it = 0; it < 256; ++it) {
+          uint32_t changed = 0;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+          for (int h = 0; h < 2; ++h) {
 #pragma unroll
-              for (int w = 0; w < kCareWords; ++w) {
-                uint32_t up, dn;
-                if (h == 0) {
-                  up = __shfl_up(F[1][w], 1);
-                  if (tid == 0) up = 0;
-                  dn = F[1][w];
-                } else {
-                  up = F[0][w];
-                  dn = __shfl_down(F[0][w], 1);
-                  if (tid == 63) dn = 0;
-                }
-                const uint32_t cur = F[h][w], f = fm[h][w];
-                uint32_t n = cur | up | dn | (cur << 1) | (cur >> 1);
-                if (w > 0) n |= F[h][w - 1] >> 31;
-                if (w + 1 < kCareWords) n |= F[h][w + 1] << 31;
-                n &= f;
-                // fill the runs of free cells the set bits lie in: towards bit 31 with an add-carry, towards bit 0 mirrored
-                n |= f & ~(f + n);
-                const uint32_t fr_ = __brev(f), nr = __brev(n);
-                n |= __brev(fr_ & ~(fr_ + nr));
-                changed |= n ^ cur;
-                F[h][w] = n;
+            for (int w = 0; w < kCareWords; ++w) {
+              uint32_t up, dn;
+              if (h == 0) {
+                up = __shfl_up(F[1][w], 1);
+                if (tid == 0) up = 0;
+                dn = F[1][w];
+              } else {
+                up = F[0][w];
+                dn = __shfl_down(F[0][w], 1);
+                if (tid == 63) dn = 0;
               }
+              const uint32_t cur = F[h][w], f = fm[h][w];
+              uint32_t n = cur | up | dn | (cur << 1) | (cur >> 1);
+              if (w > 0) n |= F[h][w - 1] >> 31;
+              if (w + 1 < kCareWords) n |= F[h][w + 1] << 31;
+              n &= f;
+              // fill the runs of free cells the set bits lie in: towards bit 31 with an add-carry, towards bit 0 mirrored
+              n |= f & ~(f + n);
+              const uint32_t fr_ = __brev(f), nr = __brev(n);
+              n |= __brev(fr_ & ~(fr_ + nr));
+              changed |= n ^ cur;
+              F[h][w] = n;
             }
-            if (__builtin_amdgcn_ballot_w64(changed != 0) == 0) return true;
           }
-          return false;
-        };
-        const bool okR = flood(FR, fmR), okL = flood(FL, fmL);
+          if (__builtin_amdgcn_ballot_w64(changed != 0) == 0) {
+            ok = true;
+            break;
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int w = 0; w < kCareWords; ++w) s_pocket[wv][h][w][tid] = fm[h][w] & ~F[h][w];
+        if (tid == 0) s_ok[wv] = ok ? 1 : 0;
+        __syncthreads();
+        const bool okR = s_ok[0] != 0, okL = s_ok[1] != 0;
         care_ok = okR ? 1 : 0;  // not settled within the bound: no pocket is left out (the search is exact either way)
         // pockets of the box that only the large area shows -> the large area is the region
         uint32_t extra = 0;
@@ -161,11 +236,11 @@ __global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first, u
           const int row = fy0 + 2 * (int)tid + h;
 #pragma unroll
           for (int w = 0; w < kCareWords; ++w)
-            if (row >= by0 && row <= by1) extra |= ((fmL[h][w] & ~FL[h][w]) ^ (fmR[h][w] & ~FR[h][w])) & colMask(w, bx0, bx1);
+            if (row >= by0 && row <= by1) extra |= (s_pocket[1][h][w][tid] ^ s_pocket[0][h][w][tid]) & colMask(w, bx0, bx1);
         }
         const bool large = okR && okL && __builtin_amdgcn_ballot_w64(extra != 0) != 0;
         if (large) region = make_int4(fx0, fx1, fy0, fy1);
-        if (okR) {
+        if (okR && wv == 0) {
           const int ry0 = region.z, rw0 = region.x >> 5;
           uint32_t* care = pl.bfs_care + (size_t)inst * kCareRows * kCareWords;
 #pragma unroll
@@ -175,14 +250,14 @@ __global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first, u
             for (int w = 0; w < kCareWords; ++w) {
               const int ww = fw0 + w - rw0;
               if (rr < 0 || rr >= kCareRows || row > region.w || ww < 0 || ww >= kCareWords) continue;
-              const uint32_t pocket = large ? (fmL[h][w] & ~FL[h][w]) : (fmR[h][w] & ~FR[h][w]);
+              const uint32_t pocket = s_pocket[large ? 1 : 0][h][w][tid];
               care[rr * kCareWords + ww] = (row >= by0 && row <= by1) ? (colMask(w, bx0, bx1) & ~pocket) : 0u;
             }
           }
         }
       }
     }
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
       int* b = pl.bfs_box + (size_t)inst * 8;
       b[0] = region.x;
       b[1] = region.y;
@@ -191,66 +266,11 @@ __global__ __launch_bounds__(64) void k_samples(PlannerDev pl, uint32_t first, u
       b[4] = care_ok;
     }
   }
-  int32_t* cnt = pl.axis_count + 4 * inst;
-  if (tid < 3) {
-    const int a = tid;
-    const float vsamp = a == 0 ? (float)c.vx_samples : (a == 1 ? (float)c.vy_samples : (float)c.vth_samples);
-    const double max_vel_th = c.max_rot_vel, min_vel_th = -1.0 * max_vel_th;
-    double lim_min = a == 0 ? c.min_vel_x : (a == 1 ? c.min_vel_y : min_vel_th);
-    double lim_max = a == 0 ? c.max_vel_x : (a == 1 ? c.max_vel_y : max_vel_th);
-    const float acc = a == 0 ? (float)c.acc_lim_x : (a == 1 ? (float)c.acc_lim_y : (float)c.acc_lim_theta);
-    const float v = st.vel[a];
-    float maxv, minv;
-    if (!c.use_dwa) {
-      // goal = last pose of the plan narrowed to float (dwa_planner.cpp:305-306)
-      const double* P = pl.plan + (size_t)inst * pl.max_plan * 2;
-      const uint32_t np = pl.plan_count[inst];
-      const float gx = (float)P[2 * (np - 1)], gy = (float)P[2 * (np - 1) + 1];
-      double dist = hyp2((double)(gx - st.pos[0]), (double)(gy - st.pos[1]));
-      if (a < 2) lim_max = fmax(fmin(lim_max, dist / c.sim_time), lim_min);
-      maxv = (float)fmin(lim_max, v + acc * c.sim_time);
-      minv = (float)fmax(lim_min, v - acc * c.sim_time);
-    } else {
-      maxv = (float)fmin(lim_max, v + acc * c.sim_period);
-      minv = (float)fmax(lim_min, v - acc * c.sim_period);
-    }
-    float* out = pl.axis_samples + ((size_t)inst * 3 + a) * pl.max_axis;
-    const double mn = minv, mx = maxv;
-    int n = 0;
-    if (mn == mx) {
-      out[n++] = (float)mn;
-    } else {
-      int num_samples = (int)vsamp;
-      num_samples = num_samples > 2 ? num_samples : 2;
-      double step_size = (mx - mn) / double(num_samples - 1 > 1 ? num_samples - 1 : 1);
-      double current, next = mn;
-      for (int j = 0; j < num_samples - 1; ++j) {
-        current = next;
-        next += step_size;
-        if (n < (int)pl.max_axis) out[n] = (float)current;
-        ++n;
-        if ((current < 0) && (next > 0)) {
-          if (n < (int)pl.max_axis) out[n] = 0.0f;
-          ++n;
-        }
-      }
-      if (n < (int)pl.max_axis) out[n] = (float)mx;
-      ++n;
-    }
-    cnt[a] = n < (int)pl.max_axis ? n : (int)pl.max_axis;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float prod = (float)c.vx_samples * (float)c.vy_samples * (float)c.vth_samples;
-    cnt[3] = prod > 0 ? cnt[0] * cnt[1] * cnt[2] : 0;
-    pl.counters[2 * inst] = 0;
-    pl.counters[2 * inst + 1] = 0;
-  }
-  if (tid < 3) pl.bfs_order[(size_t)first * 3 + (tid == 0 ? rank[0] : (tid == 1 ? rank[1] : rank[2]))] = tid * count + blockIdx.x;
 }
 void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
   const uint32_t words = pl.ny * ((pl.nx + 31) / 32);
-  hipLaunchKernelGGL(k_samples, dim3(count + count * ((words + 63) / 64)), dim3(64), 0, s, pl, first, count);  // + the bitmaps of launch_bfs(..., free_ready)
+  // (+ the bitmaps and the zeroed work counters of launch_bfs(..., free_ready))
+  hipLaunchKernelGGL(k_samples, dim3(2 * count + count * ((words + kSamplesThreads - 1) / kSamplesThreads)), dim3(kSamplesThreads), 0, s, pl, first, count);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1764,7 +1784,7 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
     const size_t lds_w = bfs_wave_lds(pl.nx, pl.ny, R);                                                                       \
     if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<R, LEG, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); \
     if (!free_ready) hipLaunchKernelGGL(k_free_bits, dim3((pl.ny * ((pl.nx + 31) / 32) + 255) / 256, count), dim3(256), 0, s, pl, first); \
-    hipMemsetAsync(pl.bfs_next_item, 0, 2 * sizeof(uint32_t), s);                                                             \
+    if (!free_ready) hipMemsetAsync(pl.bfs_next_item, 0, 2 * sizeof(uint32_t), s);  /* (k_samples zeroes them too) */         \
     const bool direct = !LEG && pl.bfs_bounded && n_whole >= 0 && (uint32_t)n_whole < count;                                  \
     if (!direct || n_whole > 0)                                                                                               \
       hipLaunchKernelGGL((k_bfs_wave<R, LEG, P>), dim3(std::min(count * pl.bfs_grids, bfs_cu_count())), dim3(1024), lds_w, s, pl, first, count, pl.bfs_next_item, order, direct ? 1 : 0); \
@@ -1796,7 +1816,7 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
   static const bool force_global_kernel = getenv("NAVGPU_DEBUG_BFS_GLOBAL") != nullptr;  // A/B timing only
   const int big = pl.bfs_grids == 3 && !force_global_kernel ? bfs_big_rows(pl.nx, pl.ny) : 0;
   if (big) {  // (the scratch holds 12 bitmaps per robot of the fleet; a workgroup uses one)
-    hipMemsetAsync(pl.bfs_next_item, 0, 2 * sizeof(uint32_t), s);
+    if (!free_ready) hipMemsetAsync(pl.bfs_next_item, 0, 2 * sizeof(uint32_t), s);
     const dim3 wgs(std::min(count * 3u, bfs_cu_count()));
     if (big == 24) hipLaunchKernelGGL(k_bfs_big<24>, wgs, dim3(1024), 0, s, pl, first, count, pl.bfs_next_item, order, pl.bfs_scratch);
     else hipLaunchKernelGGL(k_bfs_big<32>, wgs, dim3(1024), 0, s, pl, first, count, pl.bfs_next_item, order, pl.bfs_scratch);
