@@ -903,21 +903,38 @@ __global__ __launch_bounds__(256) void k_inflate_bits(CostmapDev cm, uint32_t fi
   s_lut2[tid] = cm.lut2[tid];
   __syncthreads();
   // ---- seed bitmaps by ballot: wave w takes halo rows w, w+4, ...
+  // (all of a wave's loads are issued before the first ballot needs one: in a rolled loop every load is waited for on
+  // its own, 28 latencies in a row - that was most of this kernel's 57 us)
   int any = 0;
-  for (int r = wave; r < HR; r += 4) {
-    const int gy = ty0 - R + r;
-    const bool row_ok = gy >= min_j && gy < max_j;
+  constexpr int kSeedIt = (kMaxHR + 3) / 4;
+  // The loads are unconditional (clamped coordinates; a conditional load is waited for inside its branch) and the
+  // conditions are applied to what they return.
+  uint8_t cell[kSeedIt][2];
+  const int gxa = tx0 - 32 + (int)lane, gxb = gxa + 64;
+  const int cxa = min(max(gxa, 0), (int)cm.nx - 1), cxb = min(max(gxb, 0), (int)cm.nx - 1);
+  const bool xa_ok = gxa >= min_i && gxa < max_i && gxa >= tx0 - R && gxa < tx0 + kBX + R;
+  const bool xb_ok = gxb >= min_i && gxb < max_i && gxb >= tx0 - R && gxb < tx0 + kBX + R;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int gx = tx0 - 32 + half * 64 + (int)lane;
-      bool sd = false;
-      if (row_ok && gx >= min_i && gx < max_i && gx >= tx0 - R && gx < tx0 + kBX + R) sd = master[gy * cm.nx + gx] == kLethal;
-      const unsigned long long m = __ballot(sd);
-      if (lane == 0) {
-        s_rows[r][2 * half] = (uint32_t)m;
-        s_rows[r][2 * half + 1] = (uint32_t)(m >> 32);
+  for (int it = 0; it < kSeedIt; ++it) {
+    const int gy = ty0 - R + (int)wave + 4 * it;
+    const int cy = min(max(gy, 0), (int)cm.ny - 1);
+    cell[it][0] = master[cy * cm.nx + cxa];
+    cell[it][1] = master[cy * cm.nx + cxb];
+  }
+#pragma unroll
+  for (int it = 0; it < kSeedIt; ++it) {
+    const int r = (int)wave + 4 * it, gy = ty0 - R + r;
+    if (r < HR) {  // (wave-uniform)
+      const bool row_ok = gy >= min_j && gy < max_j;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const unsigned long long m = __ballot(row_ok && (half ? xb_ok : xa_ok) && cell[it][half] == kLethal);
+        if (lane == 0) {
+          s_rows[r][2 * half] = (uint32_t)m;
+          s_rows[r][2 * half + 1] = (uint32_t)(m >> 32);
+        }
+        any |= m != 0ull;
       }
-      any |= m != 0ull;
     }
   }
   if (any && lane == 0) s_any = 1;

@@ -30,7 +30,8 @@ for st in steps:
 print(f"{len(steps)} steps; span {sum(span) / len(span) / 1e3:.1f} us, kernels {sum(busy) / len(busy) / 1e3:.1f} us")
 for (i, k) in sorted(dur):
     g = gap.get((i, k))
-    print(f"  {i:2d} {k[:60]:60s} {sum(dur[(i, k)]) / len(dur[(i, k)]) / 1e3:8.1f} us   gap before {(sum(g) / len(g) / 1e3 if g else 0):6.1f} us")
+    d = sorted(dur[(i, k)])
+    print(f"  {i:2d} {k[:50]:50s} mean {sum(d) / len(d) / 1e3:7.1f}  median {d[len(d) // 2] / 1e3:7.1f}  min {d[0] / 1e3:7.1f}  max {d[-1] / 1e3:7.1f} us   gap before {(sum(g) / len(g) / 1e3 if g else 0):5.1f} us")
 # step-to-step: start of k_obstacle to the next one
 starts = [st[0][0] for st in steps]
 d = [b - a for a, b in zip(starts, starts[1:]) if b - a < 10 * (sum(span) / len(span))]
