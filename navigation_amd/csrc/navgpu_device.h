@@ -17,6 +17,12 @@ namespace navgpu {
 constexpr uint8_t kNoInfo = 255, kLethal = 254, kInscribed = 253, kFree = 0;
 constexpr int kMaxFootprint = 32;
 constexpr int kCareRows = 128, kCareWords = 4;  // bounded wavefronts: extent of the per-robot pocket mask (k_samples)
+#ifndef NAVGPU_SCORE_TAB_THREADS
+#define NAVGPU_SCORE_TAB_THREADS 256  // samples per k_score_tab workgroup (512 with a 52 KB image: 0.523 ms; 256 with 26 KB: 0.516 ms, configs[4] 2.17 -> 1.82 ms)
+#endif
+#ifndef NAVGPU_SCORE_TAB_LDS_KB
+#define NAVGPU_SCORE_TAB_LDS_KB 26    // first LDS budget tried for a k_score_tab workgroup's image (window + screens + table rows)
+#endif
 #ifndef NAVGPU_SCORE_THREADS
 #define NAVGPU_SCORE_THREADS 256
 #endif

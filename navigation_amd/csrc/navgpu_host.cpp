@@ -949,7 +949,7 @@ int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
   const uint32_t max_samples = ax * ay * at;
   // capacity of the per-workgroup partial results: the 256-thread launch, and the table launch's row groups (each
   // rounds its share up to whole workgroups: at most one more per v_theta value, planner_kernels.hip launch_score)
-  const uint32_t score_blocks = (max_samples + kScoreThreads - 1) / kScoreThreads + at + 2;
+  const uint32_t score_blocks = 2 * ((max_samples + std::min(kScoreThreads, NAVGPU_SCORE_TAB_THREADS) - 1) / std::min(kScoreThreads, NAVGPU_SCORE_TAB_THREADS)) + at + 2;
   if (max_axis != pl.max_axis || max_samples != pl.max_samples) {
     HIP_TRY(waitStream(f->stream));
     f->release(pl.axis_samples);

@@ -2048,6 +2048,13 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     t_row_base = gi * R;
     t_rows = min(max(cnt[2] - t_row_base, 0), R);
     t_li0 = ((int)blockIdx.x - gi * bpg) * (int)blockDim.x;
+    if (t_li0 >= t_rows * nxy) {  // no sample for this workgroup (the last group's share is rounded up to the largest): no image either
+      if (tid == 0) {
+        pl.part_cost[(size_t)inst * pl.score_blocks + blockIdx.x] = 1.0e300;
+        pl.part_index[(size_t)inst * pl.score_blocks + blockIdx.x] = 0x7FFFFFFF;
+      }
+      return;
+    }
   }
   if (TABLES && PREP != 2) {
     __syncthreads();  // s_axis, s_fp staged
@@ -2627,9 +2634,10 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   }
 }
 
-// three entry points over the same body: the table variant is compiled for 6 waves/SIMD (80 VGPRs)
-// in 512-thread workgroups (3 per CU by LDS => 24 waves/CU; measured 2.39 vs 2.59 ms at 256 threads)
-constexpr int kScoreThreadsTab = 512;
+// three entry points over the same body: the table variant is compiled for 6 waves/SIMD (80 VGPRs) in 256-thread
+// workgroups whose image (window + screens + the v_theta rows of their row group) stays below 26 KB: 6 per CU = 24 waves
+constexpr int kScoreThreadsTab = NAVGPU_SCORE_TAB_THREADS;
+constexpr int kScorePrepThreads = 512;  // the workgroup that builds a robot's image
 template <int CHUNK>
 __global__ __launch_bounds__(kScoreThreadsTab, 6) void k_score_tab(PlannerDev pl, uint32_t first, const float* explicit_sample) {
   score_body<false, true, kScoreThreadsTab, 2, CHUNK>(pl, first, explicit_sample);
@@ -2638,8 +2646,8 @@ template <int CHUNK>
 __global__ __launch_bounds__(kScoreThreads) void k_score_gen(PlannerDev pl, uint32_t first, const float* explicit_sample) {
   score_body<false, false, kScoreThreads, 2, CHUNK>(pl, first, explicit_sample);
 }
-__global__ __launch_bounds__(kScoreThreadsTab) void k_score_prep_tab(PlannerDev pl, uint32_t first) {
-  score_body<false, true, kScoreThreadsTab, 1>(pl, first, nullptr);
+__global__ __launch_bounds__(kScorePrepThreads) void k_score_prep_tab(PlannerDev pl, uint32_t first) {
+  score_body<false, true, kScorePrepThreads, 1>(pl, first, nullptr);
 }
 __global__ __launch_bounds__(kScoreThreads) void k_score_prep_gen(PlannerDev pl, uint32_t first) {
   score_body<false, false, kScoreThreads, 1>(pl, first, nullptr);
@@ -2664,7 +2672,7 @@ size_t score_table_lds_bytes(const PlannerDev& pl) {  // the tab_rows rows of on
 uint32_t score_table_rows(const PlannerDev& pl, uint32_t win) {
   const size_t wb = score_window_bytes(win), row = score_table_row_bytes(pl);
   if (row == 0 || wb + score_table_bytes(pl) + score_scratch_bytes((int)win) > 150u * 1024u) return 0;
-  for (size_t budget : {(size_t)52 * 1024, (size_t)78 * 1024}) {
+  for (size_t budget : {(size_t)NAVGPU_SCORE_TAB_LDS_KB * 1024, (size_t)52 * 1024, (size_t)78 * 1024}) {
     if (wb + 16 >= budget) continue;
     const size_t r = (budget - wb - 16) / row;
     if (r >= 1) return (uint32_t)std::min<size_t>(r, pl.tab_nth);
@@ -2694,7 +2702,7 @@ uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, c
     pl.tab_bytes = (uint32_t)score_table_bytes(pl);
     const size_t lds_prep = win_bytes + score_table_bytes(pl) + scratch;
     if (lds_prep > 48 * 1024) hipFuncSetAttribute((const void*)k_score_prep_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
-    hipLaunchKernelGGL(k_score_prep_tab, dim3(1, count), dim3(kScoreThreadsTab), lds_prep, s, pl, first);
+    hipLaunchKernelGGL(k_score_prep_tab, dim3(1, count), dim3(kScorePrepThreads), lds_prep, s, pl, first);
     pl.tab_bytes = (uint32_t)score_table_lds_bytes(pl);
     const size_t lds = win_bytes + score_table_lds_bytes(pl);
     // row groups x workgroups per group, for the largest (vx, vy) grid the configuration can produce
