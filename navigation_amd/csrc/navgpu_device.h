@@ -23,6 +23,9 @@ constexpr int kCareRows = 128, kCareWords = 4;  // bounded wavefronts: extent of
 #ifndef NAVGPU_SCORE_TAB_LDS_KB
 #define NAVGPU_SCORE_TAB_LDS_KB 26    // first LDS budget tried for a k_score_tab workgroup's image (window + screens + table rows)
 #endif
+#ifndef NAVGPU_SCORE_TAB_WAVES
+#define NAVGPU_SCORE_TAB_WAVES 6      // waves per SIMD k_score_tab is compiled for (6: 80 registers)
+#endif
 #ifndef NAVGPU_SCORE_THREADS
 #define NAVGPU_SCORE_THREADS 256
 #endif

@@ -2639,7 +2639,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
 constexpr int kScoreThreadsTab = NAVGPU_SCORE_TAB_THREADS;
 constexpr int kScorePrepThreads = 512;  // the workgroup that builds a robot's image
 template <int CHUNK>
-__global__ __launch_bounds__(kScoreThreadsTab, 6) void k_score_tab(PlannerDev pl, uint32_t first, const float* explicit_sample) {
+__global__ __launch_bounds__(kScoreThreadsTab, NAVGPU_SCORE_TAB_WAVES) void k_score_tab(PlannerDev pl, uint32_t first, const float* explicit_sample) {
   score_body<false, true, kScoreThreadsTab, 2, CHUNK>(pl, first, explicit_sample);
 }
 template <int CHUNK>
