@@ -29,3 +29,10 @@ p2 = (a[:, 5] - t0) / 100.0
 z = (a[:, 6] - t0) / 100.0; sd = (a[:, 7] - t0) / 100.0; pp = (a[:, 8] - t0) / 100.0
 print("zero LDS", (z - st).mean(), "seeds", (sd - z).mean(), "free words + init", (p1 - sd).mean(), "post-pass", (pp - p2).mean(), "decode", (en - pp).mean())
 print("prologue mean us", (p1 - st).mean(), "levels mean us", (p2 - p1).mean(), "post+decode mean us", (en - p2).mean())
+for y in range(3):
+    s = slice(256 * y, 256 * y + 256)
+    print("grid", y, "prologue %.1f (zero %.1f seeds %.1f init %.1f)  levels %.1f (%.3f us/level)  post+decode %.1f" %
+          ((p1 - st)[s].mean(), (z - st)[s].mean(), (sd - z)[s].mean(), (p1 - sd)[s].mean(), (p2 - p1)[s].mean(), ((p2 - p1)[s] / np.maximum(lv[s], 1)).mean(), (en - p2)[s].mean()))
+# how many items are in flight over time
+ts = np.linspace(0, en.max(), 42)
+print("in flight:", [int(((st <= t) & (en > t)).sum()) for t in ts])
