@@ -22,9 +22,9 @@ import csv, json, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
 # profiled regions of the library (navgpu_kernel_name) <- the device kernels they launch
 GROUPS = {"k_obstacle": ("k_obstacle",), "k_merge": ("k_merge",), "k_inflate": ("k_inflate", "k_inflate_bits"),
-          "k_bfs": ("k_bfs", "k_bfs_wave", "k_bfs_global", "k_free_bits"), "k_score": ("k_score_tab", "k_score_gen", "k_score_prep_tab", "k_score_prep_gen"),
+          "k_bfs": ("k_bfs", "k_bfs_wave", "k_bfs_big", "k_bfs_global", "k_free_bits"), "k_score": ("k_score_tab", "k_score_gen", "k_score_prep_tab", "k_score_prep_gen"),
           "k_select": ("k_select",)}
-MAIN = {"k_score": ("k_score_tab", "k_score_gen"), "k_bfs": ("k_bfs", "k_bfs_wave", "k_bfs_global")}
+MAIN = {"k_score": ("k_score_tab", "k_score_gen"), "k_bfs": ("k_bfs", "k_bfs_wave", "k_bfs_big", "k_bfs_global")}
 raw = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f"{out}/{tag}_pmc_{c.lower()}.csv")):
