@@ -256,7 +256,7 @@ def _inflated_instance(orc, n, idx, synth):
 
 
 def _check_planner(nav, orc, n, cfg_kw, n_inst=2, footprint=None, allow_unknown=1, unknown_frac=0.0, cycles=1, seed0=0,
-                   plan_len=None):
+                   plan_len=None, near_obstacles=0):
     from navigation_amd import synth
     N = L(nav)
     fp = synth.FOOTPRINT if footprint is None else footprint
@@ -268,6 +268,14 @@ def _check_planner(nav, orc, n, cfg_kw, n_inst=2, footprint=None, allow_unknown=
     insts = [_inflated_instance(orc, n, seed0 + i, synth) for i in range(n_inst)]
     rs = np.random.RandomState(99)
     for ins in insts:
+        if near_obstacles:  # lethal cells 0.35 - 1.2 m from the robot (inside the disc make_instance keeps clear): some samples collide
+            cx, cy = ins["pos"][0] / synth.RES, ins["pos"][1] / synth.RES
+            for _ in range(near_obstacles):
+                a, d = rs.uniform(0, 2 * np.pi), rs.uniform(0.35, 1.2) / synth.RES
+                x, y = int(cx + d * np.cos(a)), int(cy + d * np.sin(a))
+                if 0 <= x < n and 0 <= y < n:
+                    ins["cells"][y, x] = LETHAL
+            ins["master"] = orc.inflate(ins["cells"], synth.RES, synth.INFLATION_RADIUS, synth.COST_SCALING, synth.inscribed_radius(synth.FOOTPRINT), exact=True)
         if unknown_frac:
             m = ins["master"]
             m[(rs.random_sample(m.shape) < unknown_frac) & (m == 0)] = NOINFO

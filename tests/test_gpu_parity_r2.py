@@ -694,3 +694,30 @@ def test_rolling_static_layer_cycles(nav, orc, use_maximum, track_unknown):
         # (use_maximum over a NO_INFORMATION default: the rolling branch's plain std::max keeps 255 everywhere, static_layer.cpp:328)
         assert use_maximum or ((m[0] == LETHAL).sum() > 50 and (not track_unknown or (m[0] == NOINFO).sum() > 50))
     fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# Differential fuzz: random planner configurations (limits, accelerations, sample counts, granularities, scales incl.
+# zero, use_dwa / discretize_by_time / sum_scores / allow_unknown, footprints, map sizes incl. non-multiples of 32,
+# plan lengths) through _check_planner: grids, sample velocities, accept masks, failure codes, costs, winner, trajectory.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", list(range(48)))
+def test_planner_random_configurations_vs_oracle(nav, orc, seed):
+    from navigation_amd import synth
+    rs = np.random.RandomState(7000 + seed)
+    pick = lambda *v: v[rs.randint(len(v))]
+    max_vel_x = float(rs.uniform(0.2, 0.9))
+    cfg = dict(
+        max_vel_x=max_vel_x, min_vel_x=float(pick(0.0, -0.1, 0.05)), max_vel_y=float(pick(0.0, 0.1, 0.25)), min_vel_y=float(pick(0.0, -0.1, -0.25)),
+        max_trans_vel=float(max_vel_x * pick(1.0, 0.8, 1.5)), min_trans_vel=float(pick(0.0, 0.1, -1.0)),
+        max_rot_vel=float(rs.uniform(0.5, 1.5)), min_rot_vel=float(pick(0.0, 0.3, 0.4)),
+        acc_lim_x=float(rs.uniform(0.5, 3.0)), acc_lim_y=float(rs.uniform(0.5, 3.0)), acc_lim_theta=float(rs.uniform(1.0, 4.0)),
+        sim_time=float(pick(0.8, 1.3, 1.7, 2.0)), sim_granularity=float(pick(0.025, 0.05, 0.1)), angular_sim_granularity=float(pick(0.05, 0.1, 0.2)),
+        sim_period=float(pick(0.05, 0.1, 0.2)), path_distance_bias=float(pick(32.0, 0.0, 5.0)), goal_distance_bias=float(pick(24.0, 0.0, 40.0)),
+        occdist_scale=float(pick(0.01, 0.0, 0.2)), forward_point_distance=float(pick(0.325, 0.0, 0.6, -0.2)),
+        vx_samples=int(pick(1, 3, 6, 9)), vy_samples=int(pick(1, 4, 7)), vth_samples=int(pick(1, 5, 12, 20)),
+        use_dwa=int(pick(1, 1, 0)), discretize_by_time=int(pick(0, 1)), sum_scores=int(pick(0, 0, 1)))
+    n = int(pick(96, 120, 157, 200, 233))
+    fp = pick(synth.FOOTPRINT, synth.FOOTPRINT5, np.array([[0.15, 0.0], [-0.1, 0.12], [-0.1, -0.12]]))
+    _check_planner(nav, orc, n, cfg, n_inst=2, footprint=fp, allow_unknown=int(pick(0, 1)), unknown_frac=float(pick(0.0, 0.01)), cycles=2,
+                   seed0=500 + 3 * seed, plan_len=int(pick(200, 60, 25)), near_obstacles=int(pick(0, 3, 8)))
