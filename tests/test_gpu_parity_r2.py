@@ -721,3 +721,89 @@ def test_planner_random_configurations_vs_oracle(nav, orc, seed):
     fp = pick(synth.FOOTPRINT, synth.FOOTPRINT5, np.array([[0.15, 0.0], [-0.1, 0.12], [-0.1, -0.12]]))
     _check_planner(nav, orc, n, cfg, n_inst=2, footprint=fp, allow_unknown=int(pick(0, 1)), unknown_frac=float(pick(0.0, 0.01)), cycles=2,
                    seed0=500 + 3 * seed, plan_len=int(pick(200, 60, 25)), near_obstacles=int(pick(0, 3, 8)))
+
+
+# ----------------------------------------------------------------------------------------------
+# Differential fuzz of the layered costmap: random layer parameters (2-D / voxel obstacle layer, combination method,
+# footprint clearing, unknown tracking, ranges, height limits, voxel geometry and thresholds, static layer, rolling
+# window, inflation geometry, map sizes), 4 cycles of moving robots with one or two sensors (marking-only and
+# clearing-only observations included): master, layer grid, voxel columns, box and origin against the oracle.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_layered_costmap_random_configurations_vs_oracle(nav, orc, seed):
+    from navigation_amd import synth
+    N = L(nav)
+    rs = np.random.RandomState(9100 + seed)
+    pick = lambda *v: v[rs.randint(len(v))]
+    n = int(pick(96, 130, 160, 211))
+    nI = 2
+    voxel, rolling, track_unknown = bool(pick(0, 1)), bool(pick(0, 1)), bool(pick(0, 1))
+    with_static = bool(pick(0, 1)) and not rolling
+    fp = pick(synth.FOOTPRINT, synth.FOOTPRINT5)
+    insc = synth.inscribed_radius(fp)
+    comb, fpc = int(pick(1, 1, 0)), bool(pick(1, 1, 0))
+    max_h = float(pick(2.0, 1.0, 0.6))
+    vox = dict(z_voxels=int(pick(10, 16, 5)), origin_z=float(pick(0.0, -0.1)), z_resolution=float(pick(0.2, 0.1, 0.25)),
+               unknown_threshold=int(pick(15, 4, 0)), mark_threshold=int(pick(0, 0, 1)))
+    infl_r, infl_k = float(pick(0.55, 0.3, 0.7)), float(pick(10.0, 3.0))
+    obs_range, ray_range = float(pick(2.5, 1.5, 4.0)), float(pick(3.0, 2.0, 5.0))
+    layers = (N.LAYER_VOXEL if voxel else N.LAYER_OBSTACLE) | N.LAYER_INFLATION | (N.LAYER_STATIC if with_static else 0)
+    fl = nav.Fleet(nI, n, n, synth.RES, layers=layers, track_unknown=track_unknown, max_points=1440, max_observations=2, rolling_window=rolling)
+    fl.configure_obstacle(combination_method=comb, footprint_clearing_enabled=fpc, max_obstacle_height=max_h, **vox)
+    fl.set_footprint(fp)
+    fl.configure_inflation(infl_r, infl_k, insc)
+    world = synth.make_instance(400, 900 + seed)
+    occ = np.where(world["cells"][:n, :n] == 254, 100, 0).astype(np.int8)
+    occ[rs.random_sample(occ.shape) < 0.02] = -1
+    oracles = []
+    for i in range(nI):
+        o = orc.LayeredCostmap(track_unknown)
+        o.resize(n, n, synth.RES, 0, 0)
+        o.set_rolling(rolling)
+        o.set_footprint(fp)
+        if with_static:
+            fl.add_static_map(occ, first=i, count=1, track_unknown_space=track_unknown)
+            o.add_static(occ, res=synth.RES, track_unknown_space=track_unknown)
+        if voxel:
+            o.add_voxel(combination_method=comb, footprint_clearing=fpc, max_obstacle_height=max_h, **vox)
+        else:
+            o.add_obstacle(combination_method=comb, footprint_clearing=fpc, max_obstacle_height=max_h)
+        o.add_inflation(infl_r, infl_k, exact=True)
+        o.set_footprint(fp)
+        oracles.append(o)
+    half = n * synth.RES / 2
+    starts = rs.uniform(half - 0.5, half + 0.5, (nI, 2))
+    two_sensors = bool(pick(0, 1))
+    for cyc in range(4):
+        poses, obs = [], []
+        for i in range(nI):
+            x = starts[i, 0] + (0.33 * cyc * (1 if i == 0 else -0.6) if rolling else 0.05 * cyc)
+            y = starts[i, 1] + (0.19 * cyc if rolling else -0.04 * cyc)
+            yaw = 0.4 * cyc - 0.7 * i
+            inst = dict(world)
+            inst["pos"] = np.array([x, y, yaw], np.float32)
+            pts = synth.laser_scan(inst, cyc, max_range=4.0, z=0.3, z_jitter=1.2 if voxel else None)
+            if cyc == 1:
+                pts[::9, 2] = max_h + 0.3  # above max_obstacle_height
+            org = (float(x), float(y), 0.3 + 0.1 * cyc)
+            poses.append([float(x), float(y), float(yaw)])
+            kinds = [dict(marking=True, clearing=True)] if not two_sensors else [dict(marking=True, clearing=False), dict(marking=False, clearing=True)]
+            oracles[i].clear_observations()
+            for kk, kind in enumerate(kinds):
+                p_k = pts if kk == 0 else pts[::2].copy()
+                obs.append(dict(instance=i, points=p_k, origin=org, obstacle_range=obs_range, raytrace_range=ray_range, **kind))
+                oracles[i].add_observation(p_k, origin=org, obstacle_range=obs_range, raytrace_range=ray_range, **kind)
+            oracles[i].update_map(*poses[-1])
+        fl.stage_observations(poses, obs)
+        fl.update_map()
+        m, ol, b, org_g = fl.master(), fl.download(N.GRID_OBSTACLE), fl.bounds(), fl.origins()
+        vx = fl.download(N.GRID_VOXEL) if voxel else None
+        for i in range(nI):
+            tag = (seed, cyc, i, dict(voxel=voxel, rolling=rolling, static=with_static, unknown=track_unknown, comb=comb))
+            assert np.array_equal(org_g[i], oracles[i].origin()), ("origin",) + tag
+            assert np.array_equal(b[i], oracles[i].bounds()), ("box",) + tag
+            assert np.array_equal(ol[i], oracles[i].layer(2)), ("layer",) + tag
+            if voxel:
+                assert np.array_equal(vx[i], oracles[i].voxels()), ("voxels",) + tag
+            assert np.array_equal(m[i], oracles[i].master()), ("master",) + tag
+    fl.close()
