@@ -577,7 +577,10 @@ typedef struct {
  * The cost bytes are those of navgpu_navfn_set_costmap with cost_mode 0 (the costmap itself: getCost translates on the fly).
  * starts_xy / goals_xy = count x {x, y} MAP coordinates as makePlan computes them (the cell index, or (w - origin) / resolution
  * - 0.5 without old_navfn_behavior); goal_cells_xy = count x {goal_x_i, goal_y_i}.  navgpu_navfn_path then returns the
- * traceback's own point list (goal first; getPlanFromPotential reverses it), navgpu_navfn_potential the potential array. */
+ * traceback's own point list (goal first; getPlanFromPotential reverses it), navgpu_navfn_potential the potential array.
+ * Limits: starts closer than 2 cells and goals closer than 1 cell to the map border are rejected (the reference reads
+ * outside its arrays there); a traceback longer than max(nx * ny / 2, 4 nx) + 4 points - the reference allows 4 nx ny -
+ * reports found = 0. */
 int navgpu_global_planner_plan(navgpu_navfn* nav, uint32_t first, uint32_t count, const navgpu_global_planner_params* params,
                                const double* starts_xy, const double* goals_xy, const int32_t* goal_cells_xy, navgpu_navfn_result* results);
 
