@@ -319,6 +319,12 @@ int navgpu_planner_cycle(navgpu_fleet* fleet, uint32_t first, uint32_t count);
  * stop-and-rotate controller keeps using them across cycles).  enable = 0: every cycle searches the whole grid, as
  * the reference does.  Planner results are identical either way. */
 int navgpu_planner_set_bounded_map_grids(navgpu_fleet* fleet, int32_t enable);
+/* replaces: the MapGridCostFunction constructor arguments DWAPlanner never passes (map_grid_cost_function.h:64-69,
+ * map_grid_cost_function.cpp:42-53, 75-129): aggregationType (0 Last - what DWAPlanner's four critics use -, 1 Sum,
+ * 2 Product) and yshift (metres, sideways) of one critic: 0 path_costs_, 1 goal_costs_, 2 goal_front_costs_,
+ * 3 alignment_costs_.  xshift stays DWAPlanner's (forward_point_distance for 2 and 3).  With any option set the scoring
+ * launches take a general per-point step (no screen, no heading tables) and the wavefronts cover the whole map. */
+int navgpu_planner_set_map_grid_options(navgpu_fleet* fleet, int32_t critic, int32_t aggregation, double yshift);
 /* introspection: the number of wavefront levels the last cycle ran for the path / goal / goal_front grid of each instance
  * (levels = count x 3).  A whole-grid search runs until nothing new is reached, a bounded one stops earlier. */
 int navgpu_planner_wavefront_levels(navgpu_fleet* fleet, uint32_t first, uint32_t count, uint32_t* levels);

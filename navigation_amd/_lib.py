@@ -222,6 +222,7 @@ SYMBOLS = [
     ("navgpu_planner_stage_poses", C.c_int, [vp, u32, u32, vp, vp]),
     ("navgpu_planner_cycle", C.c_int, [vp, u32, u32]),
     ("navgpu_planner_set_bounded_map_grids", C.c_int, [vp, C.c_int32]),
+    ("navgpu_planner_set_map_grid_options", C.c_int, [vp, C.c_int32, C.c_int32, C.c_double]),
     ("navgpu_planner_wavefront_levels", C.c_int, [vp, u32, u32, vp]),
     ("navgpu_planner_wavefront_boxes", C.c_int, [vp, u32, u32, vp]),
     ("navgpu_planner_results", C.c_int, [vp, u32, u32, vp]),

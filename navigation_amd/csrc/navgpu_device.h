@@ -140,6 +140,11 @@ struct PlannerDev {
   uint32_t fp_rcells;         // Chebyshev radius (cells) that contains every footprint cell around the centre cell
   uint32_t fp_chunk;          // cells of the longest footprint edge (+1): picks the k_score<CHUNK> instantiation
   uint32_t use_tables, tab_steps, tab_nfp, tab_nth;
+  // MapGridCostFunction options beyond DWAPlanner's own wiring (navgpu_planner_set_map_grid_options), indexed
+  // 0 path, 1 goal, 2 goal_front, 3 alignment: aggregation 0 Last | 1 Sum | 2 Product, sideways shift in metres
+  int32_t mg_agg[4];
+  double mg_yshift[4];
+  int32_t mg_generic;         // any of them set: the scoring launches take the general step (score_body<AGG>)
   uint32_t tab_rows;          // v_theta rows per row group = rows of the tables a k_score_tab workgroup keeps in LDS
   uint32_t tab_bytes;         // score_table_bytes(): the tables' share of the LDS image (0 without tables)
   double tab_dt;              // sim_time / tab_steps

@@ -840,6 +840,7 @@ static double reachMetres(const navgpu_dwa_config& c, const float vel[3], const 
 }
 static uint32_t bfsReachCells(const navgpu_fleet* f, const navgpu_robot_state& s, double goal_x, double goal_y) {
   if (!f->bounded_grids || !bfs_bounded_applies(f->pl)) return 0;
+  if (f->pl.mg_generic) return 0;  // (a sideways-shifted look-up leaves the box the reach is derived for: whole grids)
   const double reach = reachMetres(f->pl.cfg, s.vel, nullptr);
   const double cells = ceil(reach / f->pl.res) + kBoxMarginCells;
   if (!(cells < 32768.0)) return 0;
@@ -911,6 +912,16 @@ static int restageReach(navgpu_fleet* f) {
 int navgpu_planner_set_bounded_map_grids(navgpu_fleet* f, int32_t enable) {
   if (!f) return NAVGPU_ERR_INVALID;
   f->bounded_grids = enable != 0;
+  return restageReach(f);
+}
+int navgpu_planner_set_map_grid_options(navgpu_fleet* f, int32_t critic, int32_t aggregation, double yshift) {
+  if (!f || critic < 0 || critic > 3 || aggregation < 0 || aggregation > 2 || !std::isfinite(yshift)) return NAVGPU_ERR_INVALID;
+  PlannerDev& pl = f->pl;
+  pl.mg_agg[critic] = aggregation;
+  pl.mg_yshift[critic] = yshift;
+  pl.mg_generic = 0;
+  for (int k = 0; k < 4; ++k)
+    if (pl.mg_agg[k] != 0 || pl.mg_yshift[k] != 0.0) pl.mg_generic = 1;
   return restageReach(f);
 }
 int navgpu_planner_wavefront_levels(navgpu_fleet* f, uint32_t first, uint32_t count, uint32_t* levels) {

@@ -1872,7 +1872,10 @@ __host__ __device__ inline size_t score_scratch_bytes(int win) { return score_bi
 // a robot all use the same one: 74 of them in the 32x32x16 configuration)
 // CHUNK: cells of a footprint edge fetched per LDS round trip; the launcher picks the smallest of 6 / 9 / 12 / 16 that
 // covers the longest edge (a 0.4 m square at 0.05 m: 9), longer edges take several chunks
-template <bool EXPLICIT, bool TABLES, int THREADS, int PREP = 0, int CHUNK = 12>
+// AGG: the MapGridCostFunction options DWAPlanner itself never sets - aggregation Sum / Product and a sideways shift
+// (map_grid_cost_function.cpp:75-129) - as navgpu_planner_set_map_grid_options configures them: every live critic looks
+// its own cell up at every point (no screen, no shared cell); the product kernels are compiled without it.
+template <bool EXPLICIT, bool TABLES, int THREADS, int PREP = 0, int CHUNK = 12, bool AGG = false>
 __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first, const float* explicit_sample) {
   extern __shared__ __align__(16) uint8_t s_dyn[];
   uint8_t* s_win = s_dyn;
@@ -2258,6 +2261,12 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       const bool en_obs = sc_obs != 0, en_gf = sc_gf != 0, en_al = sc_al != 0, en_path = sc_path != 0, en_goal = sc_goal != 0;
       double fail_code = 0;  // code of critic `first_fail`: the only one scoreTrajectory's in-order sum can return
       double v_obs = 0, v_gf = 0, v_al = 0, v_path = 0, v_goal = 0;
+      if constexpr (AGG) {  // `if (aggregationType_ == Product) cost = 1.0` (:77-79)
+        if (pl.mg_agg[0] == 2) v_path = 1.0;
+        if (pl.mg_agg[1] == 2) v_goal = 1.0;
+        if (pl.mg_agg[2] == 2) v_gf = 1.0;
+        if (pl.mg_agg[3] == 2) v_al = 1.0;
+      }
       int first_fail = 6;  // order index of the earliest critic that failed (1..5), 6 = none
       const bool allow_unknown = c.allow_unknown != 0;
       const double fpd = c.forward_point_distance;
@@ -2277,7 +2286,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       const uint32_t fwd_lo = (en_gf || en_al) ? fwd_margin : 0u, fwd_nx = g.nx - 2u * fwd_lo, fwd_ny = g.ny - 2u * fwd_lo;
       // which of the four screens count: obstacle (dilated "not free" with sum_scores, else dilated "can fail"), path, goal
       const bool scr_sum = c.sum_scores != 0;  // the obstacle screen: dilated "not free" with sum_scores, else dilated "can fail"
-      const bool screen_on = fwd_screen && (nfp >= 3 || !en_obs);
+      const bool screen_on = !AGG && fwd_screen && (nfp >= 3 || !en_obs);
       if (osc_fail) {
         total = -5.0;
       } else {
@@ -2481,6 +2490,46 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
               v_obs = c.sum_scores ? v_obs + occ : occ;
             }
           }
+          if constexpr (AGG) {
+            // the general MapGridCostFunction step, critic by critic in the order DWAPlanner lists them
+            auto critic = [&](bool en, int order, const uint32_t* grid, double xs, double ys, bool stop_on_failure, int agg, double& v) {
+              if (!(en && order < first_fail)) return;
+              double sx = x, sy = y;
+              if (xs != 0.0) {
+                sx = sx + xs * cs;
+                sy = sy + xs * sn;
+              }
+              if (ys != 0.0) {
+                double s2, c2;
+                sincos(th + M_PI_2, &s2, &c2);
+                sx = sx + ys * c2;
+                sy = sy + ys * s2;
+              }
+              uint32_t ux, uy;
+              if (!w2m(sx, sy, ux, uy)) {
+                fail_code = -4.0;
+                first_fail = order;
+                return;
+              }
+              const uint32_t d = grid[uy * g.nx + ux];
+              if (stop_on_failure && (d == N_obst || d == N_unreach)) {
+                fail_code = d == N_obst ? -3.0 : -2.0;
+                first_fail = order;
+                return;
+              }
+              const double gd = (double)d;
+              if (agg == 0)
+                v = gd;
+              else if (agg == 1)
+                v += gd;
+              else if (v > 0)
+                v *= gd;
+            };
+            critic(en_gf, 2, dfront, fpd, pl.mg_yshift[2], false, pl.mg_agg[2], v_gf);
+            critic(en_al, 3, dpath, fpd, pl.mg_yshift[3], false, pl.mg_agg[3], v_al);
+            critic(en_path, 4, dpath, 0.0, pl.mg_yshift[0], true, pl.mg_agg[0], v_path);
+            critic(en_goal, 5, dgoal, 0.0, pl.mg_yshift[1], true, pl.mg_agg[1], v_goal);
+          } else {
           if ((en_path && 4 < first_fail) || (en_goal && 5 < first_fail)) {
             if (!ok_c) {
               if (en_path && 4 < first_fail) {
@@ -2537,6 +2586,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
               if (en_al && 3 < first_fail) v_al = dpath[cell];
             }
           }
+          }  // !AGG
           }  // !screened
           // ---- advance (computeNewPositions :253-260): fp64 on fp32 state, rounded back to fp32
           if (continued) {
@@ -2655,6 +2705,13 @@ __global__ __launch_bounds__(kScoreThreads) void k_score_prep_gen(PlannerDev pl,
 __global__ __launch_bounds__(kScoreThreads) void k_score_explicit(PlannerDev pl, uint32_t first, const float* explicit_sample) {
   score_body<true, false, kScoreThreads>(pl, first, explicit_sample);
 }
+// the same two entry points with the general MapGridCostFunction step (aggregation Sum / Product, sideways shift)
+__global__ __launch_bounds__(kScoreThreads) void k_score_gen_agg(PlannerDev pl, uint32_t first, const float* explicit_sample) {
+  score_body<false, false, kScoreThreads, 2, 16, true>(pl, first, explicit_sample);
+}
+__global__ __launch_bounds__(kScoreThreads) void k_score_explicit_agg(PlannerDev pl, uint32_t first, const float* explicit_sample) {
+  score_body<true, false, kScoreThreads, 0, 12, true>(pl, first, explicit_sample);
+}
 
 size_t score_window_bytes(uint32_t win) {  // costmap window + the four per-cell screens
   return (((size_t)win * win + 15) & ~(size_t)15) + score_bits_bytes((int)win);
@@ -2692,10 +2749,16 @@ uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, c
   pl.tab_bytes = 0;
   if (explicit_sample) {
     const size_t lds_x = win_bytes + scratch;
+    if (pl.mg_generic) {
+      if (lds_x > 48 * 1024) hipFuncSetAttribute((const void*)k_score_explicit_agg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x);
+      hipLaunchKernelGGL(k_score_explicit_agg, dim3(1, count), dim3(kScoreThreads), lds_x, s, pl, first, explicit_sample);
+      return 1;
+    }
     if (lds_x > 48 * 1024) hipFuncSetAttribute((const void*)k_score_explicit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x);
     hipLaunchKernelGGL(k_score_explicit, dim3(1, count), dim3(kScoreThreads), lds_x, s, pl, first, explicit_sample);
     return 1;
   }
+  if (pl.mg_generic) pl.use_tables = 0;  // (the general step has no table variant)
   pl.prep_bytes = (uint32_t)score_prep_bytes(pl);  // (after the debug override of use_tables)
   if (pl.use_tables) {
     // the prep launch builds all rows (its LDS holds the whole image); a scoring workgroup holds one row group
@@ -2727,6 +2790,11 @@ uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, c
   {                                                                                                                            \
     if (win_bytes > 48 * 1024) hipFuncSetAttribute((const void*)k_score_gen<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes); \
     hipLaunchKernelGGL(k_score_gen<C>, dim3(gen_blocks, count), dim3(kScoreThreads), win_bytes, s, pl, first, explicit_sample);          \
+  }
+  if (pl.mg_generic) {
+    if (win_bytes > 48 * 1024) hipFuncSetAttribute((const void*)k_score_gen_agg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes);
+    hipLaunchKernelGGL(k_score_gen_agg, dim3(gen_blocks, count), dim3(kScoreThreads), win_bytes, s, pl, first, explicit_sample);
+    return gen_blocks;
   }
   if (pl.fp_chunk <= 6) NAVGPU_SCORE_GEN(6)
   else if (pl.fp_chunk <= 9) NAVGPU_SCORE_GEN(9)

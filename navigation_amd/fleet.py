@@ -248,6 +248,14 @@ class Fleet:
         check(self.L.navgpu_planner_wavefront_boxes(self.h, first, count, _ptr(out)), "wavefront_boxes")
         return out
 
+    MAP_GRID_CRITICS = {"path": 0, "goal": 1, "goal_front": 2, "alignment": 3}
+    AGGREGATIONS = {"last": 0, "sum": 1, "product": 2}
+
+    def set_map_grid_options(self, critic, aggregation="last", yshift=0.0):
+        """MapGridCostFunction's aggregationType / yshift of one of DWAPlanner's four map-grid critics."""
+        check(self.L.navgpu_planner_set_map_grid_options(self.h, self.MAP_GRID_CRITICS[critic], self.AGGREGATIONS[aggregation], float(yshift)),
+              "set_map_grid_options")
+
     def set_bounded_map_grids(self, enable):
         """navgpu_planner_set_bounded_map_grids: wavefronts stop once the robot's box is settled (default on)."""
         check(self.L.navgpu_planner_set_bounded_map_grids(self.h, 1 if enable else 0), "set_bounded_map_grids")

@@ -432,6 +432,13 @@ void orc_dwa_set_costmap(void* h, const uint8_t* cells) {
   memcpy(p->grid.cells.data(), cells, p->grid.cells.size());
 }
 void orc_dwa_configure(void* h, const navgpu_dwa_config* c) { static_cast<PlannerHandle*>(h)->planner.reconfigure(toCfg(*c)); }
+// MapGridCritic options DWAPlanner never sets itself: critic 0 path, 1 goal, 2 goal_front, 3 alignment
+void orc_dwa_set_map_grid_options(void* h, int critic, int aggregation, double yshift) {
+  auto& p = static_cast<PlannerHandle*>(h)->planner;
+  MapGridCritic* c[4] = {&p.path, &p.goal, &p.goal_front, &p.alignment};
+  c[critic]->aggregation = aggregation;
+  c[critic]->yshift = yshift;
+}
 void orc_dwa_set_plan(void* h) { static_cast<PlannerHandle*>(h)->planner.setPlan(); }
 // updatePlanAndLocalCosts + findBestPath.  sample_* arrays optional (cap slots).
 int orc_dwa_cycle(void* h, const float* pos, const float* vel, const double* plan_xy, uint32_t n_plan, const double* fp_xy,

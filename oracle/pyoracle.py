@@ -137,6 +137,7 @@ def lib():
     sig("orc_dwa_set_costmap", None, vp, u8p)
     sig("orc_dwa_configure", None, vp, C.POINTER(DwaConfig))
     sig("orc_dwa_set_plan", None, vp)
+    sig("orc_dwa_set_map_grid_options", None, vp, i, i, d)
     sig("orc_dwa_cycle", i, vp, f32p, f32p, f64p, u, f64p, u, C.POINTER(PlanResult), C.c_void_p, i,
         C.c_void_p, C.c_void_p, C.c_void_p, i)
     sig("orc_dwa_check_trajectory", i, vp, f32p, f32p, f32p)
@@ -438,6 +439,11 @@ class DwaPlanner:
 
     def set_plan(self):
         self.L.orc_dwa_set_plan(self.h)
+
+    def set_map_grid_options(self, critic, aggregation="last", yshift=0.0):
+        """MapGridCostFunction's aggregationType / yshift (map_grid_cost_function.cpp:42-53) of path | goal | goal_front | alignment."""
+        self.L.orc_dwa_set_map_grid_options(self.h, {"path": 0, "goal": 1, "goal_front": 2, "alignment": 3}[critic],
+                                            {"last": 0, "sum": 1, "product": 2}[aggregation], float(yshift))
 
     def cycle(self, pos, vel, plan, footprint, want_samples=True, traj_cap=4096):
         plan = _f64(plan).reshape(-1, 2)

@@ -256,7 +256,7 @@ def _inflated_instance(orc, n, idx, synth):
 
 
 def _check_planner(nav, orc, n, cfg_kw, n_inst=2, footprint=None, allow_unknown=1, unknown_frac=0.0, cycles=1, seed0=0,
-                   plan_len=None, near_obstacles=0):
+                   plan_len=None, near_obstacles=0, map_grid_options=()):
     from navigation_amd import synth
     N = L(nav)
     fp = synth.FOOTPRINT if footprint is None else footprint
@@ -281,6 +281,10 @@ def _check_planner(nav, orc, n, cfg_kw, n_inst=2, footprint=None, allow_unknown=
             m[(rs.random_sample(m.shape) < unknown_frac) & (m == 0)] = NOINFO
     fl.upload(N.GRID_MASTER, np.stack([i["master"] for i in insts]))
     planners = [orc.DwaPlanner(i["master"], synth.RES, 0.0, 0.0, ocfg) for i in insts]
+    for critic, agg, ysh in map_grid_options:  # MapGridCostFunction's aggregationType / yshift, beyond DWAPlanner's own wiring
+        fl.set_map_grid_options(critic, agg, ysh)
+        for p in planners:
+            p.set_map_grid_options(critic, agg, ysh)
     fl.set_plan()
     for p in planners:
         p.set_plan()

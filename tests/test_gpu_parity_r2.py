@@ -864,3 +864,64 @@ def test_trajectory_planner_random_configurations_vs_oracle(nav, orc, seed):
             pos[k, 2] += r.drive[2] * dt
             vel[k] = r.drive
     fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# MapGridCostFunction's aggregation types and yshift (map_grid_cost_function.cpp:42-53, 75-129): what DWAPlanner never
+# sets itself, configured per critic through navgpu_planner_set_map_grid_options; every sample's cost, failure code,
+# the winner and checkTrajectory against the oracle.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("options", [
+    [("path", "sum", 0.0)],
+    [("goal", "product", 0.0), ("path", "sum", 0.0)],
+    [("goal_front", "sum", 0.15), ("alignment", "last", -0.2)],
+    [("path", "last", 0.1), ("goal", "last", -0.1)],
+    [("path", "product", 0.05), ("goal", "sum", 0.0), ("goal_front", "product", 0.0), ("alignment", "sum", 0.3)],
+])
+def test_map_grid_aggregation_and_yshift(nav, orc, options):
+    for kw in (dict(discretize_by_time=1, sim_granularity=0.1, sim_time=1.5), dict()):
+        _check_planner(nav, orc, 160, dict(vx_samples=5, vy_samples=4, vth_samples=9, **kw), n_inst=2, cycles=2, seed0=40, near_obstacles=4,
+                       map_grid_options=options)
+    # setting everything back to Last / 0 returns to the usual kernels (and to bounded wavefronts)
+    from navigation_amd import synth
+    N = L(nav)
+    fl = nav.Fleet(1, 120, 120, synth.RES, layers=N.LAYER_OBSTACLE, keep_sample_costs=True)
+    fl.configure_planner(nav.DwaConfig(vx_samples=4, vy_samples=1, vth_samples=5))
+    fl.set_footprint(synth.FOOTPRINT)
+    ins = synth.make_instance(120, 77)
+    fl.upload(N.GRID_MASTER, ins["cells"][None])
+    fl.set_plan()
+    r0 = fl.find_best_path([ins["pos"]], [ins["vel"]], [ins["plan"]])[0]
+    c0 = fl.samples(0)[0].copy()
+    fl.set_map_grid_options("path", "sum", 0.1)
+    fl.find_best_path([ins["pos"]], [ins["vel"]], [ins["plan"]])
+    assert not np.array_equal(fl.samples(0)[0], c0)
+    fl.set_map_grid_options("path", "last", 0.0)
+    r1 = fl.find_best_path([ins["pos"]], [ins["vel"]], [ins["plan"]])[0]
+    assert (r1.best_index, r1.cost) == (r0.best_index, r0.cost) and np.array_equal(fl.samples(0)[0], c0)
+    # DWAPlanner::checkTrajectory with the options set: the general step in the explicit-sample kernel
+    from test_gpu_parity import _inflated_instance
+    ins2 = _inflated_instance(orc, 160, 4, synth)
+    m2 = ins2["master"]
+    m2[:, int(ins2["pos"][0] / synth.RES) + 12] = LETHAL
+    cfg2 = nav.DwaConfig(vx_samples=6, vy_samples=6, vth_samples=8, sim_time=1.0, sim_granularity=0.1, discretize_by_time=1)
+    f2 = nav.Fleet(1, 160, 160, synth.RES, layers=N.LAYER_OBSTACLE)
+    f2.configure_planner(cfg2)
+    f2.set_footprint(synth.FOOTPRINT)
+    f2.upload(N.GRID_MASTER, m2)
+    p2 = orc.DwaPlanner(m2, synth.RES, 0.0, 0.0, orc.DwaConfig(**cfg2.as_dict()))
+    for critic, agg, ysh in options:
+        f2.set_map_grid_options(critic, agg, ysh)
+        p2.set_map_grid_options(critic, agg, ysh)
+    pos2 = ins2["pos"].copy()
+    pos2[2] = 0.0
+    f2.find_best_path([pos2], [ins2["vel"]], [ins2["plan"]])
+    p2.cycle(pos2, ins2["vel"], ins2["plan"], synth.FOOTPRINT)
+    for vs in ([0.5, 0.0, 0.0], [0.1, 0.0, 0.5], [0.0, 0.0, 0.0], [0.3, 0.1, -0.4], [0.55, 0.0, 0.0]):
+        assert f2.check_trajectory(0, vs) == p2.check_trajectory(pos2, ins2["vel"], vs), vs
+    f2.close()
+    from navigation_amd._lib import NavgpuError, check
+    for bad in ((4, 0, 0.0), (0, 3, 0.0), (1, 0, float("nan"))):
+        with pytest.raises(NavgpuError):
+            check(fl.L.navgpu_planner_set_map_grid_options(fl.h, *bad), "set_map_grid_options")
+    fl.close()
