@@ -437,7 +437,8 @@ int navgpu_local_planner_get_plan(navgpu_fleet* fleet, uint32_t instance, double
  * state with acceleration-limited velocities, a different sample enumeration and a sequential, stateful
  * selection (in-place rotation / strafing / backing up with oscillation and escape flags).  The GPU rolls
  * out every candidate sample of createTrajectories; the host replays the reference's selection over the
- * per-sample results.  heading_scoring and simple_attractor (both default false) are not supported. */
+ * per-sample results.  heading_scoring (headingDiff's line-of-sight scan over the plan, :372-386) and simple_attractor
+ * (:310-315) are options of the same rollout. */
 typedef struct {
   double acc_lim_x, acc_lim_y, acc_lim_theta;
   double sim_time, sim_granularity, angular_sim_granularity;
@@ -446,11 +447,12 @@ typedef struct {
   double max_vel_x, min_vel_x, max_vel_th, min_vel_th, min_in_place_vel_th;
   double backup_vel;                              /* escape_vel */
   double sim_period;
+  double heading_scoring_timestep;                /* BaseLocalPlanner.cfg: 0.1 (TrajectoryPlannerROS's own param default: 0.8) */
   double y_vels[8];
   int32_t n_y_vels;
   int32_t vx_samples, vtheta_samples;
   int32_t holonomic_robot, dwa, allow_unknown;
-  int32_t heading_scoring, simple_attractor;      /* must be 0 */
+  int32_t heading_scoring, simple_attractor;
 } navgpu_tp_config;
 
 /* TrajectoryPlanner members that persist between cycles (trajectory_planner.h:290-300) */

@@ -113,7 +113,7 @@ class TpConfig(C.Structure):
         "acc_lim_x", "acc_lim_y", "acc_lim_theta", "sim_time", "sim_granularity", "angular_sim_granularity",
         "pdist_scale", "gdist_scale", "occdist_scale", "heading_lookahead", "oscillation_reset_dist",
         "escape_reset_dist", "escape_reset_theta", "max_vel_x", "min_vel_x", "max_vel_th", "min_vel_th",
-        "min_in_place_vel_th", "backup_vel", "sim_period")] + [("y_vels", C.c_double * 8)] + [
+        "min_in_place_vel_th", "backup_vel", "sim_period", "heading_scoring_timestep")] + [("y_vels", C.c_double * 8)] + [
         (n, C.c_int32) for n in ("n_y_vels", "vx_samples", "vtheta_samples", "holonomic_robot", "dwa", "allow_unknown",
                                  "heading_scoring", "simple_attractor")]
 
@@ -121,7 +121,8 @@ class TpConfig(C.Structure):
                     angular_sim_granularity=0.025, pdist_scale=0.6, gdist_scale=0.8, occdist_scale=0.01,
                     heading_lookahead=0.325, oscillation_reset_dist=0.05, escape_reset_dist=0.10,
                     escape_reset_theta=1.5707963267948966, max_vel_x=0.55, min_vel_x=0.0, max_vel_th=1.0, min_vel_th=-1.0,
-                    min_in_place_vel_th=0.4, backup_vel=-0.1, sim_period=0.05, y_vels=(-0.3, -0.1, 0.1, 0.3),
+                    min_in_place_vel_th=0.4, backup_vel=-0.1, sim_period=0.05, heading_scoring_timestep=0.1,
+                    y_vels=(-0.3, -0.1, 0.1, 0.3),
                     vx_samples=20, vtheta_samples=20, holonomic_robot=1, dwa=0, allow_unknown=1, heading_scoring=0,
                     simple_attractor=0)
 

@@ -131,10 +131,6 @@ static uint32_t tpMaxSamples(const navgpu_tp_config& c) {
 int navgpu_tp_configure(navgpu_fleet* f, const navgpu_tp_config* cfg_in) {
   if (!f || !cfg_in) return NAVGPU_ERR_INVALID;
   navgpu_tp_config c = *cfg_in;
-  if (c.heading_scoring || c.simple_attractor) {
-    g_last_error = "navgpu_tp_configure: heading_scoring / simple_attractor are not supported";
-    return NAVGPU_ERR_INVALID;
-  }
   if (c.n_y_vels < 0 || c.n_y_vels > 8 || !(c.sim_time > 0) || !(c.sim_granularity > 0) || !(c.angular_sim_granularity > 0))
     return NAVGPU_ERR_INVALID;
   if (c.vx_samples <= 0) c.vx_samples = 1;          // trajectory_planner.cpp:98-107
@@ -144,7 +140,8 @@ int navgpu_tp_configure(navgpu_fleet* f, const navgpu_tp_config* cfg_in) {
   for (int i = 0; i < c.n_y_vels; ++i) ymax = std::max(ymax, fabs(c.y_vels[i]));
   const double vxmax = std::max(std::max(fabs(c.max_vel_x), fabs(c.min_vel_x)), std::max(fabs(c.backup_vel), 0.1));
   const double wmax = std::max(std::max(fabs(c.max_vel_th), fabs(c.min_vel_th)), fabs(c.min_in_place_vel_th));
-  const double steps = std::max(hypot(vxmax, ymax) * c.sim_time / c.sim_granularity, wmax / c.angular_sim_granularity) + 1.5;
+  const double steps = (c.heading_scoring ? c.sim_time / c.sim_granularity  // (heading scoring: int(sim_time / sim_granularity + 0.5) steps, :240-244)
+                                          : std::max(hypot(vxmax, ymax) * c.sim_time / c.sim_granularity, wmax / c.angular_sim_granularity)) + 1.5;
   if (steps > (double)f->pl.max_sim_steps) {
     g_last_error = "navgpu_tp_configure: trajectories need more points than max_sim_steps";
     return NAVGPU_ERR_CAPACITY;
@@ -255,6 +252,10 @@ int navgpu_tp_find_best_path(navgpu_fleet* f, uint32_t first, uint32_t count, co
   for (uint32_t k = 0; k < count; ++k) {
     const uint32_t inst = first + k;
     navgpu_fleet::TpHost& h = f->tph[inst];
+    if (c.simple_attractor && h.plan.empty()) {  // the reference indexes global_plan_[size() - 1] (:311-314)
+      g_last_error = "navgpu_tp_find_best_path: simple_attractor needs a plan";
+      return NAVGPU_ERR_STATE;
+    }
     const float* pos = states[k].pos;
     const float* vel = states[k].vel;
     tpFootprintCells(pos, &f->h_fp_spec[(size_t)inst * kMaxFootprint * 2], f->h_fp_n[inst], f->h_origin[2 * inst],
@@ -547,6 +548,7 @@ int navgpu_tp_score_trajectory(navgpu_fleet* f, uint32_t instance, const double 
   if (!f || !pose || !vel || !vs || !cost || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
   if (!f->tp_configured) return NAVGPU_ERR_STATE;
   TpDev& tp = f->tp;
+  if (tp.cfg.simple_attractor && f->tph[instance].plan.empty()) return NAVGPU_ERR_STATE;
   const uint32_t ms = tp.max_samples;
   const double start[6] = {pose[0], pose[1], pose[2], vel[0], vel[1], vel[2]};
   const uint32_t one = 1;

@@ -76,6 +76,64 @@ struct TpWorld {
     }
     return line_cost;
   }
+  // TrajectoryPlanner::pointCost / lineCost (trajectory_planner.cpp:388-472): the planner's own ray walk for headingDiff;
+  // unlike CostmapModel::pointCost it fails on INSCRIBED cells too
+  __device__ double planLineCost(int x0, int x1, int y0, int y1) const {
+    int deltax = x1 - x0, deltay = y1 - y0;
+    deltax = deltax < 0 ? -deltax : deltax;
+    deltay = deltay < 0 ? -deltay : deltay;
+    int x = x0, y = y0;
+    int xinc1, xinc2, yinc1, yinc2, den, num, numadd, numpixels;
+    xinc1 = xinc2 = (x1 >= x0) ? 1 : -1;
+    yinc1 = yinc2 = (y1 >= y0) ? 1 : -1;
+    if (deltax >= deltay) {
+      xinc1 = 0;
+      yinc2 = 0;
+      den = deltax;
+      num = deltax / 2;
+      numadd = deltay;
+      numpixels = deltax;
+    } else {
+      xinc2 = 0;
+      yinc1 = 0;
+      den = deltay;
+      num = deltay / 2;
+      numadd = deltax;
+      numpixels = deltay;
+    }
+    double line_cost = 0.0;
+    for (int curpixel = 0; curpixel <= numpixels; ++curpixel) {
+      const uint8_t cost = master[(uint32_t)y * g.nx + (uint32_t)x];
+      if (cost == kLethal || cost == kInscribed || (cost == kNoInfo && !allow_unknown)) return -1;
+      if (line_cost < (double)cost) line_cost = (double)cost;
+      num += numadd;
+      if (num >= den) {
+        num -= den;
+        x += xinc1;
+        y += yinc1;
+      }
+      x += xinc2;
+      y += yinc2;
+    }
+    return line_cost;
+  }
+  // TrajectoryPlanner::headingDiff (:372-386): the farthest plan pose with a clear line of sight from the robot's cell
+  __device__ double headingDiff(int cell_x, int cell_y, double x, double y, double heading, const double* plan, uint32_t n_plan) const {
+    for (int i = (int)n_plan - 1; i >= 0; --i) {
+      uint32_t gx_c, gy_c;
+      if (worldToMap(g, plan[2 * i], plan[2 * i + 1], gx_c, gy_c)) {
+        if (planLineCost(cell_x, (int)gx_c, cell_y, (int)gy_c) >= 0) {
+          const double gx = g.ox + (gx_c + 0.5) * g.res, gy = g.oy + (gy_c + 0.5) * g.res;  // mapToWorld
+          // angles::shortest_angular_distance(heading, atan2(..)) = normalize_angle(to - from), fmod form
+          const double a = atan2(gy - y, gx - x) - heading;
+          double r = fmod(fmod(a, 2.0 * M_PI) + 2.0 * M_PI, 2.0 * M_PI);
+          if (r > M_PI) r -= 2.0 * M_PI;
+          return fabs(r);
+        }
+      }
+    }
+    return 1.7976931348623157e308;  // DBL_MAX
+  }
   // WorldModel::footprintCost(x, y, theta, spec) (world_model.h:65-86) + CostmapModel::footprintCost
   __device__ double footprintCost(double x, double y, double theta, const double* spec, uint32_t nfp) const {
     const double cos_th = cos(theta), sin_th = sin(theta);
@@ -147,9 +205,16 @@ __global__ __launch_bounds__(128) void k_tp_rollout(PlannerDev pl, TpDev tp, uin
   double x_i = st[0], y_i = st[1], theta_i = st[2];
   double vx_i = st[3], vy_i = st[4], vtheta_i = st[5];
   const double vmag = hypot(vx_samp, vy_samp);
-  int num_steps = int(fmax((vmag * c.sim_time) / c.sim_granularity, fabs(vtheta_samp) / c.angular_sim_granularity) + 0.5);
+  int num_steps;
+  if (!c.heading_scoring)
+    num_steps = int(fmax((vmag * c.sim_time) / c.sim_granularity, fabs(vtheta_samp) / c.angular_sim_granularity) + 0.5);
+  else
+    num_steps = int(c.sim_time / c.sim_granularity + 0.5);
   if (num_steps == 0) num_steps = 1;
   const double dt = c.sim_time / num_steps;
+  double time = 0.0, heading_diff = 0.0;
+  const double* plan = pl.plan + (size_t)inst * pl.max_plan * 2;
+  const uint32_t n_plan = pl.plan_count[inst];
   const double impossible_cost = (double)pl.cells;  // path_map_.obstacleCosts()
   double path_dist = 0.0, goal_dist = 0.0, occ_cost = 0.0;
   double cost = -1.0;
@@ -170,12 +235,26 @@ __global__ __launch_bounds__(128) void k_tp_rollout(PlannerDev pl, TpDev tp, uin
       break;
     }
     occ_cost = fmax(fmax(occ_cost, footprint_cost), double(wm.master[cell_y * pl.nx + cell_x]));
-    path_dist = (double)dpath[cell_y * pl.nx + cell_x];
-    goal_dist = (double)dgoal[cell_y * pl.nx + cell_x];
-    if (impossible_cost <= goal_dist || impossible_cost <= path_dist) {
-      cost = -2.0;
-      finished = false;
-      break;
+    if (c.simple_attractor) {  // :310-315 (the host refuses an empty plan)
+      const double gx = plan[2 * (n_plan - 1)], gy = plan[2 * (n_plan - 1) + 1];
+      goal_dist = (x_i - gx) * (x_i - gx) + (y_i - gy) * (y_i - gy);
+    } else {
+      bool update_path_and_goal_distances = true;
+      if (c.heading_scoring) {  // :321-327
+        if (time >= c.heading_scoring_timestep && time < c.heading_scoring_timestep + dt)
+          heading_diff = wm.headingDiff((int)cell_x, (int)cell_y, x_i, y_i, theta_i, plan, n_plan);
+        else
+          update_path_and_goal_distances = false;
+      }
+      if (update_path_and_goal_distances) {
+        path_dist = (double)dpath[cell_y * pl.nx + cell_x];
+        goal_dist = (double)dgoal[cell_y * pl.nx + cell_x];
+        if (impossible_cost <= goal_dist || impossible_cost <= path_dist) {
+          cost = -2.0;
+          finished = false;
+          break;
+        }
+      }
     }
     ex = x_i;
     ey = y_i;
@@ -194,8 +273,11 @@ __global__ __launch_bounds__(128) void k_tp_rollout(PlannerDev pl, TpDev tp, uin
     theta_i = theta_i + vtheta_i * dt;
     x_i = nx_;
     y_i = ny_;
+    time += dt;
   }
-  if (finished) cost = c.pdist_scale * path_dist + goal_dist * c.gdist_scale + c.occdist_scale * occ_cost;
+  if (finished)
+    cost = !c.heading_scoring ? c.pdist_scale * path_dist + goal_dist * c.gdist_scale + c.occdist_scale * occ_cost
+                              : c.occdist_scale * occ_cost + c.pdist_scale * path_dist + 0.3 * heading_diff + goal_dist * c.gdist_scale;
   if (store_points) return;
   TpOut o;
   o.cost = cost;

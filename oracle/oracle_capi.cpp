@@ -617,6 +617,9 @@ static TpConfig toTpCfg(const navgpu_tp_config& c) {
   o.n_y_vels = c.n_y_vels;
   for (int i = 0; i < 8; ++i) o.y_vels[i] = c.y_vels[i];
   o.allow_unknown = c.allow_unknown;
+  o.heading_scoring = c.heading_scoring;
+  o.simple_attractor = c.simple_attractor;
+  o.heading_scoring_timestep = c.heading_scoring_timestep;
   return o;
 }
 void* orc_tp_create(uint32_t sx, uint32_t sy, double res, double ox, double oy, const uint8_t* cells, const navgpu_tp_config* c,

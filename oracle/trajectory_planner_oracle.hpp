@@ -8,7 +8,8 @@
 // Pinned by base_local_planner/test/utest.cpp:75-102 (footprintObstacles: two generateTrajectory
 // known answers), test/footprint_helper_test.cpp (outline / fill cells) and the MapGrid fixtures; the
 // sequential selection logic of createTrajectories has no reference test — restated line by line.
-// Not restated: heading_scoring_ and simple_attractor_ (both default false).
+// heading_scoring_ / simple_attractor_ (both default false) included: headingDiff :372-386 with the planner's own
+// lineCost / pointCost (:388-472; pointCost also fails on INSCRIBED cells, unlike CostmapModel's).
 #pragma once
 #include <cfloat>
 
@@ -30,6 +31,8 @@ struct TpConfig {  // BaseLocalPlanner.cfg defaults
   int n_y_vels = 4;
   double y_vels[8] = {-0.3, -0.1, 0.1, 0.3, 0, 0, 0, 0};
   int allow_unknown = 1;
+  int heading_scoring = 0, simple_attractor = 0;
+  double heading_scoring_timestep = 0.1;
 };
 
 struct FpCell {  // Position2DInt
@@ -179,13 +182,18 @@ struct TrajectoryPlannerOracle {
 
   void generateTrajectory(double x, double y, double theta, double vx, double vy, double vtheta, double vx_samp, double vy_samp,
                           double vtheta_samp, double acc_x, double acc_y, double acc_theta, double impossible_cost,
-                          Trajectory& traj) {  // :214-370 (heading_scoring_ = simple_attractor_ = false)
+                          Trajectory& traj) {  // :214-370
     double x_i = x, y_i = y, theta_i = theta;
     double vx_i = vx, vy_i = vy, vtheta_i = vtheta;
     double vmag = hypot(vx_samp, vy_samp);
-    int num_steps = int(std::max((vmag * c.sim_time) / c.sim_granularity, fabs(vtheta_samp) / c.angular_sim_granularity) + 0.5);
+    int num_steps;
+    if (!c.heading_scoring)
+      num_steps = int(std::max((vmag * c.sim_time) / c.sim_granularity, fabs(vtheta_samp) / c.angular_sim_granularity) + 0.5);
+    else
+      num_steps = int(c.sim_time / c.sim_granularity + 0.5);
     if (num_steps == 0) num_steps = 1;
     double dt = c.sim_time / num_steps;
+    double time = 0.0, heading_diff = 0.0;
     traj.reset();
     traj.xv = vx_samp;
     traj.yv = vy_samp;
@@ -204,11 +212,25 @@ struct TrajectoryPlannerOracle {
         return;
       }
       occ_cost = std::max(std::max(occ_cost, footprint_cost), double(cm->cost(cell_x, cell_y)));
-      path_dist = path_map.dist[cm->index(cell_x, cell_y)];
-      goal_dist = goal_map.dist[cm->index(cell_x, cell_y)];
-      if (impossible_cost <= goal_dist || impossible_cost <= path_dist) {
-        traj.cost = -2.0;
-        return;
+      if (c.simple_attractor) {  // :310-315
+        const Pt2& g = global_plan[global_plan.size() - 1];
+        goal_dist = (x_i - g.x) * (x_i - g.x) + (y_i - g.y) * (y_i - g.y);
+      } else {
+        bool update_path_and_goal_distances = true;
+        if (c.heading_scoring) {  // :321-327: path and goal distance of ONE point of the trajectory, plus its heading difference
+          if (time >= c.heading_scoring_timestep && time < c.heading_scoring_timestep + dt)
+            heading_diff = headingDiff(cell_x, cell_y, x_i, y_i, theta_i);
+          else
+            update_path_and_goal_distances = false;
+        }
+        if (update_path_and_goal_distances) {
+          path_dist = path_map.dist[cm->index(cell_x, cell_y)];
+          goal_dist = goal_map.dist[cm->index(cell_x, cell_y)];
+          if (impossible_cost <= goal_dist || impossible_cost <= path_dist) {
+            traj.cost = -2.0;
+            return;
+          }
+        }
       }
       traj.x.push_back(x_i);
       traj.y.push_back(y_i);
@@ -219,8 +241,46 @@ struct TrajectoryPlannerOracle {
       x_i = computeNewXPosition(x_i, vx_i, vy_i, theta_i, dt);
       y_i = computeNewYPosition(y_i, vx_i, vy_i, theta_i, dt);
       theta_i = computeNewThetaPosition(theta_i, vtheta_i, dt);
+      time += dt;
     }
-    traj.cost = c.pdist_scale * path_dist + goal_dist * c.gdist_scale + c.occdist_scale * occ_cost;
+    if (!c.heading_scoring)
+      traj.cost = c.pdist_scale * path_dist + goal_dist * c.gdist_scale + c.occdist_scale * occ_cost;
+    else
+      traj.cost = c.occdist_scale * occ_cost + c.pdist_scale * path_dist + 0.3 * heading_diff + goal_dist * c.gdist_scale;
+  }
+  // TrajectoryPlanner::pointCost / lineCost (:388-472): the planner's own ray walk; INSCRIBED fails too
+  double tpPointCost(int x, int y) const {
+    const uint8_t cost = cm->cost(x, y);
+    if (cost == LETHAL_OBSTACLE || cost == INSCRIBED_INFLATED_OBSTACLE || (cost == NO_INFORMATION && !c.allow_unknown)) return -1;
+    return cost;
+  }
+  double tpLineCost(int x0, int x1, int y0, int y1) const {
+    double line_cost = 0.0;
+    bool bad = false;
+    lineCells(x0, y0, x1, y1, [&](int x, int y) {
+      const double pc = tpPointCost(x, y);
+      if (pc < 0) {
+        bad = true;
+        return false;
+      }
+      if (line_cost < pc) line_cost = pc;
+      return true;
+    });
+    return bad ? -1 : line_cost;
+  }
+  // :372-386: the farthest plan pose with a clear line of sight from the robot's cell
+  double headingDiff(int cell_x, int cell_y, double x, double y, double heading) const {
+    for (int i = (int)global_plan.size() - 1; i >= 0; --i) {
+      uint32_t gx_c, gy_c;
+      if (cm->worldToMap(global_plan[i].x, global_plan[i].y, gx_c, gy_c)) {
+        if (tpLineCost(cell_x, (int)gx_c, cell_y, (int)gy_c) >= 0) {
+          double gx, gy;
+          cm->mapToWorld(gx_c, gy_c, gx, gy);
+          return fabs(tpNormalizeAngle(atan2(gy - y, gx - x) - heading));  // angles::shortest_angular_distance(heading, atan2(..))
+        }
+      }
+    }
+    return DBL_MAX;
   }
   double scoreTrajectory(double x, double y, double theta, double vx, double vy, double vtheta, double vx_samp, double vy_samp,
                          double vtheta_samp) {  // :518-531

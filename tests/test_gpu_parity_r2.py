@@ -814,7 +814,7 @@ def test_layered_costmap_random_configurations_vs_oracle(nav, orc, seed):
 # of two robots each, against the oracle: every createTrajectories call's sample, cost, length; the result, the
 # trajectory and the persistent state (escape / oscillation flags).
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(40)))
 def test_trajectory_planner_random_configurations_vs_oracle(nav, orc, seed):
     from navigation_amd import synth
     from test_gpu_parity import _inflated_instance, _tp_compare_cycle
@@ -832,7 +832,8 @@ def test_trajectory_planner_random_configurations_vs_oracle(nav, orc, seed):
         backup_vel=float(pick(-0.1, -0.2)), sim_period=float(pick(0.05, 0.1)),
         y_vels=pick((-0.3, -0.1, 0.1, 0.3), (-0.2, 0.2), (0.15,)),
         vx_samples=int(pick(3, 6, 8)), vtheta_samples=int(pick(5, 9, 12)), holonomic_robot=int(pick(0, 1)), dwa=int(pick(0, 1)),
-        allow_unknown=int(pick(0, 1)))  # (heading_scoring / simple_attractor: rejected by navgpu_tp_configure)
+        allow_unknown=int(pick(0, 1)), heading_scoring=int(pick(0, 0, 1)), simple_attractor=int(pick(0, 0, 0, 1)),
+        heading_scoring_timestep=float(pick(0.1, 0.4, 0.8)))
     fp = pick(synth.FOOTPRINT, synth.FOOTPRINT5)
     insts = [_inflated_instance(orc, n, 300 + 2 * seed + i, synth) for i in range(n_inst)]
     c = n // 2
