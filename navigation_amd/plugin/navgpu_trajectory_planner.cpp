@@ -70,6 +70,7 @@ void TrajectoryPlanner::reconfigure(base_local_planner::BaseLocalPlannerConfig& 
   c.dwa = config.dwa;
   c.heading_scoring = config.heading_scoring;
   c.simple_attractor = config.simple_attractor;
+  c.heading_scoring_timestep = config.heading_scoring_timestep;  // :119
   c.sim_period = sim_period_;
   c.allow_unknown = costmap_2d::Costmap2D(costmap_).getDefaultValue() == 0 ? 0 : 1;  // trajectory_planner.cpp:196
   std::vector<std::string> y_strs;  // :124-139

@@ -6,8 +6,7 @@
 //   tc_->updatePlan(plan, compute_dists)       -> navgpu_tp_update_plan
 //   tc_->findBestPath(pose, vel, drive_cmds)   -> navgpu_tp_find_best_path + navgpu_tp_trajectory
 //   tc_->checkTrajectory / scoreTrajectory     -> navgpu_tp_score_trajectory
-// Source-only in this repository (needs the ROS headers).  heading_scoring and
-// simple_attractor are not supported by the GPU path: reconfigure() throws if either is requested.
+// Source-only in this repository (needs the ROS headers).
 #ifndef NAVGPU_TRAJECTORY_PLANNER_H_
 #define NAVGPU_TRAJECTORY_PLANNER_H_
 
