@@ -2284,6 +2284,10 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       const uint32_t fwd_margin = (uint32_t)fmin(ceil(fabs(fpd) * inv_res) + 1.0, 1.0e6);
       const bool fwd_screen = !(en_gf || en_al) || (2u * fwd_margin < g.nx && 2u * fwd_margin < g.ny);
       const uint32_t fwd_lo = (en_gf || en_al) ? fwd_margin : 0u, fwd_nx = g.nx - 2u * fwd_lo, fwd_ny = g.ny - 2u * fwd_lo;
+      // (the screens' LDS offset in a vector register: as a scalar it is spilled and read back with v_readlane at every point)
+      uint32_t fb_off = (uint32_t)win_bytes;
+      asm volatile("" : "+v"(fb_off));
+      const uint4* s_fb4 = reinterpret_cast<const uint4*>(s_dyn + fb_off);
       // which of the four screens count: obstacle (dilated "not free" with sum_scores, else dilated "can fail"), path, goal
       const bool scr_sum = c.sum_scores != 0;  // the obstacle screen: dilated "not free" with sum_scores, else dilated "can fail"
       const bool screen_on = !AGG && fwd_screen && (nfp >= 3 || !en_obs);
@@ -2310,7 +2314,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           bool screened = false;
           if (screen_on && step != num_steps - 1 && ok_c && inWin((int)cx, (int)cy)) {
             const int lxw = (int)cx - wx0;
-            const uint4 fb = reinterpret_cast<const uint4*>(s_fb)[((int)cy - wy0) * nw + (lxw >> 5)];
+            const uint4 fb = s_fb4[((int)cy - wy0) * nw + (lxw >> 5)];
             // (a critic that has already failed, or that follows one that has, cannot change the outcome any more)
             const uint32_t any = (scr_sum ? fb.x : fb.y) | (first_fail > 4 ? fb.z : 0u) | (first_fail > 5 ? fb.w : 0u);
             screened = !((any >> (lxw & 31)) & 1u) && (cx - fwd_lo < fwd_nx) && (cy - fwd_lo < fwd_ny);
