@@ -2837,6 +2837,7 @@ void launch_cell_costs(const PlannerDev& pl, uint32_t inst, float4* out, hipStre
 // the winner's points, run OscillationCostFunction::updateOscillationFlags
 // (oscillation_cost_function.cpp:56-164), fill drive velocities.
 // ------------------------------------------------------------------------------------------------
+constexpr int kSelectSteps = 128;  // steps whose trigonometry k_select computes side by side (longer trajectories: one lane)
 __global__ __launch_bounds__(64) void k_select(PlannerDev pl, uint32_t first, uint32_t n_blocks) {
   const uint32_t inst = first + blockIdx.x;
   const uint32_t tid = threadIdx.x;
@@ -2859,9 +2860,90 @@ __global__ __launch_bounds__(64) void k_select(PlannerDev pl, uint32_t first, ui
       bi = oi;
     }
   }
-  if (tid != 0) return;
+  bc = __shfl(bc, 0);
+  bi = __shfl(bi, 0);
+  // The winner's points.  A step's position needs the step before it, but its heading only the headings before it:
+  // lane 0 runs the (cheap) velocity / heading recurrences, every lane then takes the sines and cosines of some steps,
+  // lane 0 adds the positions up - the two dozen fp64 sincos calls in a row were most of this kernel's 15 us.
+  __shared__ float s_lv[kSelectSteps][3];
+  __shared__ float s_pth[kSelectSteps];
+  __shared__ double s_sc[kSelectSteps][4];
+  __shared__ int s_steps;
   const navgpu_robot_state st = pl.state[inst];
   const int32_t* cnt = pl.axis_count + 4 * inst;
+  float sel_vs[3] = {0.f, 0.f, 0.f}, sel_lv0[3] = {0.f, 0.f, 0.f};
+  double sel_dt = 0.0;
+  int sel_steps = 0;
+  if (bi != 0x7FFFFFFF) {  // (uniform)
+    const int nth = cnt[2], nyv = cnt[1];
+    const int ix = bi / (nyv * nth), rem = bi - ix * (nyv * nth);
+    const int iy = rem / nth, ith = rem - iy * nth;
+    sel_vs[0] = pl.axis_samples[((size_t)inst * 3 + 0) * pl.max_axis + ix];
+    sel_vs[1] = pl.axis_samples[((size_t)inst * 3 + 1) * pl.max_axis + iy];
+    sel_vs[2] = pl.axis_samples[((size_t)inst * 3 + 2) * pl.max_axis + ith];
+    const double vmag = hyp2((double)sel_vs[0], (double)sel_vs[1]);
+    double ns;
+    if (c.discretize_by_time)
+      ns = ceil(c.sim_time / c.sim_granularity);
+    else
+      ns = ceil(fmax(vmag * c.sim_time / c.sim_granularity, fabs((double)sel_vs[2]) * c.sim_time / c.angular_sim_granularity));
+    sel_steps = (int)ns;
+    if (sel_steps > (int)pl.max_sim_steps) sel_steps = (int)pl.max_sim_steps;
+    sel_dt = c.sim_time / sel_steps;
+    const bool continued = !c.use_dwa;
+    const float acc[3] = {(float)c.acc_lim_x, (float)c.acc_lim_y, (float)c.acc_lim_theta};
+    auto newVel = [&](const float* vel_in, float* out) {
+      for (int i = 0; i < 3; ++i) {
+        if (vel_in[i] < sel_vs[i])
+          out[i] = (float)fmin((double)sel_vs[i], vel_in[i] + acc[i] * sel_dt);
+        else
+          out[i] = (float)fmax((double)sel_vs[i], vel_in[i] - acc[i] * sel_dt);
+      }
+    };
+    float lv[3] = {sel_vs[0], sel_vs[1], sel_vs[2]};
+    if (continued) {
+      float t0[3];
+      newVel(st.vel, t0);
+      lv[0] = t0[0];
+      lv[1] = t0[1];
+      lv[2] = t0[2];
+    }
+    sel_lv0[0] = lv[0];
+    sel_lv0[1] = lv[1];
+    sel_lv0[2] = lv[2];
+    if (sel_steps <= kSelectSteps) {
+      if (tid == 0) {
+        float pth = st.pos[2];
+        for (int step = 0; step < sel_steps; ++step) {
+          s_pth[step] = pth;
+          if (continued) {
+            float t1[3];
+            newVel(lv, t1);
+            lv[0] = t1[0];
+            lv[1] = t1[1];
+            lv[2] = t1[2];
+          }
+          s_lv[step][0] = lv[0];
+          s_lv[step][1] = lv[1];
+          s_lv[step][2] = lv[2];
+          pth = (float)(pth + lv[2] * sel_dt);
+        }
+      }
+      __syncthreads();
+      for (int step = (int)tid; step < sel_steps; step += 64) {
+        const double th = s_pth[step];
+        double sn, cs, sn2 = 0.0, cs2 = 0.0;
+        sincos(th, &sn, &cs);
+        if (s_lv[step][1] != 0.0f) sincos(M_PI_2 + th, &sn2, &cs2);
+        s_sc[step][0] = cs;
+        s_sc[step][1] = sn;
+        s_sc[step][2] = cs2;
+        s_sc[step][3] = sn2;
+      }
+      __syncthreads();
+    }
+  }
+  if (tid != 0) return;
   navgpu_plan_result r;
   r.n_samples = cnt[3];
   r.n_scored = pl.counters[2 * inst];
@@ -2876,65 +2958,57 @@ __global__ __launch_bounds__(64) void k_select(PlannerDev pl, uint32_t first, ui
     r.cost = -7.0;  // result_traj_.cost_ pre-set (dwa_planner.cpp:316)
     r.drive[0] = r.drive[1] = r.drive[2] = 0.0;
   } else {
-    const int nth = cnt[2], nyv = cnt[1];
-    const int ix = bi / (nyv * nth), rem = bi - ix * (nyv * nth);
-    const int iy = rem / nth, ith = rem - iy * nth;
-    float vs[3];
-    vs[0] = pl.axis_samples[((size_t)inst * 3 + 0) * pl.max_axis + ix];
-    vs[1] = pl.axis_samples[((size_t)inst * 3 + 1) * pl.max_axis + iy];
-    vs[2] = pl.axis_samples[((size_t)inst * 3 + 2) * pl.max_axis + ith];
-    const double vmag = hyp2((double)vs[0], (double)vs[1]);
-    double ns;
-    if (c.discretize_by_time)
-      ns = ceil(c.sim_time / c.sim_granularity);
-    else
-      ns = ceil(fmax(vmag * c.sim_time / c.sim_granularity, fabs((double)vs[2]) * c.sim_time / c.angular_sim_granularity));
-    int num_steps = (int)ns;
-    if (num_steps > (int)pl.max_sim_steps) num_steps = (int)pl.max_sim_steps;
-    const double dt = c.sim_time / num_steps;
-    const bool continued = !c.use_dwa;
-    const float acc[3] = {(float)c.acc_lim_x, (float)c.acc_lim_y, (float)c.acc_lim_theta};
-    float lv[3] = {vs[0], vs[1], vs[2]};
-    auto newVel = [&](const float* vel_in, float* out) {
-      for (int i = 0; i < 3; ++i) {
-        if (vel_in[i] < vs[i])
-          out[i] = (float)fmin((double)vs[i], vel_in[i] + acc[i] * dt);
-        else
-          out[i] = (float)fmax((double)vs[i], vel_in[i] - acc[i] * dt);
-      }
-    };
-    if (continued) {
-      float t0[3];
-      newVel(st.vel, t0);
-      lv[0] = t0[0];
-      lv[1] = t0[1];
-      lv[2] = t0[2];
-    }
-    r.xv = lv[0];
-    r.yv = lv[1];
-    r.thetav = lv[2];
+    const int num_steps = sel_steps;
+    const double dt = sel_dt;
+    r.xv = sel_lv0[0];
+    r.yv = sel_lv0[1];
+    r.thetav = sel_lv0[2];
     float px = st.pos[0], py = st.pos[1], pth = st.pos[2];
-    for (int step = 0; step < num_steps; ++step) {
-      tr[3 * step] = px;
-      tr[3 * step + 1] = py;
-      tr[3 * step + 2] = pth;
-      if (continued) {
-        float t1[3];
-        newVel(lv, t1);
-        lv[0] = t1[0];
-        lv[1] = t1[1];
-        lv[2] = t1[2];
+    if (num_steps <= kSelectSteps) {
+      for (int step = 0; step < num_steps; ++step) {
+        tr[3 * step] = px;
+        tr[3 * step + 1] = py;
+        tr[3 * step + 2] = s_pth[step];
+        const float lx = s_lv[step][0], ly = s_lv[step][1];
+        const float nxp = (float)(px + (lx * s_sc[step][0] + ly * s_sc[step][2]) * dt);
+        const float nyp = (float)(py + (lx * s_sc[step][1] + ly * s_sc[step][3]) * dt);
+        px = nxp;
+        py = nyp;
       }
-      const double th = pth;
-      double sn, cs, sn2 = 0.0, cs2 = 0.0;
-      sincos(th, &sn, &cs);
-      if (lv[1] != 0.0f) sincos(M_PI_2 + th, &sn2, &cs2);
-      const float nxp = (float)(px + (lv[0] * cs + lv[1] * cs2) * dt);
-      const float nyp = (float)(py + (lv[0] * sn + lv[1] * sn2) * dt);
-      const float ntp = (float)(pth + lv[2] * dt);
-      px = nxp;
-      py = nyp;
-      pth = ntp;
+    } else {  // (more steps than the shared tables hold: the plain sequential form)
+      const bool continued = !c.use_dwa;
+      const float acc[3] = {(float)c.acc_lim_x, (float)c.acc_lim_y, (float)c.acc_lim_theta};
+      float lv[3] = {sel_lv0[0], sel_lv0[1], sel_lv0[2]};
+      auto newVel = [&](const float* vel_in, float* out) {
+        for (int i = 0; i < 3; ++i) {
+          if (vel_in[i] < sel_vs[i])
+            out[i] = (float)fmin((double)sel_vs[i], vel_in[i] + acc[i] * dt);
+          else
+            out[i] = (float)fmax((double)sel_vs[i], vel_in[i] - acc[i] * dt);
+        }
+      };
+      for (int step = 0; step < num_steps; ++step) {
+        tr[3 * step] = px;
+        tr[3 * step + 1] = py;
+        tr[3 * step + 2] = pth;
+        if (continued) {
+          float t1[3];
+          newVel(lv, t1);
+          lv[0] = t1[0];
+          lv[1] = t1[1];
+          lv[2] = t1[2];
+        }
+        const double th = pth;
+        double sn, cs, sn2 = 0.0, cs2 = 0.0;
+        sincos(th, &sn, &cs);
+        if (lv[1] != 0.0f) sincos(M_PI_2 + th, &sn2, &cs2);
+        const float nxp = (float)(px + (lv[0] * cs + lv[1] * cs2) * dt);
+        const float nyp = (float)(py + (lv[0] * sn + lv[1] * sn2) * dt);
+        const float ntp = (float)(pth + lv[2] * dt);
+        px = nxp;
+        py = nyp;
+        pth = ntp;
+      }
     }
     r.best_index = bi;
     r.n_points = num_steps;
