@@ -1919,12 +1919,24 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     fy = fmin(fmax(fy, -1.0e6), 1.0e6);
     wx0 = (int)fx - win / 2;
     wy0 = (int)fy - win / 2;
-    for (int i = tid; PREP != 2 && i < win * win; i += blockDim.x) {
-      int ly = i / win, lx = i - ly * win;
-      int gx = wx0 + lx, gy = wy0 + ly;
-      uint8_t v = 0;
-      if (gx >= 0 && gy >= 0 && gx < (int)g.nx && gy < (int)g.ny) v = master[gy * g.nx + gx];
-      s_win[i] = v;
+    // (eight loads of a lane in flight at a time - unconditional, clamped: a conditional load in a rolled loop is waited
+    // for on its own, nine latencies in a row for a 65 x 65 window)
+    for (int i0 = tid; PREP != 2 && i0 < win * win; i0 += 8 * (int)blockDim.x) {
+      uint8_t v[8];
+      bool in_map[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int ic = min(i0 + u * (int)blockDim.x, win * win - 1);
+        const int ly = ic / win, lx = ic - ly * win;
+        const int gx = wx0 + lx, gy = wy0 + ly;
+        in_map[u] = gx >= 0 && gy >= 0 && gx < (int)g.nx && gy < (int)g.ny;
+        v[u] = master[min(max(gy, 0), (int)g.ny - 1) * g.nx + min(max(gx, 0), (int)g.nx - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * (int)blockDim.x;
+        if (i < win * win) s_win[i] = in_map[u] ? v[u] : (uint8_t)0;
+      }
     }
   }
   // ---- per-cell screens of the window, four bitmaps interleaved per 32-cell word: s_fb[(y * nw + j) * 4 + k]
@@ -1993,26 +2005,42 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   {  // MapGrid screens: 64 consecutive cells of a (padded) window row per wave step, packed by ballot
     const uint32_t n_obst = pl.cells, n_unreach = pl.cells + 1;
     const int row_cells = nw * 32;
-    for (int base = (int)(tid & ~63u); base < win * row_cells; base += (int)blockDim.x) {
-      const int idx = base + (int)(tid & 63u);
-      const int y = idx / row_cells, lx = idx - y * row_cells;
-      const int gx = wx0 + lx, gy = wy0 + y;
-      bool pf = true, gf = true;
-      if (lx < win && gx >= 0 && gy >= 0 && gx < (int)g.nx && gy < (int)g.ny) {
-        const uint32_t dp = dpath[gy * g.nx + gx], dg = dgoal[gy * g.nx + gx];
-        pf = dp == n_obst || dp == n_unreach;
-        gf = dg == n_obst || dg == n_unreach;
+    // (four steps of a wave = eight distance loads per lane in flight, unconditional and clamped, as for the window above)
+    for (int base0 = (int)(tid & ~63u); base0 < win * row_cells; base0 += 4 * (int)blockDim.x) {
+      uint32_t dp[4], dg[4];
+      bool in_map[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = min(base0 + u * (int)blockDim.x + (int)(tid & 63u), win * row_cells - 1);
+        const int y = idx / row_cells, lx = idx - y * row_cells;
+        const int gx = wx0 + lx, gy = wy0 + y;
+        in_map[u] = lx < win && gx >= 0 && gy >= 0 && gx < (int)g.nx && gy < (int)g.ny;
+        const uint32_t cell = (uint32_t)(min(max(gy, 0), (int)g.ny - 1)) * g.nx + (uint32_t)min(max(gx, 0), (int)g.nx - 1);
+        dp[u] = dpath[cell];
+        dg[u] = dgoal[cell];
       }
-      pf = pf && pl.scale_path != 0;  // a critic with scale 0 is never evaluated: its screen stays clear
-      gf = gf && pl.scale_goal != 0;
-      const unsigned long long mp = __ballot(pf), mg = __ballot(gf);
-      if ((tid & 63u) == 0) {
-        const int w = idx >> 5;  // linear word index y * nw + j; a wave covers two words (possibly of two rows)
-        s_fb[4 * w + 2] = (uint32_t)mp;
-        s_fb[4 * w + 3] = (uint32_t)mg;
-        if (w + 1 < win * nw) {
-          s_fb[4 * (w + 1) + 2] = (uint32_t)(mp >> 32);
-          s_fb[4 * (w + 1) + 3] = (uint32_t)(mg >> 32);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int base = base0 + u * (int)blockDim.x;
+        if (base < win * row_cells) {  // (wave-uniform)
+          const int idx = base + (int)(tid & 63u);
+          bool pf = true, gf = true;
+          if (in_map[u] && idx < win * row_cells) {
+            pf = dp[u] == n_obst || dp[u] == n_unreach;
+            gf = dg[u] == n_obst || dg[u] == n_unreach;
+          }
+          pf = pf && pl.scale_path != 0;  // a critic with scale 0 is never evaluated: its screen stays clear
+          gf = gf && pl.scale_goal != 0;
+          const unsigned long long mp = __ballot(pf), mg = __ballot(gf);
+          if ((tid & 63u) == 0) {
+            const int w = idx >> 5;  // linear word index y * nw + j; a wave covers two words (possibly of two rows)
+            s_fb[4 * w + 2] = (uint32_t)mp;
+            s_fb[4 * w + 3] = (uint32_t)mg;
+            if (w + 1 < win * nw) {
+              s_fb[4 * (w + 1) + 2] = (uint32_t)(mp >> 32);
+              s_fb[4 * (w + 1) + 3] = (uint32_t)(mg >> 32);
+            }
+          }
         }
       }
     }
