@@ -23,6 +23,7 @@ __device__ __forceinline__ Geom geomOf(const PlannerDev& pl, uint32_t inst) {
 // One lane per axis: `next += step_size` is a sequential fp64 accumulation and must stay one.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t bfsFreeWord(const uint8_t* master, uint32_t row, uint32_t nx, uint32_t wi, uint32_t unknown_is_obstacle);
+__device__ __forceinline__ uint32_t bfsObstacleNibble(uint32_t v, uint32_t unknown_is_obstacle);
 // Three kinds of 128-thread blocks, all latency-bound and independent of each other, side by side:
 //   [0, count)          one robot's wavefront region, pocket floods and care words (wave 0: the region's flood, wave 1: the
 //                       large area's), 
@@ -170,6 +171,38 @@ __global__ __launch_bounds__(kSamplesThreads) void k_samples(PlannerDev pl, uint
         // this wave's area: x0..x1, y0..y1 (wave 0: the region, wave 1: the large area)
         const int ax0 = wv ? fx0 : region.x, ax1 = wv ? fx1 : region.y, ay0 = wv ? fy0 : region.z, ay1 = wv ? fy1 : region.w;
         uint32_t fm[2][kCareWords], F[2][kCareWords];
+        // the traversable-cell words of this lane's two rows.  Usual case (rows 16-byte aligned, whole words): all sixteen
+        // 16-byte loads are issued before the first is used - bfsFreeWord's general form waits for each word on its own
+        uint32_t fword[2][kCareWords];
+        if ((pl.nx & 15u) == 0 && (uint32_t)(fw1 * 32 + 31) < pl.nx) {
+          uint4 ca[2][kCareWords], cb[2][kCareWords];
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int w = 0; w < kCareWords; ++w) {
+              const uint4* p = reinterpret_cast<const uint4*>(master + (size_t)min(fy0 + 2 * (int)tid + h, fy1) * pl.nx + (size_t)min(fw0 + w, fw1) * 32);
+              ca[h][w] = p[0];
+              cb[h][w] = p[1];
+            }
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int w = 0; w < kCareWords; ++w) {
+              const uint4 a = ca[h][w], b = cb[h][w];
+              fword[h][w] = ~(bfsObstacleNibble(a.x, unknown_is_obstacle) | (bfsObstacleNibble(a.y, unknown_is_obstacle) << 4) |
+                              (bfsObstacleNibble(a.z, unknown_is_obstacle) << 8) | (bfsObstacleNibble(a.w, unknown_is_obstacle) << 12) |
+                              (bfsObstacleNibble(b.x, unknown_is_obstacle) << 16) | (bfsObstacleNibble(b.y, unknown_is_obstacle) << 20) |
+                              (bfsObstacleNibble(b.z, unknown_is_obstacle) << 24) | (bfsObstacleNibble(b.w, unknown_is_obstacle) << 28));
+            }
+        } else {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int w = 0; w < kCareWords; ++w) {
+              const int row = fy0 + 2 * (int)tid + h;
+              fword[h][w] = (row <= fy1 && fw0 + w <= fw1) ? bfsFreeWord(master, (uint32_t)row, pl.nx, (uint32_t)(fw0 + w), unknown_is_obstacle) : 0u;
+            }
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int row = fy0 + 2 * (int)tid + h;
@@ -179,7 +212,7 @@ __global__ __launch_bounds__(kSamplesThreads) void k_samples(PlannerDev pl, uint
             fm[h][w] = F[h][w] = 0;
             if (row <= fy1 && fw0 + w <= fw1) {
               const uint32_t cm = in_a ? colMask(w, ax0, ax1) : 0u;
-              const uint32_t fw_ = bfsFreeWord(master, (uint32_t)row, pl.nx, (uint32_t)(fw0 + w), unknown_is_obstacle);
+              const uint32_t fw_ = fword[h][w];
               fm[h][w] = fw_ & cm;
               const uint32_t rim = (row == ay0 || row == ay1) ? cm : (colMask(w, ax0, ax0) | colMask(w, ax1, ax1));
               F[h][w] = fm[h][w] & rim;
