@@ -2502,20 +2502,21 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
                     // of one dependent LDS round trip per cell); cells past the end re-read the first
                     // cell, cells past a lethal cell cannot change the outcome (-1 either way).
                     constexpr int kChunk = CHUNK;
-                    int idx = (pyc - wy0) * win + (pxc - wx0);
-                    const int idx_first = idx;
+                    // (the LDS address itself is stepped: with an index, the window's base is added again for every cell)
+                    const uint8_t* pw = s_win + ((pyc - wy0) * win + (pxc - wx0));
+                    const uint8_t* const pw_first = pw;
                     const int inc1 = yinc1 * win + xinc1, inc2 = yinc2 * win + xinc2;
                     for (int cp = 0; cp <= numpixels && !bad; cp += kChunk) {
                       uint32_t cellv[kChunk];
 #pragma unroll
                       for (int u = 0; u < kChunk; ++u) {
-                        cellv[u] = s_win[(cp + u <= numpixels) ? idx : idx_first];
+                        cellv[u] = *((cp + u <= numpixels) ? pw : pw_first);
                         num += numadd;
                         if (num >= den) {
                           num -= den;
-                          idx += inc1;
+                          pw += inc1;
                         }
-                        idx += inc2;
+                        pw += inc2;
                       }
 #pragma unroll
                       for (int u = 0; u < kChunk; ++u) mx_cost = max(mx_cost, cellv[u]);
