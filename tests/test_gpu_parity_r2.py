@@ -926,3 +926,30 @@ def test_map_grid_aggregation_and_yshift(nav, orc, options):
         with pytest.raises(NavgpuError):
             check(fl.L.navgpu_planner_set_map_grid_options(fl.h, *bad), "set_map_grid_options")
     fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# Determinism of the whole step at configs[2]'s size: the same 24 cycles (perturbed poses, scans, plans) run twice on two
+# fleets give the same winners, costs, counters, wavefront levels and master grids, cycle by cycle.  (Work queues,
+# atomics and the hand-shakes between waves must not leak scheduling order into results.)
+# ----------------------------------------------------------------------------------------------
+def test_fleet_256_cycles_are_deterministic(nav):
+    import bench
+    runs = []
+    for _ in range(2):
+        fl, insts, cfg = bench.build_fleet(nav, 256, 400, 0)
+        _, _, pos_h, vel_h, plans_h = fl._bench_host_inputs
+        poses = bench.PoseSchedule(pos_h, vel_h, 24, seed=5)
+        out = []
+        for k in range(24):
+            bench.step(fl, poses, k)
+            res = fl.results()
+            out.append((np.array([(r.best_index, r.n_scored, r.n_valid, r.oscillation_flags) for r in res]), np.array([r.cost for r in res]),
+                        fl.wavefront_levels().copy()))
+        runs.append((out, fl.master().copy()))
+        fl.close()
+    for k in range(24):
+        a, b = runs[0][0][k], runs[1][0][k]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), k
+    assert np.array_equal(runs[0][1], runs[1][1])
+    assert (runs[0][0][-1][0][:, 0] >= 0).sum() > 200
