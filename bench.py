@@ -296,6 +296,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--instances", type=int, default=256, help="robot instances per GPU")
+    ap.add_argument("--total-instances", type=int, default=0,
+                    help="strong scaling (SURVEY 8e: 2048 robots over the node): this many robots in all, split over the ranks by "
+                         "navigation_amd.sharding.shard_range; 0 = --instances per GPU (weak scaling, the contract workload)")
     ap.add_argument("--size", type=int, default=400, help="costmap cells per side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true")
@@ -336,8 +339,12 @@ def main():
 
     nav.lib()  # fails loudly if the HIP extension is missing
     n_inst, n_cells = args.instances, args.size
+    seed0 = rank * n_inst
+    if args.total_instances:
+        from navigation_amd.sharding import shard_range
+        seed0, n_inst = shard_range(args.total_instances, rank, world)
     vs = tuple(int(v) for v in args.vsamples.split(","))
-    fl, insts, cfg = build_fleet(nav, n_inst, n_cells, seed0=rank * n_inst, device=local_rank, vs=vs, footprint=args.footprint)
+    fl, insts, cfg = build_fleet(nav, n_inst, n_cells, seed0=seed0, device=local_rank, vs=vs, footprint=args.footprint)
     _, _, pos_h, vel_h, plans_h = fl._bench_host_inputs
     poses = None if args.fixed_poses else PoseSchedule(pos_h, vel_h, 64, seed=4242 + rank)
 
@@ -433,11 +440,12 @@ def main():
             "metric": "scored trajectories/sec (whole node) + costmap inflation cells/sec, 400x400 map",
             "value": traj_per_s, "unit": "trajectories/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "strong" if args.total_instances else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"configs[2]: {n_inst} batched robot instances per MI355X, {n_cells}x{n_cells} costmaps "
                                    f"+ inflation, 32x32x16 velocity samples, 20 sim steps, LaserScan (720 beams) update "
-                                   f"each cycle; N GPUs = N x {n_inst} instances (N=8 is configs[3])",
+                                   f"each cycle; " + (f"{args.total_instances} instances in all, split over the ranks (strong scaling)" if args.total_instances
+                                                      else f"N GPUs = N x {n_inst} instances (N=8 is configs[3])"),
                        "instances_per_gpu": n_inst, "costmap": f"{n_cells}x{n_cells}@0.05", "vsamples": "x".join(str(v) for v in vs),
                        "sim_steps": T_STEPS, "critics": "oscillation+obstacle+goal_front+alignment+path+goal",
                        "parallelism": f"fleet-shard x{world}"},
