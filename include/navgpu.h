@@ -218,6 +218,14 @@ int navgpu_grid_device(navgpu_fleet* fleet, int grid, void** device_ptr, size_t*
 int navgpu_costmap_export(navgpu_fleet* fleet, uint32_t instance, uint32_t x0, uint32_t y0, uint32_t xn, uint32_t yn, int8_t* out);
 /* Costmap2D::resetMaps() on the given grid (default value of that grid) */
 int navgpu_grid_reset(navgpu_fleet* fleet, int grid, uint32_t first, uint32_t count);
+/* replaces: Costmap2D::resetMap(x0, y0, xn, yn) (costmap_2d.cpp:93-99: rows [y0, yn), columns [x0, xn)) on
+ * NAVGPU_GRID_MASTER or NAVGPU_GRID_OBSTACLE (a voxel layer's 2-D grid; its columns are untouched, as in the reference) */
+int navgpu_grid_reset_window(navgpu_fleet* fleet, int grid, uint32_t first, uint32_t count, uint32_t x0, uint32_t y0, uint32_t xn, uint32_t yn);
+/* replaces: CostmapLayer::resetBoundingBox(min, max) (costmap_layer.cpp:30-43; what Costmap2DROS::resetBoundingBox calls on
+ * every CostmapLayer, costmap_2d_ros.cpp:574-611) on the obstacle / voxel layer: boxes = count x {min_x, min_y, max_x,
+ * max_y} in world coordinates; the layer grid is reset inside (worldToMapEnforceBounds of both corners, resetMap) and the
+ * box joins the bounds of the next navgpu_costmap_update / navgpu_obstacle_update_bounds (addExtraBounds / useExtraBounds). */
+int navgpu_layer_reset_bounding_box(navgpu_fleet* fleet, uint32_t first, uint32_t count, const double* boxes);
 
 /* ------------------------------------------------------------------------------------------ */
 /* costmap layers                                                                             */

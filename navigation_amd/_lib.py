@@ -205,6 +205,8 @@ SYMBOLS = [
     ("navgpu_grid_download", C.c_int, [vp, C.c_int, u32, u32, vp]),
     ("navgpu_grid_device", C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]),
     ("navgpu_grid_reset", C.c_int, [vp, C.c_int, u32, u32]),
+    ("navgpu_grid_reset_window", C.c_int, [vp, C.c_int, u32, u32, u32, u32, u32, u32]),
+    ("navgpu_layer_reset_bounding_box", C.c_int, [vp, u32, u32, vp]),
     ("navgpu_static_set_map", C.c_int, [vp, u32, u32, vp, i32, i32, i32, i32, i32]),
     ("navgpu_static_set_rolling_map", C.c_int, [vp, vp, u32, u32, C.c_double, C.c_double, C.c_double, i32, i32, i32, i32, i32]),
     ("navgpu_static_set_transform", C.c_int, [vp, u32, u32, vp]),

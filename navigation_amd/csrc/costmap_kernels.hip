@@ -317,6 +317,15 @@ __global__ __launch_bounds__(256) void k_obstacle(CostmapDev cm, uint32_t first,
   }
 
   const bool has_obs_layer = (cm.layers & (NAVGPU_LAYER_OBSTACLE | NAVGPU_LAYER_VOXEL)) && cm.obs_enabled;
+  if (tid == 0 && has_obs_layer && st->has_extra_bounds) {  // useExtraBounds (obstacle_layer.cpp:347, voxel_layer.cpp:123; costmap_layer.cpp:46-60)
+    b.min_x = (st->extra[0] < b.min_x) ? st->extra[0] : b.min_x;
+    b.min_y = (st->extra[1] < b.min_y) ? st->extra[1] : b.min_y;
+    b.max_x = (b.max_x < st->extra[2]) ? st->extra[2] : b.max_x;
+    b.max_y = (b.max_y < st->extra[3]) ? st->extra[3] : b.max_y;
+    st->extra[0] = st->extra[1] = 1e6;
+    st->extra[2] = st->extra[3] = -1e6;
+    st->has_extra_bounds = 0;
+  }
   const uint32_t ob = inst * cm.max_obs, oe = ob + cm.obs_count[inst];
   const float* inst_points = cm.points + (size_t)inst * cm.max_points * 3;
   const uint32_t unknown_thr = VOXEL ? (uint32_t)(cm.unknown_threshold + (16 - cm.z_voxels)) : 0;  // voxel_layer.cpp:89
@@ -637,6 +646,48 @@ __global__ __launch_bounds__(256) void k_obstacle(CostmapDev cm, uint32_t first,
       }
     }
   }
+}
+
+// k_reset_bounding_box: CostmapLayer::resetBoundingBox (costmap_layer.cpp:30-43) on the obstacle / voxel layer's 2-D grid:
+// worldToMapEnforceBounds of both corners, Costmap2D::resetMap (rows [y0, yn), columns [x0, xn): the end cell is NOT
+// included, costmap_2d.cpp:93-99), addExtraBounds for the next updateBounds.  A VoxelLayer's columns stay as they are
+// (it overrides resetMaps, not resetMap).
+__global__ __launch_bounds__(256) void k_reset_bounding_box(CostmapDev cm, uint32_t first, const double* boxes_world) {
+  const uint32_t inst = first + blockIdx.x;
+  const Geom g{cm.origin[2 * inst], cm.origin[2 * inst + 1], cm.res, cm.nx, cm.ny};
+  const double* bw = boxes_world + 4 * blockIdx.x;
+  int x0, y0, xn, yn;
+  enforceBounds(g, bw[0], bw[1], x0, y0);
+  enforceBounds(g, bw[2], bw[3], xn, yn);
+  uint8_t* layer = cm.obst + (size_t)inst * cm.cells_padded;
+  if (xn > x0 && yn > y0) {
+    const uint32_t w = (uint32_t)(xn - x0), n = w * (uint32_t)(yn - y0);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) layer[(uint32_t)(y0 + i / w) * g.nx + (uint32_t)x0 + i % w] = cm.obstacle_default;
+  }
+  if (threadIdx.x == 0) {
+    InstCostmapState* st = cm.state + inst;
+    if (!st->has_extra_bounds) {  // (a fresh state is all zeros: the reference starts from 1e6 / -1e6)
+      st->extra[0] = st->extra[1] = 1e6;
+      st->extra[2] = st->extra[3] = -1e6;
+    }
+    st->extra[0] = (bw[0] < st->extra[0]) ? bw[0] : st->extra[0];
+    st->extra[1] = (bw[1] < st->extra[1]) ? bw[1] : st->extra[1];
+    st->extra[2] = (st->extra[2] < bw[2]) ? bw[2] : st->extra[2];
+    st->extra[3] = (st->extra[3] < bw[3]) ? bw[3] : st->extra[3];
+    st->has_extra_bounds = 1;
+  }
+}
+// Costmap2D::resetMap(x0, y0, xn, yn) (costmap_2d.cpp:93-99) of one byte grid per instance
+__global__ __launch_bounds__(256) void k_reset_window(uint8_t* grid, size_t stride, uint32_t nx, uint32_t x0, uint32_t y0, uint32_t xn, uint32_t yn, uint8_t value) {
+  uint8_t* gp = grid + (size_t)blockIdx.x * stride;
+  const uint32_t w = xn - x0, n = w * (yn - y0);
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) gp[(y0 + i / w) * nx + x0 + i % w] = value;
+}
+void launch_reset_window(uint8_t* grid, size_t stride, uint32_t count, uint32_t nx, uint32_t x0, uint32_t y0, uint32_t xn, uint32_t yn, uint8_t value, hipStream_t s) {
+  hipLaunchKernelGGL(k_reset_window, dim3(count), dim3(256), 0, s, grid, stride, nx, x0, y0, xn, yn, value);
+}
+void launch_reset_bounding_box(const CostmapDev& cm, uint32_t first, uint32_t count, const double* boxes_world, hipStream_t s) {
+  hipLaunchKernelGGL(k_reset_bounding_box, dim3(count), dim3(256), 0, s, cm, first, boxes_world);
 }
 
 void launch_obstacle(const CostmapDev& cm, uint32_t first, uint32_t count, const double* bounds_in, int only_bounds, hipStream_t s) {

@@ -39,6 +39,8 @@ struct InstCostmapState {  // per-instance state that persists across update cyc
   int32_t box_valid;                                      // 0 when xn < x0 || yn < y0 (layered_costmap.cpp:128-135)
   int32_t pad;
   double bounds[4];                                       // min_x, min_y, max_x, max_y after all updateBounds
+  double extra[4];                                        // CostmapLayer::extra_min_x_, _min_y_, _max_x_, _max_y_ of the obstacle layer
+  int32_t has_extra_bounds, pad2;                         // (costmap_layer.cpp:21-60)
 };
 
 struct ObsCsr {  // one observation, device form
@@ -190,6 +192,8 @@ void launch_tp_rollout(const PlannerDev& pl, const TpDev& tp, uint32_t first, ui
 // ---- launchers (defined in the .hip files) ---------------------------------------------------
 void launch_obstacle(const CostmapDev& cm, uint32_t first, uint32_t count, const double* bounds_in, int only_bounds,
                      hipStream_t s);
+void launch_reset_window(uint8_t* grid, size_t stride, uint32_t count, uint32_t nx, uint32_t x0, uint32_t y0, uint32_t xn, uint32_t yn, uint8_t value, hipStream_t s);
+void launch_reset_bounding_box(const CostmapDev& cm, uint32_t first, uint32_t count, const double* boxes_world, hipStream_t s);
 void launch_merge(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s, bool layer_only = false);
 void launch_inflate(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s);
 void launch_static_interpret(uint8_t* dst, const int8_t* occ, uint32_t cells, uint32_t cells_padded, uint32_t count,

@@ -326,6 +326,40 @@ int navgpu_grid_reset(navgpu_fleet* f, int grid, uint32_t first, uint32_t count)
   return checkLaunch();
 }
 
+static int applyPendingShift(navgpu_fleet* f, uint32_t first, uint32_t count);
+int navgpu_grid_reset_window(navgpu_fleet* f, int grid, uint32_t first, uint32_t count, uint32_t x0, uint32_t y0, uint32_t xn, uint32_t yn) {
+  if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  CostmapDev& cm = f->cm;
+  if (xn > cm.nx || yn > cm.ny || x0 > xn || y0 > yn) return NAVGPU_ERR_INVALID;  // (the reference's memset length underflows for xn < x0)
+  uint8_t* base = nullptr;
+  uint8_t value = 0;
+  switch (grid) {
+    case NAVGPU_GRID_MASTER: base = cm.master; value = cm.master_default; break;
+    case NAVGPU_GRID_OBSTACLE: base = cm.obst; value = cm.obstacle_default; break;  // (a VoxelLayer's columns are not touched: it overrides resetMaps only)
+    default: return NAVGPU_ERR_INVALID;
+  }
+  if (!base) return NAVGPU_ERR_STATE;
+  f->touchInputs(first, count);
+  if (xn > x0 && yn > y0) launch_reset_window(base + (size_t)first * cm.cells_padded, cm.cells_padded, count, cm.nx, x0, y0, xn, yn, value, f->stream);
+  return checkLaunch();
+}
+int navgpu_layer_reset_bounding_box(navgpu_fleet* f, uint32_t first, uint32_t count, const double* boxes) {
+  if (!f || !boxes || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  CostmapDev& cm = f->cm;
+  if (!cm.obst) return NAVGPU_ERR_STATE;
+  for (uint32_t i = 0; i < count; ++i)
+    if (!(boxes[4 * i] <= boxes[4 * i + 2]) || !(boxes[4 * i + 1] <= boxes[4 * i + 3])) return NAVGPU_ERR_INVALID;
+  {
+    int rc = applyPendingShift(f, first, count);  // (a staged rolling-window origin is applied first: the box is in world coordinates)
+    if (rc) return rc;
+  }
+  f->touchInputs(first, count);
+  HIP_TRY(hipMemcpyAsync(f->d_bounds_tmp, boxes, sizeof(double) * 4 * count, hipMemcpyHostToDevice, f->stream));
+  launch_reset_bounding_box(cm, first, count, f->d_bounds_tmp, f->stream);
+  HIP_TRY(waitStream(f->stream));  // d_bounds_tmp and the caller's buffer are free again
+  return checkLaunch();
+}
+
 // ---- footprint helpers (costmap_2d/src/footprint.cpp, costmap_math.{h,cpp}); pure host functions
 static double fpDistance(double x0, double y0, double x1, double y1) { return hypot(x1 - x0, y1 - y0); }  // costmap_math.h:58-61
 static double fpDistanceToLine(double pX, double pY, double x0, double y0, double x1, double y1) {  // costmap_math.cpp:32-67

@@ -100,6 +100,17 @@ class Fleet:
         check(self.L.navgpu_grid_device(self.h, grid, C.byref(p), C.byref(s)), "grid_device")
         return p.value, s.value
 
+    def reset_window(self, grid, x0, y0, xn, yn, first=0, count=None):
+        """Costmap2D::resetMap(x0, y0, xn, yn) on GRID_MASTER or GRID_OBSTACLE."""
+        first, count = self._range(first, count)
+        check(self.L.navgpu_grid_reset_window(self.h, grid, first, count, x0, y0, xn, yn), "grid_reset_window")
+
+    def reset_bounding_box(self, boxes, first=0, count=None):
+        """CostmapLayer::resetBoundingBox on the obstacle / voxel layer: boxes (count, 4) = min_x, min_y, max_x, max_y (world)."""
+        first, count = self._range(first, count)
+        b = np.ascontiguousarray(np.broadcast_to(np.asarray(boxes, np.float64).reshape(-1, 4), (count, 4)))
+        check(self.L.navgpu_layer_reset_bounding_box(self.h, first, count, _ptr(b)), "layer_reset_bounding_box")
+
     # ---------------------------------------------------------------- layers
     def add_static_map(self, occupancy, first=0, count=None, track_unknown_space=True, use_maximum=False,
                        trinary_costmap=True, lethal_cost_threshold=100, unknown_cost_value=-1):

@@ -197,6 +197,14 @@ void ObstacleLayer::reset() {  // obstacle_layer.cpp:589-596: deactivate, resetM
   costmap_2d::ObstacleLayer::reset();
   if (gpu_.fleet()) navgpu_grid_reset(gpu_.fleet(), NAVGPU_GRID_OBSTACLE, 0, 1);  // + the voxel columns of a voxel fleet
 }
+void ObstacleLayer::resetMap(unsigned int x0, unsigned int y0, unsigned int xn, unsigned int yn) {
+  // Costmap2D::resetMap is what CostmapLayer::resetBoundingBox (costmap_layer.cpp:30-43; Costmap2DROS::resetBoundingBox's
+  // per-layer call) clears the layer with: the device-resident layer grid follows; the extra bounds it adds stay on the
+  // host and enter gpuUpdateBounds through useExtraBounds
+  costmap_2d::ObstacleLayer::resetMap(x0, y0, xn, yn);
+  if (gpu_.fleet() && navgpu_grid_reset_window(gpu_.fleet(), NAVGPU_GRID_OBSTACLE, 0, 1, x0, y0, xn, yn) != NAVGPU_OK)
+    ROS_ERROR("navgpu_grid_reset_window: %s", navgpu_last_error());
+}
 bool ObstacleLayer::gpuUpdateBounds(double rx, double ry, double ryaw, double* min_x, double* min_y, double* max_x, double* max_y) {
   // obstacle_layer.cpp:340-413.  The reconfigurable parameters are re-pushed every cycle (ObstaclePluginConfig's
   // callback is private to the reference class; four scalars)

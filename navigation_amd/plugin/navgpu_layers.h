@@ -96,6 +96,7 @@ class ObstacleLayer : public costmap_2d::ObstacleLayer {
   virtual void onInitialize();
   virtual void matchSize();
   virtual void reset();
+  virtual void resetMap(unsigned int x0, unsigned int y0, unsigned int xn, unsigned int yn);  // CostmapLayer::resetBoundingBox's clear
   virtual void updateBounds(double robot_x, double robot_y, double robot_yaw, double* min_x, double* min_y, double* max_x,
                             double* max_y);
   virtual void updateCosts(costmap_2d::Costmap2D& master_grid, int min_i, int min_j, int max_i, int max_j);

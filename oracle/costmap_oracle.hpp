@@ -402,6 +402,35 @@ struct StaticLayerOracle {
 // ---------------------------------------------------------------------------------------------
 struct ObstacleLayerOracle {
   Grid2D grid;  // the layer's own costmap (CostmapLayer : Layer, Costmap2D)
+  // CostmapLayer's extra bounds (costmap_layer.cpp:21-60): a box added by resetBoundingBox, taken up by the next updateBounds
+  double extra_min_x = 1e6, extra_max_x = -1e6, extra_min_y = 1e6, extra_max_y = -1e6;
+  bool has_extra_bounds = false;
+  void addExtraBounds(double mx0, double my0, double mx1, double my1) {
+    extra_min_x = std::min(mx0, extra_min_x);
+    extra_max_x = std::max(mx1, extra_max_x);
+    extra_min_y = std::min(my0, extra_min_y);
+    extra_max_y = std::max(my1, extra_max_y);
+    has_extra_bounds = true;
+  }
+  void resetBoundingBox(double min_x, double min_y, double max_x, double max_y) {  // costmap_layer.cpp:30-43 (the 2-D grid only, also for a VoxelLayer)
+    int start_x, start_y, end_x, end_y;
+    grid.worldToMapEnforceBounds(min_x, min_y, start_x, start_y);
+    grid.worldToMapEnforceBounds(max_x, max_y, end_x, end_y);
+    grid.resetMap(start_x, start_y, end_x, end_y);
+    addExtraBounds(min_x, min_y, max_x, max_y);
+  }
+  void useExtraBounds(Bounds& b) {
+    if (!has_extra_bounds) return;
+    b.min_x = std::min(extra_min_x, b.min_x);
+    b.min_y = std::min(extra_min_y, b.min_y);
+    b.max_x = std::max(extra_max_x, b.max_x);
+    b.max_y = std::max(extra_max_y, b.max_y);
+    extra_min_x = 1e6;
+    extra_min_y = 1e6;
+    extra_max_x = -1e6;
+    extra_max_y = -1e6;
+    has_extra_bounds = false;
+  }
   bool enabled = true, footprint_clearing_enabled = true;
   double max_obstacle_height = 2.0;
   int combination_method = 1;
@@ -459,6 +488,7 @@ struct ObstacleLayerOracle {
   void updateBounds(double rx, double ry, double ryaw, const std::vector<Observation>& marking,
                     const std::vector<Observation>& clearing, Bounds& b) {
     if (!enabled) return;
+    useExtraBounds(b);  // obstacle_layer.cpp:347
     for (const Observation& o : clearing) raytraceFreespace(o, b);
     for (const Observation& obs : marking) {
       double sq_obstacle_range = obs.obstacle_range * obs.obstacle_range;
@@ -706,6 +736,7 @@ struct VoxelLayerOracle : ObstacleLayerOracle {
   void updateBoundsVoxel(double rx, double ry, double ryaw, const std::vector<Observation>& marking,
                          const std::vector<Observation>& clearing, Bounds& b) {
     if (!enabled) return;
+    useExtraBounds(b);  // voxel_layer.cpp:123
     for (const Observation& o : clearing) raytraceFreespaceVoxel(o, b);
     for (const Observation& obs : marking) {
       double sq_obstacle_range = obs.obstacle_range * obs.obstacle_range;

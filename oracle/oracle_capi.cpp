@@ -158,6 +158,10 @@ void orc_lc_clear_observations(void* h) {
   lc->marking.clear();
   lc->clearing.clear();
 }
+// CostmapLayer::resetBoundingBox on the obstacle / voxel layer (what Costmap2DROS::resetBoundingBox calls per layer)
+void orc_lc_reset_bounding_box(void* h, double min_x, double min_y, double max_x, double max_y) {
+  static_cast<LayeredCostmapOracle*>(h)->olayer.resetBoundingBox(min_x, min_y, max_x, max_y);
+}
 void orc_lc_update_map(void* h, double rx, double ry, double ryaw) { static_cast<LayeredCostmapOracle*>(h)->updateMap(rx, ry, ryaw); }
 void orc_lc_get_master(void* h, uint8_t* out) {
   auto* lc = static_cast<LayeredCostmapOracle*>(h);

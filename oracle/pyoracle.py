@@ -101,6 +101,7 @@ def lib():
     sig("orc_lc_add_observation", None, vp, d, d, d, f32p, u, d, d, i, i)
     sig("orc_lc_clear_observations", None, vp)
     sig("orc_lc_update_map", None, vp, d, d, d)
+    sig("orc_lc_reset_bounding_box", None, vp, d, d, d, d)
     sig("orc_lc_get_master", None, vp, u8p)
     sig("orc_lc_set_master", None, vp, u8p)
     sig("orc_lc_get_layer", None, vp, i, u8p)
@@ -289,6 +290,10 @@ class LayeredCostmap:
 
     def update_map(self, rx=0.0, ry=0.0, ryaw=0.0):
         self.L.orc_lc_update_map(self.h, rx, ry, ryaw)
+
+    def reset_bounding_box(self, min_x, min_y, max_x, max_y):
+        """CostmapLayer::resetBoundingBox (costmap_layer.cpp:30-43) on the obstacle / voxel layer."""
+        self.L.orc_lc_reset_bounding_box(self.h, min_x, min_y, max_x, max_y)
 
     def size(self):
         sx, sy = C.c_uint32(), C.c_uint32()

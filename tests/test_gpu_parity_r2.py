@@ -953,3 +953,71 @@ def test_fleet_256_cycles_are_deterministic(nav):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), k
     assert np.array_equal(runs[0][1], runs[1][1])
     assert (runs[0][0][-1][0][:, 0] >= 0).sum() > 200
+
+
+# ----------------------------------------------------------------------------------------------
+# CostmapLayer::resetBoundingBox (costmap_layer.cpp:30-60; Costmap2DROS::resetBoundingBox's per-layer call): the obstacle
+# / voxel layer's 2-D grid is reset inside a world box and the box joins the bounds of the next update (extra bounds) -
+# so the master is rewritten there.  Marks accumulated over two cycles, a reset between cycles 2 and 3 (robot 0 a box in
+# the scanned area, robot 1 a box partly off the map), then two more cycles; non-rolling and rolling, 2-D and voxel.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("voxel,rolling", [(False, False), (True, False), (False, True), (True, True)])
+def test_layer_reset_bounding_box(nav, orc, voxel, rolling):
+    from navigation_amd import synth
+    N = L(nav)
+    n, nI = 160, 2
+    insc = synth.inscribed_radius(synth.FOOTPRINT)
+    layers = (N.LAYER_VOXEL if voxel else N.LAYER_OBSTACLE) | N.LAYER_INFLATION
+    fl = nav.Fleet(nI, n, n, synth.RES, layers=layers, track_unknown=True, max_points=720, max_observations=1, rolling_window=rolling)
+    fl.configure_obstacle()
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, insc)
+    oracles = []
+    for i in range(nI):
+        o = orc.LayeredCostmap(True)
+        o.resize(n, n, synth.RES, 0, 0)
+        o.set_rolling(rolling)
+        o.set_footprint(synth.FOOTPRINT)
+        o.add_voxel() if voxel else o.add_obstacle()
+        o.add_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, exact=True)
+        o.set_footprint(synth.FOOTPRINT)
+        oracles.append(o)
+    world = synth.make_instance(400, 91)
+    for cyc in range(5):
+        if cyc == 2:
+            boxes = np.array([[3.0, 2.5, 5.2, 4.4], [-1.0, 6.0, 2.5, 9.5]])
+            fl.reset_bounding_box(boxes)
+            for i in range(nI):
+                oracles[i].reset_bounding_box(*boxes[i])
+            ol = fl.download(N.GRID_OBSTACLE)
+            for i in range(nI):
+                assert np.array_equal(ol[i], oracles[i].layer(2)), ("layer after reset", i)
+        poses, obs = [], []
+        for i in range(nI):
+            x, y, yaw = 3.6 + 0.3 * i + (0.25 * cyc if rolling else 0.0), 3.9 - 0.2 * i, 0.5 * cyc - 0.3 * i
+            inst = dict(world)
+            inst["pos"] = np.array([x, y, yaw], np.float32)
+            pts = synth.laser_scan(inst, cyc, max_range=4.0, z=0.3, z_jitter=1.0 if voxel else None)
+            org = (float(x), float(y), 0.3)
+            poses.append([float(x), float(y), float(yaw)])
+            obs.append(dict(instance=i, points=pts, origin=org, obstacle_range=2.5, raytrace_range=3.0))
+            oracles[i].clear_observations()
+            oracles[i].add_observation(pts, origin=org, obstacle_range=2.5, raytrace_range=3.0)
+            oracles[i].update_map(*poses[-1])
+        fl.stage_observations(poses, obs)
+        fl.update_map()
+        m, ol, b = fl.master(), fl.download(N.GRID_OBSTACLE), fl.bounds()
+        for i in range(nI):
+            assert np.array_equal(b[i], oracles[i].bounds()), ("box", cyc, i, b[i], oracles[i].bounds())
+            assert np.array_equal(ol[i], oracles[i].layer(2)), ("layer", cyc, i)
+            assert np.array_equal(m[i], oracles[i].master()), ("master", cyc, i)
+        if cyc == 2 and not rolling:  # the reset box is part of this update's window
+            assert b[0][0] <= 60 and b[0][1] >= 104 and b[0][2] <= 50 and b[0][3] >= 88
+    # Costmap2D::resetMap on cell coordinates (what the Layer adapter forwards)
+    fl.reset_window(N.GRID_OBSTACLE, 10, 20, 70, 90)
+    want = [o.layer(2).copy() for o in oracles]
+    got = fl.download(N.GRID_OBSTACLE)
+    for i in range(nI):
+        want[i][20:90, 10:70] = 255
+        assert np.array_equal(got[i], want[i])
+    fl.close()
