@@ -12,10 +12,25 @@
  * the fleet's HIP stream; `navgpu_sync` (or any *_results/_download call) waits for them.
  *
  * Conventions: return 0 on success, negative navgpu_status on error (no exceptions, like the
- * reference's bool / negative-cost error channel); the caller owns every buffer it passes;
- * calls on one fleet must be serialised by the caller (the reference holds the costmap mutex
- * around both virtual calls: costmap_2d/src/layered_costmap.cpp:83, move_base/src/move_base.cpp:947).
+ * reference's bool / negative-cost error channel); the caller owns every buffer it passes.
  * There is NO CPU fallback: without a usable HIP device `navgpu_fleet_create` fails.
+ *
+ * Threading: every entry point that takes a fleet (or a navgpu_navfn handle) holds that handle's
+ * own recursive mutex for its whole body and makes the handle's GPU current on the calling thread,
+ * so calls on ONE handle from several host threads are serialised inside the library: a
+ * reconfigure (navgpu_planner_configure, navgpu_inflation_configure, navgpu_obstacle_configure,
+ * navgpu_set_footprint ...) issued by a second thread while another is inside a stage / update /
+ * cycle waits for that call to return, drains the stream before it frees or re-allocates a device
+ * table, and a call that fails leaves the previous configuration in force.  This is the role of
+ * DWAPlanner::configuration_mutex_ (dwa_local_planner/src/dwa_planner.cpp:55,301) and
+ * InflationLayer::inflation_access_ (costmap_2d/plugins/inflation_layer.cpp:68,112,175).  What the
+ * library cannot know is which calls form ONE control cycle: a caller that must not see a
+ * reconfigure land between its stage and its cycle holds its own lock around the pair, as the
+ * adapters do (navgpu::DWAPlannerROS::configuration_mutex_, the layers' gpu_access_ /
+ * inflation_access_), next to the master-costmap mutex the reference already holds around both
+ * virtual calls (costmap_2d/src/layered_costmap.cpp:83, move_base/src/move_base.cpp:947).
+ * navgpu_fleet_destroy / navgpu_navfn_destroy must not race any other call on the same handle.
+ * Distinct handles are independent.  navgpu_last_error is per thread.
  */
 #ifndef NAVGPU_H_
 #define NAVGPU_H_
@@ -585,7 +600,11 @@ typedef struct {
   int32_t allow_unknown;      /* Expander::setHasUnknown                                                                     */
   int32_t lethal_cost, neutral_cost; /* GlobalPlanner.cfg: 253, 50                                                           */
   float cost_factor;          /* GlobalPlanner.cfg: 3.0                                                                      */
-  int32_t outline_map;        /* 1: GlobalPlanner::outlineMap(costs, nx, ny, LETHAL_OBSTACLE) first, as makePlan does (:296) */
+  int32_t outline_map;        /* 1: GlobalPlanner::outlineMap(costs, nx, ny, LETHAL_OBSTACLE) first, as makePlan does (:296).
+                               * With 0, or with lethal_cost 255 under A*, border cells can be expanded; the reference then
+                               * reads potential[] / costs[] one row outside its arrays.  Here such neighbours read as
+                               * unreached lethal cells (never outside device memory); results on maps whose expansion
+                               * stays off the border are unchanged                                                          */
   int32_t reserved;
 } navgpu_global_planner_params;
 /* replaces: the body of GlobalPlanner::makePlan between worldToMap and the plan assembly (planner_core.cpp:250-311):

@@ -326,15 +326,20 @@ __global__ __launch_bounds__(256) void k_gp_plan(NavfnDev nv, uint32_t first, na
   __syncthreads();
   if (threadIdx.x != 0) return;
 
+  // A border cell can enter the expansion when nothing outlines the map (gp.outline_map == 0) or when the outline's 254 is
+  // below lethal_cost (A* with lethal_cost 255).  The reference then reads potential[n - nx] / costs[n + nx] outside its
+  // arrays (harmless garbage on the CPU heap); here every neighbour access goes through potAt() / getCost(), which give
+  // an off-array cell the values of an unreached lethal one.  In-array reads are unchanged, bit for bit.
+  auto potAt = [&](int n) -> float { return (n >= 0 && n < ns) ? potential[n] : kHigh; };
   auto calculatePotential = [&](uint8_t cost, int n, float prev_potential) -> float {
     if (!quadratic) {
       if (prev_potential < 0) {
-        const float min_h = fminf(potential[n - 1], potential[n + 1]), min_v = fminf(potential[n - nx], potential[n + nx]);
+        const float min_h = fminf(potAt(n - 1), potAt(n + 1)), min_v = fminf(potAt(n - nx), potAt(n + nx));
         prev_potential = fminf(min_h, min_v);
       }
       return prev_potential + cost;
     }
-    const float l = potential[n - 1], r = potential[n + 1], u = potential[n - nx], d = potential[n + nx];
+    const float l = potAt(n - 1), r = potAt(n + 1), u = potAt(n - nx), d = potAt(n + nx);
     float ta, tc;
     if (l < r) tc = l; else tc = r;
     if (u < d) ta = u; else ta = d;
@@ -350,6 +355,7 @@ __global__ __launch_bounds__(256) void k_gp_plan(NavfnDev nv, uint32_t first, na
     return ta + hf * v;
   };
   auto getCost = [&](int n) -> float {
+    if (n < 0 || n >= ns) return lethal;
     float c = costs[n];
     if (c < lethal - 1 || (unknown && c == 255)) {
       c = c * factor + neutral;
@@ -418,15 +424,15 @@ __global__ __launch_bounds__(256) void k_gp_plan(NavfnDev nv, uint32_t first, na
           const float de = (float)(0.707106781 * (float)getCost(n + nx));
           potential[n] = pot;
           if (pot < threshold) {
-            if (potential[n - 1] > pot + le) push(nxt, nxtE, n - 1);
-            if (potential[n + 1] > pot + re) push(nxt, nxtE, n + 1);
-            if (potential[n - nx] > pot + ue) push(nxt, nxtE, n - nx);
-            if (potential[n + nx] > pot + de) push(nxt, nxtE, n + nx);
+            if (potAt(n - 1) > pot + le) push(nxt, nxtE, n - 1);
+            if (potAt(n + 1) > pot + re) push(nxt, nxtE, n + 1);
+            if (potAt(n - nx) > pot + ue) push(nxt, nxtE, n - nx);
+            if (potAt(n + nx) > pot + de) push(nxt, nxtE, n + nx);
           } else {
-            if (potential[n - 1] > pot + le) push(ovr, ovrE, n - 1);
-            if (potential[n + 1] > pot + re) push(ovr, ovrE, n + 1);
-            if (potential[n - nx] > pot + ue) push(ovr, ovrE, n - nx);
-            if (potential[n + nx] > pot + de) push(ovr, ovrE, n + nx);
+            if (potAt(n - 1) > pot + le) push(ovr, ovrE, n - 1);
+            if (potAt(n + 1) > pot + re) push(ovr, ovrE, n + 1);
+            if (potAt(n - nx) > pot + ue) push(ovr, ovrE, n - nx);
+            if (potAt(n + nx) > pot + de) push(ovr, ovrE, n + nx);
           }
         }
       }
@@ -533,8 +539,8 @@ __global__ __launch_bounds__(256) void k_gp_plan(NavfnDev nv, uint32_t first, na
   };
   if (found_legal && !gp.use_grid_path) {  // GradientPath::getPath (gradient_path.cpp:68-248)
     auto gradCell = [&](int n) {
+      if (n < nx || n > nx * ny - nx) return;  // (the reference tests this second: its gradx_[n] read may lie past the array)
       if (gradx[n] + grady[n] > 0.0) return;
-      if (n < nx || n > nx * ny - nx) return;
       const float cv = potential[n];
       float dx = 0.0f, dy = 0.0f;
       if (cv >= kHigh) {
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(256) void k_gp_plan(NavfnDev nv, uint32_t first, na
         if (potential[n - 1] < kHigh) dx += potential[n - 1] - cv;
         if (potential[n + 1] < kHigh) dx += cv - potential[n + 1];
         if (potential[n - nx] < kHigh) dy += potential[n - nx] - cv;
-        if (potential[n + nx] < kHigh) dy += cv - potential[n + nx];
+        if (potAt(n + nx) < kHigh) dy += cv - potAt(n + nx);  // (n = ns - nx passes the test above)
       }
       float norm = (float)hypot((double)dx, (double)dy);
       if (norm > 0) {
@@ -574,15 +580,15 @@ __global__ __launch_bounds__(256) void k_gp_plan(NavfnDev nv, uint32_t first, na
       pushPoint((float)px, (float)py);
       const bool oscillation_detected = npath > 2 && last3x[2] == last3x[0] && last3y[2] == last3y[0];
       const int stcnx = stc + nx, stcpx = stc - nx;
-      if (potential[stc] >= kHigh || potential[stc + 1] >= kHigh || potential[stc - 1] >= kHigh || potential[stcnx] >= kHigh ||
-          potential[stcnx + 1] >= kHigh || potential[stcnx - 1] >= kHigh || potential[stcpx] >= kHigh || potential[stcpx + 1] >= kHigh ||
-          potential[stcpx - 1] >= kHigh || oscillation_detected) {
+      if (potential[stc] >= kHigh || potAt(stc + 1) >= kHigh || potAt(stc - 1) >= kHigh || potAt(stcnx) >= kHigh ||
+          potAt(stcnx + 1) >= kHigh || potAt(stcnx - 1) >= kHigh || potAt(stcpx) >= kHigh || potAt(stcpx + 1) >= kHigh ||
+          potAt(stcpx - 1) >= kHigh || oscillation_detected) {
         int minc = stc;
         int minp = truncX86(potential[stc]);
         const int nb[8] = {stcpx - 1, stcpx, stcpx + 1, stc - 1, stc + 1, stcnx - 1, stcnx, stcnx + 1};
         for (int q = 0; q < 8; ++q)
-          if (potential[nb[q]] < (float)minp) {
-            minp = (int)potential[nb[q]];
+          if (potAt(nb[q]) < (float)minp) {
+            minp = (int)potAt(nb[q]);
             minc = nb[q];
           }
         stc = minc;
@@ -594,11 +600,12 @@ __global__ __launch_bounds__(256) void k_gp_plan(NavfnDev nv, uint32_t first, na
         gradCell(stc + 1);
         gradCell(stcnx);
         gradCell(stcnx + 1);
-        const float x1 = (float)((1.0 - dx) * gradx[stc] + dx * gradx[stc + 1]);
-        const float x2 = (float)((1.0 - dx) * gradx[stcnx] + dx * gradx[stcnx + 1]);
+        auto gAt = [&](const float* g, int n) -> float { return n < ns ? g[n] : 0.0f; };  // (stc on the last row: the reference reads past its arrays)
+        const float x1 = (float)((1.0 - dx) * gradx[stc] + dx * gAt(gradx, stc + 1));
+        const float x2 = (float)((1.0 - dx) * gAt(gradx, stcnx) + dx * gAt(gradx, stcnx + 1));
         const float x = (float)((1.0 - dy) * x1 + dy * x2);
-        const float y1 = (float)((1.0 - dx) * grady[stc] + dx * grady[stc + 1]);
-        const float y2 = (float)((1.0 - dx) * grady[stcnx] + dx * grady[stcnx + 1]);
+        const float y1 = (float)((1.0 - dx) * grady[stc] + dx * gAt(grady, stc + 1));
+        const float y2 = (float)((1.0 - dx) * gAt(grady, stcnx) + dx * gAt(grady, stcnx + 1));
         const float y = (float)((1.0 - dy) * y1 + dy * y2);
         if (x == 0.0 && y == 0.0) break;
         const float ss = (float)(0.5f / hypot((double)x, (double)y));  // pathStep_ = 0.5 (:47)

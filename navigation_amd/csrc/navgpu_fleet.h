@@ -6,8 +6,10 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -40,6 +42,12 @@ int ensureCompleteGrids(navgpu_fleet* f, uint32_t first, uint32_t count);
 
 struct navgpu_fleet {
   navgpu_fleet_desc desc{};
+  // Every entry point that takes the fleet holds this for its whole body (FleetGuard): the calls on one fleet are
+  // serialised INSIDE the library, so a reconfigure from another host thread (dynamic_reconfigure's spinner thread:
+  // DWAPlanner::configuration_mutex_, dwa_planner.cpp:55,301; InflationLayer::inflation_access_,
+  // inflation_layer.cpp:68,112,175) can never run beside a stage / update / cycle of the same fleet.  Recursive because
+  // the control-cycle mirror (navgpu_local_planner_*) calls other entry points.
+  std::recursive_mutex mu;
   hipStream_t stream = nullptr;
   CostmapDev cm{};
   PlannerDev pl{};
@@ -119,6 +127,11 @@ struct navgpu_fleet {
   int alloc(T** p, size_t count) {
     void* q = nullptr;
     size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    if (const char* lim = getenv("NAVGPU_DEBUG_ALLOC_LIMIT"))  // tests: make a large allocation fail on purpose
+      if (bytes > strtoull(lim, nullptr, 10)) {
+        g_last_error = "hipMalloc: refused by NAVGPU_DEBUG_ALLOC_LIMIT";
+        return NAVGPU_ERR_HIP;
+      }
     hipError_t e = hipMalloc(&q, bytes);
     if (e != hipSuccess) {
       g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
@@ -189,6 +202,19 @@ struct navgpu_fleet {
     return NAVGPU_OK;
   }
 };
+
+// lock + "this thread talks to the fleet's GPU" (hipSetDevice is per host thread: a caller's second thread starts on
+// device 0 whatever device the fleet lives on)
+#ifndef NAVGPU_TEST_NO_FLEET_LOCK
+struct FleetGuard {
+  std::lock_guard<std::recursive_mutex> lk;
+  explicit FleetGuard(navgpu_fleet* f) : lk(f->mu) { (void)hipSetDevice(f->desc.device); }
+};
+#else  // negative control of tests/test_fleet_threads_tsan.py only: ThreadSanitizer must object to this build
+struct FleetGuard {
+  explicit FleetGuard(navgpu_fleet* f) { (void)hipSetDevice(f->desc.device); }
+};
+#endif
 
 #define PROFILED(fleet, kid, launch_expr)            \
   do {                                               \

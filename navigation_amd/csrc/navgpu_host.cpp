@@ -232,6 +232,7 @@ int navgpu_fleet_destroy(navgpu_fleet* f) {
 }
 int navgpu_sync(navgpu_fleet* f) {
   if (!f) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   HIP_TRY(waitStream(f->stream));
   return NAVGPU_OK;
 }
@@ -239,6 +240,7 @@ void* navgpu_stream(navgpu_fleet* f) { return f ? (void*)f->stream : nullptr; }
 
 int navgpu_fleet_set_origin(navgpu_fleet* f, uint32_t first, uint32_t count, const double* xy) {
   if (!f || !xy || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   f->touchInputs(first, count);
   memcpy(&f->h_origin[(size_t)first * 2], xy, sizeof(double) * 2 * count);
   HIP_TRY(hipMemcpyAsync(f->cm.origin + (size_t)first * 2, xy, sizeof(double) * 2 * count, hipMemcpyHostToDevice, f->stream));
@@ -248,6 +250,7 @@ int navgpu_fleet_set_origin(navgpu_fleet* f, uint32_t first, uint32_t count, con
 
 int navgpu_fleet_get_origin(navgpu_fleet* f, uint32_t first, uint32_t count, double* xy) {
   if (!f || !xy || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   memcpy(xy, &f->h_origin[(size_t)first * 2], sizeof(double) * 2 * count);
   return NAVGPU_OK;
 }
@@ -271,6 +274,7 @@ static int gridInfo(navgpu_fleet* f, int grid, void** base, size_t* elem, size_t
 }
 int navgpu_grid_upload(navgpu_fleet* f, int grid, uint32_t first, uint32_t count, const void* host) {
   if (!f || !host || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   f->touchInputs(first, count);
   void* base;
   size_t elem, stride, used;
@@ -285,6 +289,7 @@ int navgpu_grid_upload(navgpu_fleet* f, int grid, uint32_t first, uint32_t count
 }
 int navgpu_grid_download(navgpu_fleet* f, int grid, uint32_t first, uint32_t count, void* host) {
   if (!f || !host || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   void* base;
   size_t elem, stride, used;
   int rc = gridInfo(f, grid, &base, &elem, &stride, &used);
@@ -297,6 +302,7 @@ int navgpu_grid_download(navgpu_fleet* f, int grid, uint32_t first, uint32_t cou
 }
 int navgpu_grid_device(navgpu_fleet* f, int grid, void** ptr, size_t* stride_bytes) {
   if (!f || !ptr) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   void* base;
   size_t elem, stride, used;
   int rc = gridInfo(f, grid, &base, &elem, &stride, &used);
@@ -308,6 +314,7 @@ int navgpu_grid_device(navgpu_fleet* f, int grid, void** ptr, size_t* stride_byt
 }
 int navgpu_grid_reset(navgpu_fleet* f, int grid, uint32_t first, uint32_t count) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   f->touchInputs(first, count);
   CostmapDev& cm = f->cm;
   switch (grid) {
@@ -329,6 +336,7 @@ int navgpu_grid_reset(navgpu_fleet* f, int grid, uint32_t first, uint32_t count)
 static int applyPendingShift(navgpu_fleet* f, uint32_t first, uint32_t count);
 int navgpu_grid_reset_window(navgpu_fleet* f, int grid, uint32_t first, uint32_t count, uint32_t x0, uint32_t y0, uint32_t xn, uint32_t yn) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   CostmapDev& cm = f->cm;
   if (xn > cm.nx || yn > cm.ny || x0 > xn || y0 > yn) return NAVGPU_ERR_INVALID;  // (the reference's memset length underflows for xn < x0)
   uint8_t* base = nullptr;
@@ -345,6 +353,7 @@ int navgpu_grid_reset_window(navgpu_fleet* f, int grid, uint32_t first, uint32_t
 }
 int navgpu_layer_reset_bounding_box(navgpu_fleet* f, uint32_t first, uint32_t count, const double* boxes) {
   if (!f || !boxes || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   CostmapDev& cm = f->cm;
   if (!cm.obst) return NAVGPU_ERR_STATE;
   for (uint32_t i = 0; i < count; ++i)
@@ -415,6 +424,7 @@ int navgpu_footprint_from_radius(double radius, double* xy16) {  // footprint.cp
 /* Costmap2DPublisher view of a window of the master grid */
 int navgpu_costmap_export(navgpu_fleet* f, uint32_t instance, uint32_t x0, uint32_t y0, uint32_t xn, uint32_t yn, int8_t* out) {
   if (!f || !out || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   const CostmapDev& cm = f->cm;
   if (x0 >= xn || y0 >= yn || xn > cm.nx || yn > cm.ny) return NAVGPU_ERR_INVALID;
   if (!f->d_occ) {
@@ -432,6 +442,7 @@ int navgpu_costmap_export(navgpu_fleet* f, uint32_t instance, uint32_t x0, uint3
 int navgpu_static_set_map(navgpu_fleet* f, uint32_t first, uint32_t count, const int8_t* occ, int32_t track_unknown_space,
                           int32_t use_maximum, int32_t trinary, int32_t lethal_cost_threshold, int32_t unknown_cost_value) {
   if (!f || !occ || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   CostmapDev& cm = f->cm;
   if (!cm.stat) return NAVGPU_ERR_STATE;
   if (!f->d_occ) {
@@ -458,6 +469,7 @@ int navgpu_static_set_rolling_map(navgpu_fleet* f, const int8_t* occ, uint32_t s
                                   double origin_y, int32_t track_unknown_space, int32_t use_maximum, int32_t trinary, int32_t lethal_cost_threshold,
                                   int32_t unknown_cost_value) {
   if (!f || !occ || size_x == 0 || size_y == 0 || !(resolution > 0)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   CostmapDev& cm = f->cm;
   if (!f->desc.rolling_window || !(cm.layers & NAVGPU_LAYER_STATIC) || !cm.stat_tf) {
     g_last_error = "navgpu_static_set_rolling_map needs a rolling_window fleet with NAVGPU_LAYER_STATIC (else: navgpu_static_set_map)";
@@ -474,11 +486,18 @@ int navgpu_static_set_rolling_map(navgpu_fleet* f, const int8_t* occ, uint32_t s
     f->release(d_in);
     return rc;
   }
-  HIP_TRY(hipMemcpyAsync(d_in, occ, cells, hipMemcpyHostToDevice, f->stream));
   const int lethal = std::max(std::min(lethal_cost_threshold, 100), 0);  // static_layer.cpp:80
-  launch_static_interpret(d_map, d_in, (uint32_t)cells, (uint32_t)cells, 1, track_unknown_space, trinary, lethal, unknown_cost_value, f->stream);
-  HIP_TRY(waitStream(f->stream));
+  hipError_t e = hipMemcpyAsync(d_in, occ, cells, hipMemcpyHostToDevice, f->stream);
+  if (e == hipSuccess) {
+    launch_static_interpret(d_map, d_in, (uint32_t)cells, (uint32_t)cells, 1, track_unknown_space, trinary, lethal, unknown_cost_value, f->stream);
+    e = waitStream(f->stream);
+  }
   f->release(d_in);
+  if (e != hipSuccess) {  // nothing of the previous map has been touched yet
+    f->release(d_map);
+    g_last_error = std::string("navgpu_static_set_rolling_map: ") + hipGetErrorString(e);
+    return NAVGPU_ERR_HIP;
+  }
   if (cm.stat_roll) f->release(cm.stat_roll);
   cm.stat_roll = d_map;
   cm.stat_nx = size_x;
@@ -494,6 +513,7 @@ int navgpu_static_set_rolling_map(navgpu_fleet* f, const int8_t* occ, uint32_t s
 
 int navgpu_static_set_transform(navgpu_fleet* f, uint32_t first, uint32_t count, const double* m) {
   if (!f || !m || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->cm.stat_tf) return NAVGPU_ERR_STATE;
   HIP_TRY(hipMemcpyAsync(f->cm.stat_tf + (size_t)first * 12, m, sizeof(double) * 12 * count, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(waitStream(f->stream));  // the caller's buffer is free on return
@@ -503,6 +523,7 @@ int navgpu_static_set_transform(navgpu_fleet* f, uint32_t first, uint32_t count,
 
 int navgpu_obstacle_configure(navgpu_fleet* f, const navgpu_obstacle_params* p) {
   if (!f || !p) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (p->z_voxels < 0 || p->z_voxels > 16) return NAVGPU_ERR_INVALID;
   CostmapDev& cm = f->cm;
   f->obsp = *p;
@@ -522,7 +543,14 @@ int navgpu_obstacle_configure(navgpu_fleet* f, const navgpu_obstacle_params* p) 
 
 int navgpu_inflation_configure(navgpu_fleet* f, const navgpu_inflation_params* p) {
   if (!f || !p) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   CostmapDev& cm = f->cm;
+  // the exact-EDT kernel takes the max over candidate seeds; that equals "cost of the nearest
+  // seed" only if the table is monotone in distance — true for cost_scaling_factor >= 0.
+  if (p->cost_scaling_factor < 0) {
+    g_last_error = "cost_scaling_factor < 0 is not supported";
+    return NAVGPU_ERR_INVALID;
+  }
   // cellDistance (costmap_2d.cpp:181-185)
   double cells_dist = std::max(0.0, ceil(p->inflation_radius / cm.res));
   if (cells_dist > 64) return NAVGPU_ERR_CAPACITY;
@@ -547,18 +575,13 @@ int navgpu_inflation_configure(navgpu_fleet* f, const navgpu_inflation_params* p
       if (distance > R) cost = 0;
       lut[(size_t)i * n + j] = cost;
     }
-  // the exact-EDT kernel takes the max over candidate seeds; that equals "cost of the nearest
-  // seed" only if the table is monotone in distance — true for cost_scaling_factor >= 0.
-  if (p->cost_scaling_factor < 0) {
-    g_last_error = "cost_scaling_factor < 0 is not supported";
-    return NAVGPU_ERR_INVALID;
-  }
-  HIP_TRY(hipMemcpyAsync(cm.lut, lut.data(), lut.size(), hipMemcpyHostToDevice, f->stream));
   // reference-order mode: cached_distances_ (hypot by this host's libm, as the reference builds them) and the
-  // priority queue's storage - every cell is pushed at most once by each of its four neighbours, plus once as a seed
+  // priority queue's storage - every cell is pushed at most once by each of its four neighbours, plus once as a seed.
+  // Everything that can fail (limits, allocations) comes BEFORE the first write to the configuration in use: a failed
+  // reconfigure leaves the previous one intact.
   std::vector<double> dist_lut((size_t)n * n);
-  cm.infl_pq = p->priority_queue_order ? 1 : 0;
-  if (cm.infl_pq) {
+  const int want_pq = p->priority_queue_order ? 1 : 0;
+  if (want_pq) {
     for (uint32_t i = 0; i < n; ++i)
       for (uint32_t j = 0; j < n; ++j) dist_lut[(size_t)i * n + j] = hypot(i, j);
     if (cm.nx > 65535 || cm.ny > 65535) return NAVGPU_ERR_CAPACITY;
@@ -566,10 +589,10 @@ int navgpu_inflation_configure(navgpu_fleet* f, const navgpu_inflation_params* p
     if (!cm.dist_lut && (rc = f->alloc(&cm.dist_lut, (size_t)66 * 66))) return rc;
     if (!cm.pq_seen && (rc = f->alloc(&cm.pq_seen, (size_t)f->desc.n_instances * cm.cells_padded))) return rc;
     if (!cm.pq_heap) {
-      cm.pq_cap = (uint64_t)5 * cm.cells;
-      if ((rc = f->alloc(&cm.pq_heap, (size_t)f->desc.n_instances * cm.pq_cap))) return rc;
+      const uint64_t cap = (uint64_t)5 * cm.cells;
+      if ((rc = f->alloc(&cm.pq_heap, (size_t)f->desc.n_instances * cap))) return rc;
+      cm.pq_cap = cap;
     }
-    HIP_TRY(hipMemcpyAsync(cm.dist_lut, dist_lut.data(), sizeof(double) * dist_lut.size(), hipMemcpyHostToDevice, f->stream));
   }
   // cost by squared distance for the bit-parallel kernel: max over the (i, j) pairs that share d^2,
   // usable only if it is non-increasing in d^2 (then max-over-seeds == cost of the nearest seed)
@@ -593,9 +616,15 @@ int navgpu_inflation_configure(navgpu_fleet* f, const navgpu_inflation_params* p
       prev = lut2[d2];
     }
   }
-  HIP_TRY(hipMemcpyAsync(cm.lut2, lut2.data(), lut2.size(), hipMemcpyHostToDevice, f->stream));
-  cm.lut2_ok = lut2_ok ? 1 : 0;
+  // the tables are read by kernels already queued on the stream: upload behind them, commit the scalars only once all
+  // three uploads have been accepted (the kernels of later calls take cm by value)
   HIP_TRY(waitStream(f->stream));
+  HIP_TRY(hipMemcpyAsync(cm.lut, lut.data(), lut.size(), hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(hipMemcpyAsync(cm.lut2, lut2.data(), lut2.size(), hipMemcpyHostToDevice, f->stream));
+  if (want_pq) HIP_TRY(hipMemcpyAsync(cm.dist_lut, dist_lut.data(), sizeof(double) * dist_lut.size(), hipMemcpyHostToDevice, f->stream));
+  HIP_TRY(waitStream(f->stream));
+  cm.infl_pq = want_pq;
+  cm.lut2_ok = lut2_ok ? 1 : 0;
   const bool changed = !f->inflation_configured || f->infl.inflation_radius != p->inflation_radius ||
                        f->infl.cost_scaling_factor != p->cost_scaling_factor || f->infl.inscribed_radius != p->inscribed_radius ||
                        f->infl.enabled != p->enabled || f->infl.priority_queue_order != p->priority_queue_order;
@@ -674,6 +703,7 @@ static int ensurePrep(navgpu_fleet* f) {
 
 int navgpu_set_footprint(navgpu_fleet* f, uint32_t first, uint32_t count, const double* xy, uint32_t nv) {
   if (!f || !f->rangeOk(first, count) || (nv && !xy)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (nv > f->desc.max_footprint || nv > (uint32_t)kMaxFootprint) return NAVGPU_ERR_CAPACITY;
   for (uint32_t i = first; i < first + count; ++i) {
     f->h_fp_n[i] = nv;
@@ -696,6 +726,7 @@ int navgpu_set_footprint(navgpu_fleet* f, uint32_t first, uint32_t count, const 
 int navgpu_costmap_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const double* poses, const navgpu_observation* obs,
                          uint32_t n_obs, const float* points, uint32_t n_points_total) {
   if (!f || !poses || !f->rangeOk(first, count) || (n_obs && (!obs || (!points && n_points_total)))) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   CostmapDev& cm = f->cm;
   if (f->desc.rolling_window && f->shift_pending) return NAVGPU_ERR_STATE;  // previous stage not consumed by an update yet
   if (f->desc.rolling_window) f->touchInputs(first, count);  // the origins move now
@@ -789,6 +820,7 @@ static int applyPendingShift(navgpu_fleet* f, uint32_t first, uint32_t count) {
 
 int navgpu_costmap_update(navgpu_fleet* f, uint32_t first, uint32_t count) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   f->touchInputs(first, count);
   CostmapDev& cm = f->cm;
   if ((cm.layers & NAVGPU_LAYER_INFLATION) && !f->inflation_configured) return NAVGPU_ERR_STATE;
@@ -804,6 +836,7 @@ int navgpu_costmap_update(navgpu_fleet* f, uint32_t first, uint32_t count) {
 
 int navgpu_costmap_bounds(navgpu_fleet* f, uint32_t first, uint32_t count, int32_t* boxes) {
   if (!f || !boxes || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   std::vector<InstCostmapState> st(count);
   HIP_TRY(hipMemcpyAsync(st.data(), f->cm.state + first, sizeof(InstCostmapState) * count, hipMemcpyDeviceToHost, f->stream));
   HIP_TRY(waitStream(f->stream));
@@ -814,6 +847,7 @@ int navgpu_costmap_bounds(navgpu_fleet* f, uint32_t first, uint32_t count, int32
 
 int navgpu_inflate(navgpu_fleet* f, uint32_t first, uint32_t count, const int32_t* boxes) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   f->touchInputs(first, count);
   if (!f->inflation_configured) return NAVGPU_ERR_STATE;
   const int32_t* d_boxes = nullptr;
@@ -828,6 +862,7 @@ int navgpu_inflate(navgpu_fleet* f, uint32_t first, uint32_t count, const int32_
 
 int navgpu_obstacle_update_bounds(navgpu_fleet* f, uint32_t first, uint32_t count, double* bounds) {
   if (!f || !bounds || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->cm.obst) return NAVGPU_ERR_STATE;
   {
     int rc = applyPendingShift(f, first, count);  // ObstacleLayer::updateBounds :344-345: updateOrigin first
@@ -842,6 +877,7 @@ int navgpu_obstacle_update_bounds(navgpu_fleet* f, uint32_t first, uint32_t coun
 
 int navgpu_obstacle_update_costs(navgpu_fleet* f, uint32_t first, uint32_t count, const int32_t* boxes) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   f->touchInputs(first, count);
   const int32_t* d_boxes = nullptr;
   if (boxes) {
@@ -945,21 +981,24 @@ static int restageReach(navgpu_fleet* f) {
 
 int navgpu_planner_set_bounded_map_grids(navgpu_fleet* f, int32_t enable) {
   if (!f) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   f->bounded_grids = enable != 0;
   return restageReach(f);
 }
 int navgpu_planner_set_map_grid_options(navgpu_fleet* f, int32_t critic, int32_t aggregation, double yshift) {
   if (!f || critic < 0 || critic > 3 || aggregation < 0 || aggregation > 2 || !std::isfinite(yshift)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   PlannerDev& pl = f->pl;
   pl.mg_agg[critic] = aggregation;
   pl.mg_yshift[critic] = yshift;
   pl.mg_generic = 0;
   for (int k = 0; k < 4; ++k)
     if (pl.mg_agg[k] != 0 || pl.mg_yshift[k] != 0.0) pl.mg_generic = 1;
-  return restageReach(f);
+  return restageReach(f);  // (grids a bounded cycle left behind: navgpu_planner_check_trajectory completes them first)
 }
 int navgpu_planner_wavefront_levels(navgpu_fleet* f, uint32_t first, uint32_t count, uint32_t* levels) {
   if (!f || !levels || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   HIP_TRY(hipMemcpyAsync(levels, f->pl.bfs_levels + (size_t)first * 3, sizeof(uint32_t) * 3 * count, hipMemcpyDeviceToHost, f->stream));
   HIP_TRY(waitStream(f->stream));
   return NAVGPU_OK;
@@ -967,6 +1006,7 @@ int navgpu_planner_wavefront_levels(navgpu_fleet* f, uint32_t first, uint32_t co
 
 int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
   if (!f || !c) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!(c->sim_time > 0) || !(c->sim_granularity > 0) || !(c->angular_sim_granularity > 0)) return NAVGPU_ERR_INVALID;
   PlannerDev& pl = f->pl;
   navgpu_dwa_config cfg = *c;
@@ -1038,6 +1078,7 @@ int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
 
 int navgpu_planner_set_plan(navgpu_fleet* f, uint32_t first, uint32_t count) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   HIP_TRY(hipMemsetAsync(f->pl.osc_flags + first, 0, sizeof(uint32_t) * count, f->stream));  // resetOscillationFlags
   return NAVGPU_OK;
 }
@@ -1045,6 +1086,7 @@ int navgpu_planner_set_plan(navgpu_fleet* f, uint32_t first, uint32_t count) {
 int navgpu_planner_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const navgpu_robot_state* states, const double* plan_xy,
                          uint32_t n_plan_total) {
   if (!f || !states || !plan_xy || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->planner_configured) return NAVGPU_ERR_STATE;
   PlannerDev& pl = f->pl;
   const navgpu_dwa_config& c = pl.cfg;
@@ -1088,6 +1130,7 @@ int navgpu_planner_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
 // never waits for the stream.
 int navgpu_planner_stage_poses(navgpu_fleet* f, uint32_t first, uint32_t count, const float* pos_xyth, const float* vel_xyth) {
   if (!f || !pos_xyth || !vel_xyth || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->planner_configured || !f->planner_staged) return NAVGPU_ERR_STATE;
   PlannerDev& pl = f->pl;
   const navgpu_dwa_config& c = pl.cfg;
@@ -1139,6 +1182,7 @@ int navgpu_planner_stage_poses(navgpu_fleet* f, uint32_t first, uint32_t count, 
 // {0, nx-1, 0, ny-1} for a robot whose grids were searched whole
 int navgpu_planner_wavefront_boxes(navgpu_fleet* f, uint32_t first, uint32_t count, int32_t* boxes) {
   if (!f || !boxes || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   for (uint32_t li = 0; li < count; ++li) {
     const uint32_t i = first + li;
     if (f->grid_partial[i])
@@ -1165,6 +1209,7 @@ extern "C" int navgpu_debug_prep_image(navgpu_fleet* f, uint32_t inst, uint8_t* 
 #endif
 int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->planner_configured || !f->planner_staged) return NAVGPU_ERR_STATE;
   PlannerDev& pl = f->pl;
   pl.bfs_bounded = 1;  // per robot: bfs_reach (0 = whole grid)
@@ -1194,6 +1239,7 @@ int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
 
 int navgpu_planner_results(navgpu_fleet* f, uint32_t first, uint32_t count, navgpu_plan_result* results) {
   if (!f || !results || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   // zero-copy: the results already sit in pinned host memory once the stream has drained (an explicit
   // D2H copy was measured at ~4 ms per call when another HIP user, e.g. PyTorch, shares the process)
   static const bool dbg = getenv("NAVGPU_DEBUG_TIMING") != nullptr;
@@ -1212,6 +1258,7 @@ int navgpu_planner_results(navgpu_fleet* f, uint32_t first, uint32_t count, navg
 
 int navgpu_planner_trajectory(navgpu_fleet* f, uint32_t instance, double* xyth, uint32_t cap) {
   if (!f || !xyth || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   HIP_TRY(waitStream(f->stream));
   const navgpu_plan_result r = f->hp_result[instance];
   uint32_t n = std::min<uint32_t>(r.n_points > 0 ? r.n_points : 0, cap);
@@ -1224,6 +1271,7 @@ int navgpu_planner_trajectory(navgpu_fleet* f, uint32_t instance, double* xyth, 
 
 int navgpu_planner_samples(navgpu_fleet* f, uint32_t instance, double* costs, int32_t* status, float* vel, uint32_t cap) {
   if (!f || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   PlannerDev& pl = f->pl;
   if (!pl.sample_cost) return NAVGPU_ERR_STATE;
   int32_t cnt[4];
@@ -1247,6 +1295,7 @@ int navgpu_planner_samples(navgpu_fleet* f, uint32_t instance, double* costs, in
 
 int navgpu_planner_check_trajectory(navgpu_fleet* f, uint32_t instance, const float vs[3], int32_t* ok) {
   if (!f || !vs || !ok || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->planner_configured || !f->planner_staged) return NAVGPU_ERR_STATE;
   PlannerDev& pl = f->pl;
   if (f->grid_partial[instance]) {  // the sample must stay inside the box the last wavefronts settled
@@ -1254,7 +1303,9 @@ int navgpu_planner_check_trajectory(navgpu_fleet* f, uint32_t instance, const fl
     const uint32_t need = (uint32_t)std::min(ceil(reachMetres(pl.cfg, st.vel, vs) / pl.res) + 3.0, 32768.0);
     int32_t nb[4];
     const int32_t* hb = &f->h_box[(size_t)4 * instance];
-    const bool inside = robotBox(f, instance, st.pos, need, nb) && nb[0] >= hb[0] && nb[1] <= hb[1] && nb[2] >= hb[2] && nb[3] <= hb[3];
+    // (a sideways-shifted look-up - navgpu_planner_set_map_grid_options after the cycle - leaves the box reachMetres
+    // describes: those always get complete grids)
+    const bool inside = !pl.mg_generic && robotBox(f, instance, st.pos, need, nb) && nb[0] >= hb[0] && nb[1] <= hb[1] && nb[2] >= hb[2] && nb[3] <= hb[3];
     if (!inside) {
       int rc = ensureCompleteGrids(f, instance, 1);
       if (rc) return rc;
@@ -1275,6 +1326,7 @@ int navgpu_planner_check_trajectory(navgpu_fleet* f, uint32_t instance, const fl
 
 int navgpu_planner_cost_cloud(navgpu_fleet* f, uint32_t instance, float* points, uint32_t capacity) {
   if (!f || instance >= f->desc.n_instances || (capacity && !points)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->planner_configured) return NAVGPU_ERR_STATE;
   {
     int rc = ensureCompleteGrids(f, instance, 1);
@@ -1315,6 +1367,7 @@ int navgpu_planner_cost_cloud(navgpu_fleet* f, uint32_t instance, float* points,
 
 int navgpu_planner_get_oscillation(navgpu_fleet* f, uint32_t first, uint32_t count, uint32_t* flags, float* prev) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (flags) HIP_TRY(hipMemcpyAsync(flags, f->pl.osc_flags + first, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, f->stream));
   if (prev) HIP_TRY(hipMemcpyAsync(prev, f->pl.osc_prev + (size_t)first * 3, sizeof(float) * 3 * count, hipMemcpyDeviceToHost, f->stream));
   HIP_TRY(waitStream(f->stream));
@@ -1322,6 +1375,7 @@ int navgpu_planner_get_oscillation(navgpu_fleet* f, uint32_t first, uint32_t cou
 }
 int navgpu_planner_set_oscillation(navgpu_fleet* f, uint32_t first, uint32_t count, const uint32_t* flags, const float* prev) {
   if (!f || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (flags) HIP_TRY(hipMemcpyAsync(f->pl.osc_flags + first, flags, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
   if (prev) HIP_TRY(hipMemcpyAsync(f->pl.osc_prev + (size_t)first * 3, prev, sizeof(float) * 3 * count, hipMemcpyHostToDevice, f->stream));
   HIP_TRY(waitStream(f->stream));
@@ -1331,6 +1385,7 @@ int navgpu_planner_set_oscillation(navgpu_fleet* f, uint32_t first, uint32_t cou
 // ------------------------------------------------------------------------------------------------ measurement
 int navgpu_profile_enable(navgpu_fleet* f, int32_t enable) {
   if (!f) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!enable && f->profiling) {
     int rc = f->foldEvents();
     if (rc) return rc;
@@ -1340,11 +1395,13 @@ int navgpu_profile_enable(navgpu_fleet* f, int32_t enable) {
 }
 int navgpu_profile_select(navgpu_fleet* f, uint32_t kernel_mask) {
   if (!f) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   f->prof_mask = kernel_mask;
   return NAVGPU_OK;
 }
 int navgpu_profile_reset(navgpu_fleet* f) {
   if (!f) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   int rc = f->foldEvents();
   if (rc) return rc;
   for (int k = 0; k < NAVGPU_K_COUNT; ++k) {
@@ -1355,6 +1412,7 @@ int navgpu_profile_reset(navgpu_fleet* f) {
 }
 int navgpu_profile_read(navgpu_fleet* f, int32_t k, double* total_ms, uint64_t* launches) {
   if (!f || k < 0 || k >= NAVGPU_K_COUNT) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   int rc = f->foldEvents();
   if (rc) return rc;
   if (total_ms) *total_ms = f->prof_ms[k];

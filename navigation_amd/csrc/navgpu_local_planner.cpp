@@ -75,6 +75,7 @@ int navgpu_local_plan_window(const double* plan, uint32_t n, const double pose[3
 
 int navgpu_local_planner_configure(navgpu_fleet* f, const navgpu_local_limits* lim) {
   if (!f || !lim) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   f->lp_limits = *lim;
   f->lp_configured = true;
   if (f->lp.size() != f->desc.n_instances) f->lp.assign(f->desc.n_instances, navgpu_fleet::LocalPlannerState());
@@ -83,6 +84,7 @@ int navgpu_local_planner_configure(navgpu_fleet* f, const navgpu_local_limits* l
 
 int navgpu_local_planner_set_plan(navgpu_fleet* f, uint32_t instance, const double* plan, uint32_t n, const double* T) {
   if (!f || instance >= f->desc.n_instances || (n && !plan)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->lp_configured || !f->planner_configured) return NAVGPU_ERR_STATE;
   navgpu_fleet::LocalPlannerState& st = f->lp[instance];
   st.xy_tolerance_latch = false;  // latchedStopRotateController_.resetLatching() (dwa_planner_ros.cpp:136)
@@ -95,6 +97,7 @@ int navgpu_local_planner_set_plan(navgpu_fleet* f, uint32_t instance, const doub
 
 int navgpu_local_planner_get_plan(navgpu_fleet* f, uint32_t instance, double* xyyaw, uint32_t capacity) {
   if (!f || instance >= f->desc.n_instances || !f->lp_configured) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   const std::vector<double>& pl = f->lp[instance].plan;
   const uint32_t n = (uint32_t)(pl.size() / 3);
   if (xyyaw) {
@@ -126,6 +129,7 @@ static bool stoppedOdom(const double v[3], double rot_stopped, double trans_stop
 
 int navgpu_local_planner_is_goal_reached(navgpu_fleet* f, uint32_t first, uint32_t count, const navgpu_robot_input* in, int32_t* reached) {
   if (!f || !in || !reached || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->lp_configured) return NAVGPU_ERR_STATE;
   const navgpu_local_limits& lim = f->lp_limits;
   for (uint32_t k = 0; k < count; ++k) {
@@ -147,6 +151,7 @@ int navgpu_local_planner_is_goal_reached(navgpu_fleet* f, uint32_t first, uint32
 int navgpu_local_planner_compute_velocity_commands(navgpu_fleet* f, uint32_t first, uint32_t count, const navgpu_robot_input* in,
                                                    navgpu_cmd_result* out) {
   if (!f || !in || !out || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->lp_configured || !f->planner_configured) return NAVGPU_ERR_STATE;
   const navgpu_local_limits& lim = f->lp_limits;
   const uint32_t max_plan = f->pl.max_plan;

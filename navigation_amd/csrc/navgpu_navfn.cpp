@@ -5,6 +5,7 @@ struct navgpu_navfn {
   NavfnDev nv{};
   uint32_t n = 0;
   int device = 0;
+  std::recursive_mutex mu;  // calls on one handle are serialised inside the library (as on a fleet)
   hipStream_t stream = nullptr;
   std::vector<void*> allocs;
   uint8_t* d_cmap = nullptr;   // staging for host cost maps: [n][ns_padded]
@@ -27,6 +28,13 @@ struct navgpu_navfn {
     return NAVGPU_OK;
   }
 };
+
+namespace {
+struct NavfnGuard {  // lock + make the handle's GPU current on the calling thread
+  std::lock_guard<std::recursive_mutex> lk;
+  explicit NavfnGuard(navgpu_navfn* h) : lk(h->mu) { (void)hipSetDevice(h->device); }
+};
+}  // namespace
 
 extern "C" {
 
@@ -80,6 +88,7 @@ int navgpu_navfn_create(uint32_t nx, uint32_t ny, uint32_t n_plans, int32_t devi
 
 int navgpu_navfn_destroy(navgpu_navfn* h) {
   if (!h) return NAVGPU_ERR_INVALID;
+  (void)hipSetDevice(h->device);
   if (h->stream) waitStream(h->stream);
   for (void* p : h->allocs) hipFree(p);
   if (h->h_results) hipHostFree(h->h_results);
@@ -93,8 +102,8 @@ static bool navfnRange(const navgpu_navfn* h, uint32_t first, uint32_t count) { 
 int navgpu_navfn_set_costmap(navgpu_navfn* h, uint32_t first, uint32_t count, const uint8_t* cmap, int32_t shared, int32_t cost_mode,
                              int32_t allow_unknown) {
   if (!h || !cmap || !navfnRange(h, first, count) || cost_mode < 0 || cost_mode > 2) return NAVGPU_ERR_INVALID;
+  NavfnGuard guard_(h);
   const NavfnDev& nv = h->nv;
-  HIP_TRY(hipSetDevice(h->device));
   const uint32_t maps = shared ? 1u : count;
   for (uint32_t k = 0; k < maps; ++k)
     HIP_TRY(hipMemcpyAsync(h->d_cmap + (size_t)k * nv.ns_padded, cmap + (size_t)k * nv.ns, (size_t)nv.ns, hipMemcpyHostToDevice, h->stream));
@@ -106,6 +115,8 @@ int navgpu_navfn_set_costmap(navgpu_navfn* h, uint32_t first, uint32_t count, co
 int navgpu_navfn_set_costmap_from_fleet(navgpu_navfn* h, uint32_t first, uint32_t count, navgpu_fleet* f, uint32_t fleet_first, int32_t allow_unknown) {
   if (!h || !f || !navfnRange(h, first, count) || !f->rangeOk(fleet_first, count)) return NAVGPU_ERR_INVALID;
   if ((int)f->cm.nx != h->nv.nx || (int)f->cm.ny != h->nv.ny || f->desc.device != h->device) return NAVGPU_ERR_INVALID;
+  NavfnGuard guard_(h);
+  FleetGuard fleet_guard_(f);
   HIP_TRY(waitStream(f->stream));  // the fleet's last costmap update has landed
   launch_navfn_costmap(h->nv, first, count, f->cm.master + (size_t)fleet_first * f->cm.cells_padded, f->cm.cells_padded, 1, allow_unknown, h->stream);
   HIP_TRY(waitStream(h->stream));
@@ -115,6 +126,7 @@ int navgpu_navfn_set_costmap_from_fleet(navgpu_navfn* h, uint32_t first, uint32_
 int navgpu_navfn_plan(navgpu_navfn* h, uint32_t first, uint32_t count, const int32_t* goals, const int32_t* starts, int32_t astar, int32_t at_start,
                       navgpu_navfn_result* results) {
   if (!h || !goals || !starts || !navfnRange(h, first, count)) return NAVGPU_ERR_INVALID;
+  NavfnGuard guard_(h);
   const NavfnDev& nv = h->nv;
   for (uint32_t k = 0; k < count; ++k) {  // the reference indexes its arrays with these without a check: keep them inside the border
     const int32_t* g = goals + 2 * k;
@@ -124,7 +136,6 @@ int navgpu_navfn_plan(navgpu_navfn* h, uint32_t first, uint32_t count, const int
       return NAVGPU_ERR_INVALID;
     }
   }
-  HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipMemcpyAsync(h->d_goal, goals, sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_start, starts, sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, h->stream));
   launch_navfn_plan(nv, first, count, h->d_goal, h->d_start, astar ? 1 : 0, at_start ? 1 : 0, h->stream);
@@ -137,6 +148,7 @@ int navgpu_navfn_plan(navgpu_navfn* h, uint32_t first, uint32_t count, const int
 int navgpu_global_planner_plan(navgpu_navfn* h, uint32_t first, uint32_t count, const navgpu_global_planner_params* gp, const double* starts,
                                const double* goals, const int32_t* goal_cells, navgpu_navfn_result* results) {
   if (!h || !gp || !starts || !goals || !goal_cells || !navfnRange(h, first, count)) return NAVGPU_ERR_INVALID;
+  NavfnGuard guard_(h);
   const NavfnDev& nv = h->nv;
   if (gp->lethal_cost < 2 || gp->lethal_cost > 255 || gp->neutral_cost < 0 || gp->neutral_cost > 255) return NAVGPU_ERR_INVALID;
   for (uint32_t k = 0; k < count; ++k) {  // the reference indexes its arrays with these without a check: keep them inside the outline
@@ -148,7 +160,6 @@ int navgpu_global_planner_plan(navgpu_navfn* h, uint32_t first, uint32_t count, 
       return NAVGPU_ERR_INVALID;
     }
   }
-  HIP_TRY(hipSetDevice(h->device));
   if (!gp->use_dijkstra && !h->d_heap) {
     uint64_t* q = nullptr;  // 8 bytes per entry (int index, float cost); a cell enters the queue at most once
     int rc = h->alloc(&q, (size_t)h->n * nv.ns_padded);
@@ -167,6 +178,7 @@ int navgpu_global_planner_plan(navgpu_navfn* h, uint32_t first, uint32_t count, 
 
 int navgpu_navfn_path(navgpu_navfn* h, uint32_t plan, float* xy, uint32_t cap) {
   if (!h || plan >= h->n || (!xy && cap)) return NAVGPU_ERR_INVALID;
+  NavfnGuard guard_(h);
   const NavfnDev& nv = h->nv;
   const int len = h->h_results[plan].path_length;
   const uint32_t n = std::min<uint32_t>((uint32_t)std::max(len, 0), cap);
@@ -185,6 +197,7 @@ int navgpu_navfn_path(navgpu_navfn* h, uint32_t plan, float* xy, uint32_t cap) {
 
 int navgpu_navfn_potential(navgpu_navfn* h, uint32_t plan, float* potarr) {
   if (!h || plan >= h->n || !potarr) return NAVGPU_ERR_INVALID;
+  NavfnGuard guard_(h);
   HIP_TRY(hipMemcpyAsync(potarr, h->nv.potarr + (size_t)plan * h->nv.ns_padded, sizeof(float) * (size_t)h->nv.ns, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(waitStream(h->stream));
   return NAVGPU_OK;

@@ -130,6 +130,7 @@ static uint32_t tpMaxSamples(const navgpu_tp_config& c) {
 
 int navgpu_tp_configure(navgpu_fleet* f, const navgpu_tp_config* cfg_in) {
   if (!f || !cfg_in) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   navgpu_tp_config c = *cfg_in;
   if (c.n_y_vels < 0 || c.n_y_vels > 8 || !(c.sim_time > 0) || !(c.sim_granularity > 0) || !(c.angular_sim_granularity > 0))
     return NAVGPU_ERR_INVALID;
@@ -212,6 +213,7 @@ static int tpUploadPlans(navgpu_fleet* f, uint32_t first, uint32_t count) {
 
 int navgpu_tp_update_plan(navgpu_fleet* f, uint32_t instance, const double* plan_xy, uint32_t n, int32_t compute_dists) {
   if (!f || instance >= f->desc.n_instances || (n && !plan_xy)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->tp_configured) return NAVGPU_ERR_STATE;
   if (n > f->pl.max_plan) return NAVGPU_ERR_CAPACITY;
   navgpu_fleet::TpHost& h = f->tph[instance];
@@ -239,6 +241,7 @@ static inline void tpSet(navgpu_tp_state& s, uint32_t bit, bool v) { s.flags = v
 
 int navgpu_tp_find_best_path(navgpu_fleet* f, uint32_t first, uint32_t count, const navgpu_robot_state* states, navgpu_tp_result* results) {
   if (!f || !states || !results || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->tp_configured) return NAVGPU_ERR_STATE;
   TpDev& tp = f->tp;
   const navgpu_tp_config& c = tp.cfg;
@@ -523,6 +526,7 @@ int navgpu_tp_find_best_path(navgpu_fleet* f, uint32_t first, uint32_t count, co
 
 int navgpu_tp_trajectory(navgpu_fleet* f, uint32_t instance, double* xyth, uint32_t cap) {
   if (!f || !xyth || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->tp_configured) return NAVGPU_ERR_STATE;
   const int n = f->tph[instance].n_points;
   if (n > (int)cap) return NAVGPU_ERR_CAPACITY;
@@ -535,6 +539,7 @@ int navgpu_tp_trajectory(navgpu_fleet* f, uint32_t instance, double* xyth, uint3
 
 int navgpu_tp_samples(navgpu_fleet* f, uint32_t instance, navgpu_tp_sample* samples, uint32_t cap) {
   if (!f || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->tp_configured) return NAVGPU_ERR_STATE;
   const std::vector<navgpu_tp_sample>& m = f->tph[instance].made;
   if (samples) {
@@ -546,6 +551,7 @@ int navgpu_tp_samples(navgpu_fleet* f, uint32_t instance, navgpu_tp_sample* samp
 
 int navgpu_tp_score_trajectory(navgpu_fleet* f, uint32_t instance, const double pose[3], const double vel[3], const double vs[3], double* cost) {
   if (!f || !pose || !vel || !vs || !cost || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->tp_configured) return NAVGPU_ERR_STATE;
   TpDev& tp = f->tp;
   if (tp.cfg.simple_attractor && f->tph[instance].plan.empty()) return NAVGPU_ERR_STATE;
@@ -566,12 +572,14 @@ int navgpu_tp_score_trajectory(navgpu_fleet* f, uint32_t instance, const double 
 
 int navgpu_tp_get_state(navgpu_fleet* f, uint32_t first, uint32_t count, navgpu_tp_state* states) {
   if (!f || !states || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->tp_configured) return NAVGPU_ERR_STATE;
   for (uint32_t k = 0; k < count; ++k) states[k] = f->tph[first + k].st;
   return NAVGPU_OK;
 }
 int navgpu_tp_set_state(navgpu_fleet* f, uint32_t first, uint32_t count, const navgpu_tp_state* states) {
   if (!f || !states || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
   if (!f->tp_configured) return NAVGPU_ERR_STATE;
   for (uint32_t k = 0; k < count; ++k) f->tph[first + k].st = states[k];
   return NAVGPU_OK;

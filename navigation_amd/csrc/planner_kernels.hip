@@ -1799,6 +1799,14 @@ bool bfs_bounded_applies(const PlannerDev& pl) {
   if (force_lds_kernel) return false;
   return bfs_wave_fits(pl.nx, pl.ny, 7) || (bfs_wave_fits(pl.nx, pl.ny, 13) && bfs_wave_lds(pl.nx, pl.ny, 13) <= 156u * 1024u);
 }
+// persistent DIRECT workgroups per CU (2 fill every wave slot; 1 leaves half of them to another stream's kernels)
+static uint32_t bfs_direct_wgs_per_cu() {
+  static const uint32_t v = [] {
+    const char* e = getenv("NAVGPU_BFS_WGS_PER_CU");
+    return e ? (uint32_t)std::max(1, atoi(e)) : 2u;
+  }();
+  return v;
+}
 void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order, bool free_ready, int n_whole) {
   // n_whole: how many of the robots search their whole grid this cycle (< 0 = unknown / all): a bounded launch runs the
   // DIRECT variant for the bounded searches and, only if there are any, the plane variant for the others
@@ -1824,7 +1832,7 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
     if constexpr (!LEG) {                                                                                                     \
       if (direct) {                                                                                                           \
         if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<R, false, P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); \
-        hipLaunchKernelGGL((k_bfs_wave<R, false, P, true>), dim3(std::min(count * pl.bfs_grids, (2 * lds_w <= 156u * 1024u ? 2u : 1u) * bfs_cu_count())), dim3(1024), lds_w, s, pl, first, count, pl.bfs_next_item + 1, order, 0); \
+        hipLaunchKernelGGL((k_bfs_wave<R, false, P, true>), dim3(std::min(count * pl.bfs_grids, std::min(bfs_direct_wgs_per_cu(), 2 * lds_w <= 156u * 1024u ? 2u : 1u) * bfs_cu_count())), dim3(1024), lds_w, s, pl, first, count, pl.bfs_next_item + 1, order, 0); \
       }                                                                                                                       \
     }                                                                                                                         \
     return;                                                                                                                   \

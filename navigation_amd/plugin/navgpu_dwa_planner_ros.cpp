@@ -55,6 +55,7 @@ void DWAPlannerROS::initialize(std::string name, tf::TransformListener* tf, cost
 }
 
 void DWAPlannerROS::reconfigureCB(dwa_local_planner::DWAPlannerConfig& config, uint32_t) {
+  boost::unique_lock<boost::mutex> l(configuration_mutex_);  // DWAPlanner::reconfigure (dwa_planner.cpp:55)
   if (setup_ && config.restore_defaults) {  // dwa_planner_ros.cpp:54-62
     config = default_config_;
     config.restore_defaults = false;
@@ -108,6 +109,7 @@ void DWAPlannerROS::reconfigureCB(dwa_local_planner::DWAPlannerConfig& config, u
 
 bool DWAPlannerROS::setPlan(const std::vector<geometry_msgs::PoseStamped>& orig_global_plan) {
   if (!initialized_) return false;  // dwa_planner_ros.cpp:131-142
+  boost::unique_lock<boost::mutex> l(configuration_mutex_);
   latchedStopRotateController_.resetLatching();
   navgpu_planner_set_plan(fleet_, 0, 1);  // DWAPlanner::setPlan: resetOscillationFlags
   return planner_util_.setPlan(orig_global_plan);
@@ -174,6 +176,10 @@ bool DWAPlannerROS::computeVelocityCommands(geometry_msgs::Twist& cmd_vel) {  //
   if (transformed_plan.empty()) return false;
   tf::Stamped<tf::Pose> robot_vel;
   odom_helper_.getRobotVel(robot_vel);
+  // one lock over stage + (stop-rotate | findBestPath): the reference takes configuration_mutex_ inside findBestPath
+  // (dwa_planner.cpp:301); its updatePlanAndLocalCosts reads no reconfigurable state that the GPU tables depend on,
+  // ours stages the nose goal and the wavefront boxes from cfg_, so the lock starts one call earlier
+  boost::unique_lock<boost::mutex> l(configuration_mutex_);
   if (!gpuStage(current_pose_, robot_vel, transformed_plan)) return false;  // dp_->updatePlanAndLocalCosts (:274)
 
   if (latchedStopRotateController_.isPositionReached(&planner_util_, current_pose_)) {  // :276-288

@@ -17,6 +17,8 @@
 #include <nav_core/base_local_planner.h>
 #include <tf/transform_listener.h>
 
+#include <boost/thread.hpp>
+
 #include <navgpu.h>
 
 namespace navgpu {
@@ -47,6 +49,12 @@ class DWAPlannerROS : public nav_core::BaseLocalPlanner {
   dynamic_reconfigure::Server<dwa_local_planner::DWAPlannerConfig>* dsrv_;
   dwa_local_planner::DWAPlannerConfig default_config_;
   bool setup_, initialized_;
+  // DWAPlanner::configuration_mutex_ (dwa_planner.h:163): reconfigure() takes it (dwa_planner.cpp:55) and so does
+  // findBestPath (:301); here it also covers the staging and checkTrajectory, because cfg_ and the fleet's tables are
+  // shared between the dynamic_reconfigure (spinner) thread and move_base's control thread.  libnavgpu serialises the
+  // calls on a fleet itself (see include/navgpu.h, "Threading"); this mutex keeps a reconfigure from landing BETWEEN the
+  // stage and the cycle of one computeVelocityCommands.
+  boost::mutex configuration_mutex_;
   navgpu_fleet* fleet_;
   navgpu_dwa_config cfg_;
   navgpu_robot_state staged_;  // pose / velocity of the last stage

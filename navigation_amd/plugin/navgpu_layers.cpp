@@ -141,6 +141,7 @@ void InflationLayer::onInitialize() {  // inflation_layer.cpp:70-99
   matchSize();
 }
 void InflationLayer::reconfigureCB(costmap_2d::InflationPluginConfig& c, uint32_t) {  // :101-109, :362-376
+  boost::unique_lock<boost::recursive_mutex> lock(inflation_access_);  // setInflationParameters :366
   if (p_.cost_scaling_factor != c.cost_scaling_factor || p_.inflation_radius != c.inflation_radius) need_reinflation_ = true;
   if (enabled_ != c.enabled) need_reinflation_ = true;
   enabled_ = c.enabled;
@@ -154,18 +155,22 @@ void InflationLayer::pushParams() {
     ROS_ERROR("navgpu_inflation_configure: %s", navgpu_last_error());
 }
 void InflationLayer::matchSize() {  // :110-123 — the fleet is tied to the master's geometry
+  boost::unique_lock<boost::recursive_mutex> lock(inflation_access_);  // :112
   gpu_.create(*layered_costmap_->getCostmap(), NAVGPU_LAYER_INFLATION, layered_costmap_->isTrackingUnknown(), false);
   pushParams();
 }
 void InflationLayer::onFootprintChanged() {  // :160-170
+  boost::unique_lock<boost::recursive_mutex> lock(inflation_access_);
   p_.inscribed_radius = layered_costmap_->getInscribedRadius();
   need_reinflation_ = true;
   pushParams();
 }
 void InflationLayer::updateBounds(double, double, double, double* min_x, double* min_y, double* max_x, double* max_y) {
+  boost::unique_lock<boost::recursive_mutex> lock(inflation_access_);  // (need_reinflation_ and the radius are the reconfigure thread's too)
   box_.update(&need_reinflation_, p_.inflation_radius, min_x, min_y, max_x, max_y);
 }
 void InflationLayer::updateCosts(costmap_2d::Costmap2D& master, int min_i, int min_j, int max_i, int max_j) {
+  boost::unique_lock<boost::recursive_mutex> lock(inflation_access_);  // :175
   if (!enabled_) return;  // :172-266 on the GPU: upload, inflate the box, download
   if (!gpu_.updateCosts(master, min_i, min_j, max_i, max_j, false, true, NULL)) {
     ROS_ERROR_THROTTLE(1.0, "navgpu inflation failed: %s", navgpu_last_error());
@@ -188,16 +193,19 @@ void ObstacleLayer::pushObstacleParams() {
     ROS_ERROR("navgpu_obstacle_configure: %s", navgpu_last_error());
 }
 void ObstacleLayer::matchSize() {  // obstacle_layer.cpp via CostmapLayer::matchSize (costmap_layer.cpp:17-22)
+  boost::unique_lock<boost::recursive_mutex> lock(gpu_access_);
   costmap_2d::ObstacleLayer::matchSize();
   gpu_.create(*layered_costmap_->getCostmap(), gpuLayers(), default_value_ == costmap_2d::NO_INFORMATION, rolling_window_);
   pushObstacleParams();
   if (gpuLayers() & NAVGPU_LAYER_INFLATION) onFootprintChanged();
 }
 void ObstacleLayer::reset() {  // obstacle_layer.cpp:589-596: deactivate, resetMaps, current_ = true, activate
+  boost::unique_lock<boost::recursive_mutex> lock(gpu_access_);
   costmap_2d::ObstacleLayer::reset();
   if (gpu_.fleet()) navgpu_grid_reset(gpu_.fleet(), NAVGPU_GRID_OBSTACLE, 0, 1);  // + the voxel columns of a voxel fleet
 }
 void ObstacleLayer::resetMap(unsigned int x0, unsigned int y0, unsigned int xn, unsigned int yn) {
+  boost::unique_lock<boost::recursive_mutex> lock(gpu_access_);
   // Costmap2D::resetMap is what CostmapLayer::resetBoundingBox (costmap_layer.cpp:30-43; Costmap2DROS::resetBoundingBox's
   // per-layer call) clears the layer with: the device-resident layer grid follows; the extra bounds it adds stay on the
   // host and enter gpuUpdateBounds through useExtraBounds
@@ -206,10 +214,26 @@ void ObstacleLayer::resetMap(unsigned int x0, unsigned int y0, unsigned int xn, 
     ROS_ERROR("navgpu_grid_reset_window: %s", navgpu_last_error());
 }
 bool ObstacleLayer::gpuUpdateBounds(double rx, double ry, double ryaw, double* min_x, double* min_y, double* max_x, double* max_y) {
+  boost::unique_lock<boost::recursive_mutex> lock(gpu_access_);
   // obstacle_layer.cpp:340-413.  The reconfigurable parameters are re-pushed every cycle (ObstaclePluginConfig's
   // callback is private to the reference class; four scalars)
   pushObstacleParams();
-  if (!enabled_) return true;
+  if (!enabled_) {
+    // the reference rolls the window BEFORE it looks at enabled_ (obstacle_layer.cpp:343-346): a disabled layer's origin
+    // and grid keep following the robot.  With `enabled` pushed as 0 the device call below shifts the resident grids,
+    // leaves cells and bounds alone, and hands back the new origin.
+    if (rolling_window_) {
+      const std::vector<costmap_2d::Observation> none;
+      double b[4] = {*min_x, *min_y, *max_x, *max_y}, origin[2];
+      if (!gpu_.updateBounds(rx, ry, ryaw, none, none, getFootprint(), b, origin)) {
+        ROS_ERROR_THROTTLE(1.0, "navgpu obstacle window roll failed: %s", navgpu_last_error());
+        return false;
+      }
+      origin_x_ = origin[0];
+      origin_y_ = origin[1];
+    }
+    return true;
+  }
   useExtraBounds(min_x, min_y, max_x, max_y);
   std::vector<costmap_2d::Observation> marking, clearing;  // :349-359
   bool current = getMarkingObservations(marking);
@@ -236,6 +260,7 @@ void ObstacleLayer::updateBounds(double rx, double ry, double ryaw, double* min_
   gpuUpdateBounds(rx, ry, ryaw, min_x, min_y, max_x, max_y);
 }
 void ObstacleLayer::updateCosts(costmap_2d::Costmap2D& master, int min_i, int min_j, int max_i, int max_j) {
+  boost::unique_lock<boost::recursive_mutex> lock(gpu_access_);
   if (!enabled_) return;  // obstacle_layer.cpp:427-448 on the GPU
   if (!gpu_.updateCosts(master, min_i, min_j, max_i, max_j, true, false, costmap_)) {  // costmap_: keep the layer's own grid in step
     ROS_ERROR_THROTTLE(1.0, "navgpu obstacle merge failed: %s", navgpu_last_error());
@@ -250,6 +275,7 @@ void VoxelLayer::setupDynamicReconfigure(ros::NodeHandle& nh) {  // voxel_layer.
   voxel_dsrv_->setCallback(boost::bind(&VoxelLayer::reconfigureCB, this, _1, _2));
 }
 void VoxelLayer::reconfigureCB(costmap_2d::VoxelPluginConfig& config, uint32_t) {  // voxel_layer.cpp:77-91
+  boost::unique_lock<boost::recursive_mutex> lock(gpu_access_);
   enabled_ = config.enabled;
   footprint_clearing_enabled_ = config.footprint_clearing_enabled;
   max_obstacle_height_ = config.max_obstacle_height;
@@ -314,17 +340,20 @@ void GpuLayers::matchSize() {
   ObstacleLayer::matchSize();  // creates the fleet with gpuLayers() and calls onFootprintChanged
 }
 void GpuLayers::onFootprintChanged() {  // inflation_layer.cpp:160-170
+  boost::unique_lock<boost::recursive_mutex> lock(gpu_access_);
   ip_.inscribed_radius = layered_costmap_->getInscribedRadius();
   need_reinflation_ = true;
   if (gpu_.fleet() && navgpu_inflation_configure(gpu_.fleet(), &ip_) != NAVGPU_OK)
     ROS_ERROR("navgpu_inflation_configure: %s", navgpu_last_error());
 }
 void GpuLayers::updateBounds(double rx, double ry, double ryaw, double* min_x, double* min_y, double* max_x, double* max_y) {
+  boost::unique_lock<boost::recursive_mutex> lock(gpu_access_);
   // the obstacle layer's updateBounds followed by the inflation layer's, as LayeredCostmap::updateMap :96-115 runs them
   gpuUpdateBounds(rx, ry, ryaw, min_x, min_y, max_x, max_y);
   box_.update(&need_reinflation_, ip_.inflation_radius, min_x, min_y, max_x, max_y);
 }
 void GpuLayers::updateCosts(costmap_2d::Costmap2D& master, int min_i, int min_j, int max_i, int max_j) {
+  boost::unique_lock<boost::recursive_mutex> lock(gpu_access_);
   // ObstacleLayer::updateCosts then InflationLayer::updateCosts (layered_costmap.cpp:138-142) on the resident grids
   if (!gpu_.updateCosts(master, min_i, min_j, max_i, max_j, enabled_, true, costmap_)) {
     ROS_ERROR_THROTTLE(1.0, "navgpu layered update failed: %s", navgpu_last_error());

@@ -23,6 +23,8 @@
 #include <costmap_2d/obstacle_layer.h>
 #include <dynamic_reconfigure/server.h>
 
+#include <boost/thread.hpp>
+
 #include <navgpu.h>
 
 namespace navgpu {
@@ -81,6 +83,10 @@ class InflationLayer : public costmap_2d::Layer {
   void reconfigureCB(costmap_2d::InflationPluginConfig& config, uint32_t level);
   void pushParams();
   LayerBridge gpu_;
+  // InflationLayer::inflation_access_ (inflation_layer.h:158): reconfigureCB / matchSize / updateBounds / updateCosts
+  // exclude one another (inflation_layer.cpp:68,112,175,366) - here that also keeps matchSize from destroying the fleet
+  // under a running updateCosts
+  boost::recursive_mutex inflation_access_;
   navgpu_inflation_params p_;
   bool need_reinflation_;
   InflationBounds box_;
@@ -106,6 +112,10 @@ class ObstacleLayer : public costmap_2d::ObstacleLayer {
   virtual void pushObstacleParams();
   bool gpuUpdateBounds(double rx, double ry, double ryaw, double* min_x, double* min_y, double* max_x, double* max_y);
   LayerBridge gpu_;
+  // The reference's obstacle / voxel layers take no lock in their reconfigure callbacks (a VoxelLayer reconfigure runs
+  // matchSize from the spinner thread, voxel_layer.cpp:77-91).  Here matchSize destroys and recreates the fleet handle,
+  // so every method that touches gpu_ holds this; GpuLayers uses it as its inflation_access_ as well.
+  boost::recursive_mutex gpu_access_;
 };
 
 // costmap_2d::VoxelLayer's members are private, so this adapter derives from ObstacleLayer like VoxelLayer itself does
