@@ -1212,6 +1212,493 @@ __global__ __launch_bounds__(1024, DIRECT ? 8 : 4) void k_bfs_wave(PlannerDev pl
     __syncthreads();  // s_item and the LDS staging of the decode are reused by the next item
   }
 }
+// ------------------------------------------------------------------------------------------------
+// k_bfs_rows: the BOUNDED searches of a DWA cycle, one lane per costmap ROW.
+// The dense sweep of k_bfs_wave spends its instructions on rows x words that hold no frontier: a wavefront is a thin
+// diamond ring, and of the 13 words of a 400-cell row it touches two or three (measured offline on the benchmark's maps:
+// 23 % of the (64-row, word) pairs hold or border a frontier cell at a given level).  Here a lane owns one row and keeps
+// the row's W words of `blocked` and `frontier` in registers, so
+//   * left / right neighbours are the adjacent REGISTERS (one v_alignbit each), up / down the adjacent LANES (DPP);
+//   * which GROUPS of four words are live is a wave-uniform bit mask (ballots of the groups that produced new cells,
+//     grown by the neighbouring group where a group's first / last word got some, plus the groups in which a
+//     neighbouring wave's edge row holds frontier cells): a dead group costs two scalar instructions.  A live group is
+//     one straight-line block of four interleaved dependency chains - a level is a latency chain (below), so what
+//     counts is the length of a wave's instruction path, not the number of instructions the chip issues;
+//   * TEMPORAL BLOCKING: a wave holds 64 rows of which the middle 50 are its own and 7 on either side are copies of
+//     its neighbours' rows (with their real `blocked` words).  After an exchange all 64 are exact; every level after
+//     that the outermost still-exact row on either side is lost (it lacks a neighbour), so for 7 levels the wave's own
+//     50 rows stay exact WITHOUT any communication - no progress words, no polling, no LDS traffic in the level loop.
+//     Every 7 levels the waves publish their outer 7 own rows (frontier + blocked), meet at a barrier, take the
+//     neighbours' rows into their halo lanes and read the stop flags.  A level of the word-by-word, handshake-per-level
+//     form of this kernel cost 4 265 clocks per wave (NAVGPU_BFS_STATS, tools/probe_bfs_stats.py): 1 735 waiting for the
+//     neighbours, 1 124 in 4.7 live words (a scalar branch pair and a dependent 8-instruction chain each; one wave
+//     issues one vector instruction per 4 clocks), 886 at the barrier that then closed every 8 levels.  A level is a
+//     latency chain: what counts is the length of ONE wave's instruction path and how often it must wait for another;
+//   * 400 rows are 8 waves of 50: three searches per CU are resident at once (80 registers), and the 768 items of the
+//     256-robot fleet all run side by side.
+// Distances are stored the moment the wavefront reaches a cell of the robot's region, by the lane whose row
+// it is; the touched obstacles and the unreached cells of the region after the sweep.  Everything else (seeds from the
+// plan, the stop condition with its pockets, bfs_levels for the dispatch order) is k_bfs_wave's.
+// map_grid.cpp:103-122, 174-310.
+// ------------------------------------------------------------------------------------------------
+#ifdef NAVGPU_BFS_STATS  // experiment builds only (make EXTRA=-DNAVGPU_BFS_STATS, tools/probe_bfs_stats.py): where a level's time goes
+__device__ unsigned long long g_bfs_stats[16];  // shader clocks per wave: [0] poll [1] halo + words [2] stores [3] publish [4] group end; [5] wave-levels [6] spins [7] active wave-levels [8] active groups
+#define BFS_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define BFS_ACC(i, x) bst[i] += (x)
+#else
+#define BFS_STAMP(v)
+#define BFS_ACC(i, x)
+#endif
+constexpr int kRowsHalo = 7;                       // rows a wave copies from either neighbour = levels between two exchanges
+constexpr int kRowsPerWave = 64 - 2 * kRowsHalo;   // rows a wave owns
+__host__ __device__ inline uint32_t bfs_rows_waves(uint32_t ny) { return (ny + kRowsPerWave - 1) / kRowsPerWave; }
+template <int W>
+__host__ __device__ inline size_t bfs_rows_lds_words(uint32_t nx, uint32_t ny) {
+  constexpr uint32_t Wp = (W + 3) & ~3u;
+  const uint32_t nw = bfs_rows_waves(ny);
+  return (((size_t)nw * kRowsPerWave * ((nx + 31) >> 5) + 3) & ~(size_t)3) + (size_t)kCareRows * kCareWords + (size_t)(nw + 2) * 2 * kRowsHalo * 2 * Wp;
+}
+// One group of four words (A B C D, left neighbour word L, right neighbour word R) of one level, skipped as a whole when
+// bit g of the wave's active mask is clear.  Per word:
+//   x = (f << 1 | left >> 31) | (f >> 1 | right << 31) | up | down;   cand = x & ~blocked;   blocked |= x
+// cand* leave in h* (the words are written back by rowsCommit4 once every group has read the old frontier).
+// nz: bit g set when any lane has new cells in the group; lo / hi: when its first / last word has (the neighbouring
+// group borders them next level).
+__device__ __forceinline__ void rowsGroup4(const int g, const uint32_t aw, uint32_t& nz, uint32_t& lo, uint32_t& hi,
+                                           uint32_t& bA, uint32_t& bB, uint32_t& bC, uint32_t& bD, const uint32_t fL, const uint32_t fA,
+                                           const uint32_t fB, const uint32_t fC, const uint32_t fD, const uint32_t fR, uint32_t& hA, uint32_t& hB,
+                                           uint32_t& hC, uint32_t& hD) {
+  uint32_t tA, tB, tC, tD, uA, uB, uC, uD, st;
+  asm volatile(
+      "s_bitcmp1_b32 %[aw], %[g]\n\t"
+      "s_cbranch_scc0 1f\n\t"
+      "v_mov_b32_dpp %[tA], %[fA] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp %[tB], %[fB] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp %[tC], %[fC] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp %[tD], %[fD] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_alignbit_b32 %[uA], %[fA], %[fL], 31\n\t"
+      "v_alignbit_b32 %[uB], %[fB], %[fA], 31\n\t"
+      "v_alignbit_b32 %[uC], %[fC], %[fB], 31\n\t"
+      "v_alignbit_b32 %[uD], %[fD], %[fC], 31\n\t"
+      "v_alignbit_b32 %[hA], %[fB], %[fA], 1\n\t"
+      "v_alignbit_b32 %[hB], %[fC], %[fB], 1\n\t"
+      "v_alignbit_b32 %[hC], %[fD], %[fC], 1\n\t"
+      "v_alignbit_b32 %[hD], %[fR], %[fD], 1\n\t"
+      "v_or3_b32 %[tA], %[tA], %[uA], %[hA]\n\t"
+      "v_or3_b32 %[tB], %[tB], %[uB], %[hB]\n\t"
+      "v_or3_b32 %[tC], %[tC], %[uC], %[hC]\n\t"
+      "v_or3_b32 %[tD], %[tD], %[uD], %[hD]\n\t"
+      "v_mov_b32_dpp %[uA], %[fA] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp %[uB], %[fB] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp %[uC], %[fC] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp %[uD], %[fD] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_bitop3_b32 %[hA], %[tA], %[bA], %[uA] bitop3:0x32\n\t"
+      "v_bitop3_b32 %[hB], %[tB], %[bB], %[uB] bitop3:0x32\n\t"
+      "v_bitop3_b32 %[hC], %[tC], %[bC], %[uC] bitop3:0x32\n\t"
+      "v_bitop3_b32 %[hD], %[tD], %[bD], %[uD] bitop3:0x32\n\t"
+      "v_or3_b32 %[bA], %[bA], %[tA], %[uA]\n\t"
+      "v_or3_b32 %[bB], %[bB], %[tB], %[uB]\n\t"
+      "v_or3_b32 %[bC], %[bC], %[tC], %[uC]\n\t"
+      "v_or3_b32 %[bD], %[bD], %[tD], %[uD]\n\t"
+      "v_or3_b32 %[tA], %[hA], %[hB], %[hC]\n\t"
+      "v_or_b32_e32 %[tA], %[tA], %[hD]\n\t"
+      "v_cmp_ne_u32_e32 vcc, 0, %[tA]\n\t"
+      "s_cbranch_vccz 1f\n\t"
+      "s_bitset1_b32 %[nz], %[g]\n\t"
+      "v_cmp_ne_u32_e32 vcc, 0, %[hA]\n\t"
+      "s_nop 0\n\t"
+      "s_cmp_lg_u64 vcc, 0\n\t"
+      "s_cselect_b32 %[st], 1, 0\n\t"
+      "s_lshl_b32 %[st], %[st], %[g]\n\t"
+      "s_or_b32 %[lo], %[lo], %[st]\n\t"
+      "v_cmp_ne_u32_e32 vcc, 0, %[hD]\n\t"
+      "s_nop 0\n\t"
+      "s_cmp_lg_u64 vcc, 0\n\t"
+      "s_cselect_b32 %[st], 1, 0\n\t"
+      "s_lshl_b32 %[st], %[st], %[g]\n\t"
+      "s_or_b32 %[hi], %[hi], %[st]\n\t"
+      "1:\n\t"
+      : [bA] "+v"(bA), [bB] "+v"(bB), [bC] "+v"(bC), [bD] "+v"(bD), [hA] "=&v"(hA), [hB] "=&v"(hB), [hC] "=&v"(hC), [hD] "=&v"(hD), [nz] "+s"(nz),
+        [lo] "+s"(lo), [hi] "+s"(hi), [tA] "=&v"(tA), [tB] "=&v"(tB), [tC] "=&v"(tC), [tD] "=&v"(tD),
+        [uA] "=&v"(uA), [uB] "=&v"(uB), [uC] "=&v"(uC), [uD] "=&v"(uD), [st] "=&s"(st)
+      : [aw] "s"(aw), [g] "n"(g), [fL] "v"(fL), [fA] "v"(fA), [fB] "v"(fB), [fC] "v"(fC), [fD] "v"(fD), [fR] "v"(fR)
+      : "vcc", "scc");
+}
+__device__ __forceinline__ void rowsCommit4(const int g, const uint32_t aw, uint32_t& fA, uint32_t& fB, uint32_t& fC, uint32_t& fD, const uint32_t hA,
+                                            const uint32_t hB, const uint32_t hC, const uint32_t hD) {
+  asm volatile(
+      "s_bitcmp1_b32 %[aw], %[g]\n\t"
+      "s_cbranch_scc0 2f\n\t"
+      "v_mov_b32 %[fA], %[hA]\n\t"
+      "v_mov_b32 %[fB], %[hB]\n\t"
+      "v_mov_b32 %[fC], %[hC]\n\t"
+      "v_mov_b32 %[fD], %[hD]\n\t"
+      "2:\n\t"
+      : [fA] "+v"(fA), [fB] "+v"(fB), [fC] "+v"(fC), [fD] "+v"(fD)
+      : [aw] "s"(aw), [g] "n"(g), [hA] "v"(hA), [hB] "v"(hB), [hC] "v"(hC), [hD] "v"(hD)
+      : "scc");
+}
+template <int W>
+__device__ __forceinline__ void bfsRowsGrid(const PlannerDev& pl, const uint32_t inst, const int which, const uint32_t item) {
+  constexpr int NG = (W + 3) / 4;         // groups of four words
+  constexpr int WP = NG * 4;              // words kept per row: W rounded up (the extra ones are blocked everywhere)
+  constexpr int D = kRowsHalo;
+  int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, care_ok = 0;  // the robot's region (box + 2 cells) and whether its pockets are known
+  if (pl.bfs_bounded) {
+    const int4 bb = reinterpret_cast<const int4*>(pl.bfs_box)[2 * inst];
+    bx0 = __builtin_amdgcn_readfirstlane(bb.x);
+    bx1 = __builtin_amdgcn_readfirstlane(bb.y);
+    by0 = __builtin_amdgcn_readfirstlane(bb.z);
+    by1 = __builtin_amdgcn_readfirstlane(bb.w);
+    care_ok = __builtin_amdgcn_readfirstlane(pl.bfs_box[8 * inst + 4]);
+  }
+  if (!(bx1 >= bx0 && by1 >= by0)) return;  // (uniform over the workgroup) a whole-grid search: the plane variant's item
+  extern __shared__ __align__(16) uint32_t sm[];
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_flag[3];  // rotating by exchange: something new was reached since the last one
+  __shared__ uint32_t s_open[3];  //                       something of the robot's box is still open
+  uint32_t tid_ = threadIdx.x, nx_ = pl.nx, ny_ = pl.ny;
+  asm volatile("" : "+v"(tid_), "+s"(nx_), "+s"(ny_));  // opaque per item, as in bfsWaveGrid
+  const uint32_t tid = tid_;
+  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 8] = wall_clock64();
+  const Geom g = geomOf(pl, inst);
+  const uint32_t nx = nx_, ny = ny_, Wr = (nx + 31) >> 5;  // Wr <= W words really exist
+  const uint32_t nw = blockDim.x >> 6;
+  const uint32_t lane = tid & 63u, wave_id = tid >> 6;
+  // lanes D .. 63 - D own rows wave * 50 .. wave * 50 + 49; the D lanes on either side copy the neighbouring waves' rows
+  const int row_i = (int)(wave_id * kRowsPerWave + lane) - D;
+  const bool real = row_i >= 0 && row_i < (int)ny;           // the lane's row exists (own or halo)
+  const bool owner = real && lane >= (uint32_t)D && lane < 64u - D;
+  const uint32_t row = real ? (uint32_t)row_i : 0u;
+  const uint32_t rows_p = nw * kRowsPerWave;
+  const uint32_t seed_words = (rows_p * Wr + 3u) & ~3u;
+  uint32_t* seedm = sm;                                   // [rows_p][Wr], padded to whole 16 bytes
+  uint32_t* care_l = sm + seed_words;                     // [kCareRows][kCareWords]
+  uint32_t* edge = care_l + kCareRows * kCareWords;       // [nw + 2][top | bottom][D rows][frontier WP | blocked WP]; slot = wave + 1
+  const uint32_t edge_words = (nw + 2) * 2 * D * 2 * WP;
+  const uint8_t* master = pl.master + (size_t)inst * pl.cells_padded;
+  const uint32_t* freew = pl.bfs_free + (size_t)inst * ny * Wr;
+  uint32_t* dist = (which == 0 ? pl.path : (which == 1 ? pl.goal : pl.goal_front)) + (size_t)inst * pl.cells;
+  const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
+  const uint32_t last_mask = (nx & 31) ? ((1u << (nx & 31)) - 1u) : 0xFFFFFFFFu;
+  const bool aligned4 = (nx & 3) == 0;
+
+  for (uint32_t i = tid; i < seed_words + kCareRows * kCareWords + edge_words; i += blockDim.x) sm[i] = 0;
+  if (tid < 3) s_flag[tid] = s_open[tid] = 0;
+  __syncthreads();
+  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 8 + 4] = wall_clock64();
+  if (care_ok) {  // the pocket mask of the robot's box: by region row, four words from the region's first (k_samples)
+    const uint32_t* care = pl.bfs_care + (size_t)inst * kCareRows * kCareWords;
+    for (uint32_t i = tid; i < (uint32_t)(kCareRows * kCareWords); i += blockDim.x) care_l[i] = care[i];
+  }
+  // --- seeds from the plan (as bfsWaveGrid)
+  {
+    const uint32_t n = pl.plan_count[inst];
+    const double* P = pl.plan + (size_t)inst * pl.max_plan * 2;
+    const bool ovr = which == 2;
+    const double lx = pl.front_last[2 * inst], ly = pl.front_last[2 * inst + 1];
+    const uint32_t chunk = (n + blockDim.x - 1) / blockDim.x;
+    const uint32_t i0 = min(n, tid * chunk), i1 = min(n, i0 + chunk);
+    uint32_t mine = 0;
+    for (uint32_t i = i0; i < i1; ++i) mine += adjustedPoints(P, i, lx, ly, ovr, n, g.res, true, [](uint32_t, double, double) {});
+    uint32_t total;
+    const uint32_t base = blockExclusiveScan1024(mine, s_wave, &total);
+    auto valid = [&](double x, double y, uint32_t& cell) {
+      uint32_t mx, my;
+      if (!worldToMap(g, x, y, mx, my)) return false;
+      cell = my * nx + mx;
+      return master[cell] != kNoInfo;
+    };
+    uint32_t fmin_ = 0xFFFFFFFFu, b = base;
+    for (uint32_t i = i0; i < i1; ++i)
+      b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+        uint32_t cell;
+        if (valid(x, y, cell)) fmin_ = min(fmin_, b + k);
+      });
+    const uint32_t f = blockMin1024(fmin_, s_wave);
+    if (f != 0xFFFFFFFFu) {
+      uint32_t emin = total;
+      b = base;
+      for (uint32_t i = i0; i < i1; ++i)
+        b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+          uint32_t cell;
+          if (b + k > f && !valid(x, y, cell)) emin = min(emin, b + k);
+        });
+      const uint32_t e = blockMin1024(emin, s_wave);
+      b = base;
+      for (uint32_t i = i0; i < i1; ++i)
+        b += adjustedPoints(P, i, lx, ly, ovr, n, g.res, false, [&](uint32_t k, double x, double y) {
+          const uint32_t idx = b + k;
+          const bool seed = (which == 0) ? (idx >= f && idx < e) : (idx == e - 1);
+          if (!seed) return;
+          uint32_t cell;
+          if (!valid(x, y, cell)) return;
+          const uint32_t my = cell / nx, mx = cell - my * nx;
+          atomicOr(&seedm[my * Wr + (mx >> 5)], 1u << (mx & 31));  // a few hundred seeds, once
+        });
+    }
+  }
+  __syncthreads();
+  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 8 + 5] = wall_clock64();
+
+  uint32_t blocked[WP], fr[WP];
+#pragma unroll
+  for (int j = 0; j < WP; ++j) {
+    blocked[j] = 0xFFFFFFFFu;  // rows beyond the grid and words beyond the row never produce cells
+    fr[j] = 0;
+    if (real && (uint32_t)j < Wr) {  // (halo lanes too: exact copies of the neighbours' rows)
+      fr[j] = seedm[row * Wr + j];  // seeds expand whatever their cost (map_grid.cpp:160-187)
+      blocked[j] = ~(freew[row * Wr + j] & ((uint32_t)j + 1 == Wr ? last_mask : 0xFFFFFFFFu)) | fr[j];
+    }
+  }
+  // the region in this lane's terms
+  const bool wave_in_box = (int)(wave_id * kRowsPerWave) <= by1 && (int)((wave_id + 1) * kRowsPerWave) > by0;  // wave-uniform
+  const bool row_in_box = owner && row_i >= by0 && row_i <= by1;
+  const int w0 = bx0 >> 5, w1 = bx1 >> 5;
+  uint32_t region_groups = 0;  // groups that hold words of the region
+  for (int jr = w0; jr <= w1; ++jr) region_groups |= 1u << (jr >> 2);
+  uint32_t* drow = dist + (size_t)row * nx;
+  // distances of the cells `cells` of word j of this lane's row.  Two plain bit loops (every lane runs the longest one, so
+  // their bodies are kept to a find-first-bit, an address and a store): whole aligned groups of four first - fronts that
+  // run along a row reach 32 cells of a word at once - then what is left, cell by cell
+  auto storeCells = [&](int j, uint32_t cells, uint32_t value) {
+    uint32_t* dw = drow + j * 32;
+    if (aligned4) {
+      uint32_t full = cells & (cells >> 1) & (cells >> 2) & (cells >> 3) & 0x11111111u;
+      cells &= ~(full * 15u);
+      const uint4 v4 = make_uint4(value, value, value, value);
+      while (full) {
+        const uint32_t bpos = (uint32_t)__ffs(full) - 1u;
+        *reinterpret_cast<uint4*>(dw + bpos) = v4;
+        full &= full - 1;
+      }
+    }
+    while (cells) {
+      const uint32_t bpos = (uint32_t)__ffs(cells) - 1u;
+      dw[bpos] = value;
+      cells &= cells - 1;
+    }
+  };
+  // LDS offsets (words) of the 2 * WP-word row record this lane publishes / takes in at an exchange:
+  //   own rows 0 .. D-1 (lanes D .. 2D-1) -> this wave's TOP record, read by the wave above into its lanes 64-D .. 63;
+  //   own rows 50-D .. 49 (lanes 64-2D .. 63-D) -> BOTTOM record, read by the wave below into its lanes 0 .. D-1
+  const bool pub_top = lane >= (uint32_t)D && lane < 2u * D, pub_bot = lane >= 64u - 2 * D && lane < 64u - D;
+  const uint32_t pub_wr = (((wave_id + 1) * 2 + (pub_top ? 0u : 1u)) * D + (pub_top ? lane - D : lane - (64u - 2 * D))) * 2 * WP;
+  const bool halo_top = lane < (uint32_t)D, halo_bot = lane >= 64u - D;
+  const uint32_t halo_rd = ((halo_top ? (wave_id * 2 + 1) : ((wave_id + 2) * 2)) * D + (halo_top ? lane : lane - (64u - D))) * 2 * WP;
+  constexpr uint32_t gmask = (1u << NG) - 1u;
+
+  // which groups hold or border a frontier cell of this wave's 64 rows
+  auto activity = [&]() -> uint32_t {
+    uint32_t nz = 0, lo = 0, hi = 0;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      const uint32_t t = fr[4 * q] | fr[4 * q + 1] | fr[4 * q + 2] | fr[4 * q + 3];
+      if (__builtin_amdgcn_ballot_w64(t != 0) != 0) {
+        nz |= 1u << q;
+        if (__builtin_amdgcn_ballot_w64(fr[4 * q] != 0) != 0) lo |= 1u << q;
+        if (__builtin_amdgcn_ballot_w64(fr[4 * q + 3] != 0) != 0) hi |= 1u << q;
+      }
+    }
+    return (nz | (lo >> 1) | (hi << 1)) & gmask;
+  };
+  if (wave_in_box) {
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+      if (j >= w0 && j <= w1 && row_in_box) storeCells(j, fr[j], 0u);  // the seeds: distance 0
+  }
+  uint32_t a_own = activity();
+  uint32_t level = 0, xch = 0, any_blk = 0;
+  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 8 + 2] = wall_clock64();
+  bool done = false;
+#ifdef NAVGPU_BFS_STATS
+  unsigned long long bst[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  while (!done) {
+    // ---- D levels on the wave's own: registers and DPP only
+    for (int k = 0; k < D; ++k) {
+      BFS_STAMP(ts1);
+      BFS_ACC(5, 1);
+      const uint32_t aw = __builtin_amdgcn_readfirstlane(a_own);  // (provably uniform, but the "s" operands below need the compiler to know it)
+      BFS_ACC(7, aw != 0 ? 1 : 0);
+      BFS_ACC(8, __builtin_popcount(aw));
+      if (aw != 0) {
+        uint32_t nz = 0, lo = 0, hi = 0;
+        // One group = one asm statement that carries its own wave-uniform skip, so the compiler sees straight-line code
+        // with in-place (tied) updates of `blocked` and `fr`.  (Written as C++ branches the same loop made it rename both
+        // arrays per word: register copies in the path of every SKIPPED word and a dozen more at the loop's back edge.)
+        // A group's new frontier waits in h[] until the NEXT group has read the old words (its left neighbour), then goes back.
+        uint32_t h[2][4];
+        const uint32_t zero = 0;
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+          rowsGroup4(q, aw, nz, lo, hi, blocked[4 * q], blocked[4 * q + 1], blocked[4 * q + 2], blocked[4 * q + 3],
+                     q > 0 ? fr[q > 0 ? 4 * q - 1 : 0] : zero, fr[4 * q], fr[4 * q + 1], fr[4 * q + 2], fr[4 * q + 3],
+                     q + 1 < NG ? fr[q + 1 < NG ? 4 * q + 4 : 0] : zero, h[q & 1][0], h[q & 1][1], h[q & 1][2], h[q & 1][3]);
+          if (q > 0) {
+            const int p = q > 0 ? q - 1 : 0;
+            rowsCommit4(p, aw, fr[4 * p], fr[4 * p + 1], fr[4 * p + 2], fr[4 * p + 3], h[p & 1][0], h[p & 1][1], h[p & 1][2], h[p & 1][3]);
+          }
+        }
+        rowsCommit4(NG - 1, aw, fr[4 * (NG - 1)], fr[4 * (NG - 1) + 1], fr[4 * (NG - 1) + 2], fr[4 * (NG - 1) + 3], h[(NG - 1) & 1][0], h[(NG - 1) & 1][1],
+                    h[(NG - 1) & 1][2], h[(NG - 1) & 1][3]);
+        BFS_STAMP(ts2);
+        BFS_ACC(1, ts2 - ts1);
+        // the new cells of the robot's region get their distance now, from the lane that owns the row
+        if (wave_in_box && (nz & region_groups) != 0) {
+#pragma unroll
+          for (int q = 0; q < NG; ++q) {
+            if (((nz & region_groups) >> q) & 1u) {  // wave-uniform
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const int j = 4 * q + c;
+                if (j < W && j >= w0 && j <= w1) {
+                  if (row_in_box && fr[j < W ? j : 0] != 0) storeCells(j, fr[j < W ? j : 0], level + 1);
+                }
+              }
+            }
+          }
+        }
+        BFS_STAMP(ts3);
+        BFS_ACC(2, ts3 - ts2);
+        any_blk |= nz;
+        a_own = (nz | (lo >> 1) | (hi << 1)) & gmask;
+      }
+      ++level;
+    }
+    // ---- exchange: the outer D own rows go to the neighbours, theirs come into the halo lanes; stop flags
+    BFS_STAMP(ts4);
+    const uint32_t slot = xch % 3u;
+    if (pub_top || pub_bot) {
+#pragma unroll
+      for (int q = 0; q < WP; q += 4) {
+        *reinterpret_cast<uint4*>(edge + pub_wr + q) = make_uint4(fr[q], fr[q + 1], fr[q + 2], fr[q + 3]);
+        *reinterpret_cast<uint4*>(edge + pub_wr + WP + q) = make_uint4(blocked[q], blocked[q + 1], blocked[q + 2], blocked[q + 3]);
+      }
+    }
+    if (any_blk) s_flag[slot] = 1;
+    if (wave_in_box) {  // wave-uniform: is anything of the robot's box still open, or a frontier cell inside the region?
+      uint32_t open_any = 0;
+      const uint32_t rr = (uint32_t)(row_i - by0);
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        if (j >= w0 && j <= w1) {  // wave-uniform
+          const uint32_t cw_i = (uint32_t)(j - w0);
+          if (row_in_box) {
+            const uint32_t care = (care_ok != 0 && cw_i < (uint32_t)kCareWords && rr < (uint32_t)kCareRows) ? care_l[rr * kCareWords + cw_i] : (care_ok ? 0u : 0xFFFFFFFFu);
+            const int c_lo = max(bx0 - j * 32, 0), c_hi = min(bx1 - j * 32, 31);
+            const uint32_t open = (~blocked[j] & care) | fr[j];
+            if (c_hi >= c_lo) open_any |= open & (0xFFFFFFFFu >> (31 - c_hi)) & (0xFFFFFFFFu << c_lo);
+          }
+        }
+      }
+      if (open_any != 0) s_open[slot] = 1;
+    }
+    if (tid == 0) {
+      s_flag[(xch + 1) % 3u] = 0;
+      s_open[(xch + 1) % 3u] = 0;
+    }
+    BFS_STAMP(ts5);
+    BFS_ACC(3, ts5 - ts4);
+    __syncthreads();
+    done = !s_flag[slot] || !s_open[slot];  // nothing new in D levels, or nothing open in the box: the search is over
+    if (!done) {
+      if ((halo_top || halo_bot) && real) {
+#pragma unroll
+        for (int q = 0; q < WP; q += 4) {
+          const uint4 v = *reinterpret_cast<const uint4*>(edge + halo_rd + q);
+          const uint4 b = *reinterpret_cast<const uint4*>(edge + halo_rd + WP + q);
+          fr[q] = v.x;
+          fr[q + 1] = v.y;
+          fr[q + 2] = v.z;
+          fr[q + 3] = v.w;
+          blocked[q] = b.x;
+          blocked[q + 1] = b.y;
+          blocked[q + 2] = b.z;
+          blocked[q + 3] = b.w;
+        }
+      }
+      a_own = activity();
+      __syncthreads();  // the records are free for the next exchange
+    }
+    ++xch;
+    any_blk = 0;
+    BFS_STAMP(ts6);
+    BFS_ACC(4, ts6 - ts5);
+  }
+#ifdef NAVGPU_BFS_STATS
+  if (lane == 0)
+    for (int k = 0; k < 9; ++k) atomicAdd(&g_bfs_stats[k], bst[k]);
+#endif
+  if (pl.bfs_trace && tid == 0) pl.bfs_trace[(size_t)item * 8 + 3] = wall_clock64();
+
+  // --- the rest of the region: obstacle cells an expanded cell touched -> obstacleCosts(), everything else that was not
+  // reached -> unreachableCellCosts().  Expanded = reached free cells + seeds.  (The halo lanes next to the own rows are
+  // exact copies as of the last exchange; the own rows have moved on since, so their neighbours are exchanged once more.)
+  __syncthreads();
+  {
+    uint32_t ex[WP], fb[WP];
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      const bool in = owner && (uint32_t)j < Wr;
+      fb[j] = in ? (freew[row * Wr + j] & ((uint32_t)j + 1 == Wr ? last_mask : 0xFFFFFFFFu)) : 0u;
+      ex[j] = in ? ((blocked[j] & fb[j]) | seedm[row * Wr + j]) : 0u;
+    }
+    if (pub_top || pub_bot) {
+#pragma unroll
+      for (int j = 0; j < WP; ++j) edge[pub_wr + j] = ex[j];
+    }
+    __syncthreads();
+    if ((halo_top || halo_bot) && real) {
+#pragma unroll
+      for (int j = 0; j < WP; ++j) ex[j] = edge[halo_rd + j];
+    }
+    if (wave_in_box) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        if (j >= w0 && j <= w1) {  // wave-uniform
+          const uint32_t fc = ex[j];
+          const uint32_t lw = j > 0 ? ex[j > 0 ? j - 1 : 0] : 0u, rw = j + 1 < WP ? ex[j + 1 < WP ? j + 1 : 0] : 0u;
+          const uint32_t nbr = __builtin_amdgcn_alignbit(fc, lw, 31) | __builtin_amdgcn_alignbit(rw, fc, 1) | fromLaneBelow(fc) | fromLaneAbove(fc);
+          const uint32_t cm = (uint32_t)j + 1 == Wr ? last_mask : ((uint32_t)j < Wr ? 0xFFFFFFFFu : 0u);
+          const uint32_t touched = nbr & ~fb[j] & ~fc & cm;
+          if (row_in_box) {
+            storeCells(j, touched, N_obst);
+            storeCells(j, ~fc & ~touched & cm, N_unreach);
+          }
+        }
+      }
+    }
+  }
+  if (pl.bfs_trace && tid == 0) {
+    pl.bfs_trace[(size_t)item * 8 + 6] = wall_clock64();
+    pl.bfs_trace[(size_t)item * 8 + 1] = wall_clock64() | ((unsigned long long)level << 48);
+  }
+  if (tid == 0) pl.bfs_levels[(size_t)inst * 3 + which] = level;  // next cycle's dispatch order
+}
+template <int W>
+__global__ __launch_bounds__(1024, 6) void k_bfs_rows(PlannerDev pl, uint32_t first, uint32_t count, uint32_t* next_item, const uint32_t* order) {
+  __shared__ uint32_t s_item;
+  const uint32_t total = count * 3u;
+  for (;;) {
+    if (threadIdx.x == 0) s_item = atomicAdd(next_item, 1u);
+    __syncthreads();
+    const uint32_t slot = s_item;
+    if (slot >= total) break;  // (every workgroup gets here: the counter only grows)
+    const uint32_t item = order ? order[slot] : slot;  // longest searches first
+    const uint32_t g = item / count;
+    bfsRowsGrid<W>(pl, first + (item - g * count), 2 - (int)g, item);
+    __syncthreads();
+  }
+}
+// words per row the register-resident row sweep is instantiated for; 0 = not this map's kernel
+static int bfs_rows_words(uint32_t nx, uint32_t ny) {
+  static const bool off = getenv("NAVGPU_DEBUG_BFS_NO_ROWS") != nullptr;  // A/B timing only
+  const uint32_t Wr = (nx + 31) / 32;
+  if (off || bfs_rows_waves(ny) > 16) return 0;
+  return Wr <= 7 ? 7 : (Wr <= 13 ? 13 : (Wr <= 20 ? 20 : 0));
+}
+
 // k_bfs_wave applies when all strips fit the 16 waves of one workgroup
 static bool bfs_wave_fits(uint32_t nx, uint32_t ny, int rpt) {
   const uint32_t W = (nx + 31) / 32;
@@ -1807,6 +2294,23 @@ static uint32_t bfs_direct_wgs_per_cu() {
   }();
   return v;
 }
+// the bounded searches of a DWA launch on the row sweep; false = not this map's kernel
+template <int W>
+static void launch_bfs_rows_w(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order) {
+  const uint32_t nw = bfs_rows_waves(pl.ny);
+  const size_t lds = bfs_rows_lds_words<W>(pl.nx, pl.ny) * 4;
+  if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_rows<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>(24u / nw, (uint32_t)((156u * 1024u) / (lds + 1024))), 2u * bfs_direct_wgs_per_cu()));
+  hipLaunchKernelGGL(k_bfs_rows<W>, dim3(std::min(count * 3u, per_cu * bfs_cu_count())), dim3(nw * 64), lds, s, pl, first, count, pl.bfs_next_item + 1, order);
+}
+static bool launch_bfs_rows(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order) {
+  switch (bfs_rows_words(pl.nx, pl.ny)) {
+    case 7: launch_bfs_rows_w<7>(pl, first, count, s, order); return true;
+    case 13: launch_bfs_rows_w<13>(pl, first, count, s, order); return true;
+    case 20: launch_bfs_rows_w<20>(pl, first, count, s, order); return true;
+    default: return false;
+  }
+}
 void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order, bool free_ready, int n_whole) {
   // n_whole: how many of the robots search their whole grid this cycle (< 0 = unknown / all): a bounded launch runs the
   // DIRECT variant for the bounded searches and, only if there are any, the plane variant for the others
@@ -1830,6 +2334,7 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
     if (!direct || n_whole > 0)                                                                                               \
       hipLaunchKernelGGL((k_bfs_wave<R, LEG, P>), dim3(std::min(count * pl.bfs_grids, bfs_cu_count())), dim3(1024), lds_w, s, pl, first, count, pl.bfs_next_item, order, direct ? 1 : 0); \
     if constexpr (!LEG) {                                                                                                     \
+      if (direct && launch_bfs_rows(pl, first, count, s, order)) return;                                                       \
       if (direct) {                                                                                                           \
         if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<R, false, P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); \
         hipLaunchKernelGGL((k_bfs_wave<R, false, P, true>), dim3(std::min(count * pl.bfs_grids, std::min(bfs_direct_wgs_per_cu(), 2 * lds_w <= 156u * 1024u ? 2u : 1u) * bfs_cu_count())), dim3(1024), lds_w, s, pl, first, count, pl.bfs_next_item + 1, order, 0); \
@@ -3184,6 +3689,16 @@ __global__ __launch_bounds__(64) void k_stage_poses(PoseChunk c) {
 }
 void launch_stage_poses(const PoseChunk& c, hipStream_t s) { hipLaunchKernelGGL(k_stage_poses, dim3(1), dim3(64), 0, s, c); }
 
+#ifdef NAVGPU_BFS_STATS
+extern "C" int navgpu_debug_bfs_stats(unsigned long long* out16, int reset) {
+  if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bfs_stats), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_bfs_stats), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 #if defined(NAVGPU_SCORE_STATS) || defined(NAVGPU_SCORE_TIMING)
 extern "C" int navgpu_debug_score_stats(unsigned long long* out8, int reset) {
   if (out8) hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_score_stats), sizeof(unsigned long long) * 24);
