@@ -1261,6 +1261,7 @@ __host__ __device__ inline size_t bfs_rows_lds_words(uint32_t nx, uint32_t ny) {
 // One group of four words (A B C D, left neighbour word L, right neighbour word R) of one level, skipped as a whole when
 // bit g of the wave's active mask is clear.  Per word:
 //   x = (f << 1 | left >> 31) | (f >> 1 | right << 31) | up | down;   cand = x & ~blocked;   blocked |= x
+// (six vector instructions: two v_alignbit, two v_or with the DPP row shift folded in, v_bitop3, v_or3)
 // cand* leave in h* (the words are written back by rowsCommit4 once every group has read the old frontier).
 // nz: bit g set when any lane has new cells in the group; lo / hi: when its first / last word has (the neighbouring
 // group borders them next level).
@@ -1272,10 +1273,6 @@ __device__ __forceinline__ void rowsGroup4(const int g, const uint32_t aw, uint3
   asm volatile(
       "s_bitcmp1_b32 %[aw], %[g]\n\t"
       "s_cbranch_scc0 1f\n\t"
-      "v_mov_b32_dpp %[tA], %[fA] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_mov_b32_dpp %[tB], %[fB] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_mov_b32_dpp %[tC], %[fC] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_mov_b32_dpp %[tD], %[fD] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_alignbit_b32 %[uA], %[fA], %[fL], 31\n\t"
       "v_alignbit_b32 %[uB], %[fB], %[fA], 31\n\t"
       "v_alignbit_b32 %[uC], %[fC], %[fB], 31\n\t"
@@ -1284,14 +1281,14 @@ __device__ __forceinline__ void rowsGroup4(const int g, const uint32_t aw, uint3
       "v_alignbit_b32 %[hB], %[fC], %[fB], 1\n\t"
       "v_alignbit_b32 %[hC], %[fD], %[fC], 1\n\t"
       "v_alignbit_b32 %[hD], %[fR], %[fD], 1\n\t"
-      "v_or3_b32 %[tA], %[tA], %[uA], %[hA]\n\t"
-      "v_or3_b32 %[tB], %[tB], %[uB], %[hB]\n\t"
-      "v_or3_b32 %[tC], %[tC], %[uC], %[hC]\n\t"
-      "v_or3_b32 %[tD], %[tD], %[uD], %[hD]\n\t"
-      "v_mov_b32_dpp %[uA], %[fA] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_mov_b32_dpp %[uB], %[fB] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_mov_b32_dpp %[uC], %[fC] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_mov_b32_dpp %[uD], %[fD] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %[tA], %[fA], %[uA] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %[tB], %[fB], %[uB] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %[tC], %[fC], %[uC] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %[tD], %[fD], %[uD] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %[uA], %[fA], %[hA] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %[uB], %[fB], %[hB] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %[uC], %[fC], %[hC] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %[uD], %[fD], %[hD] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
       "v_bitop3_b32 %[hA], %[tA], %[bA], %[uA] bitop3:0x32\n\t"
       "v_bitop3_b32 %[hB], %[tB], %[bB], %[uB] bitop3:0x32\n\t"
       "v_bitop3_b32 %[hC], %[tC], %[bC], %[uC] bitop3:0x32\n\t"

@@ -37,85 +37,46 @@ struct TpWorld {
     if (cost == kLethal || (cost == kNoInfo && !allow_unknown)) return -1;
     return cost;
   }
-  __device__ double lineCost(int x0, int x1, int y0, int y1) const {  // LineIterator (line_iterator.h:38-139)
-    int deltax = x1 - x0, deltay = y1 - y0;
-    deltax = deltax < 0 ? -deltax : deltax;
-    deltay = deltay < 0 ? -deltay : deltay;
-    int x = x0, y = y0;
-    int xinc1, xinc2, yinc1, yinc2, den, num, numadd, numpixels;
-    xinc1 = xinc2 = (x1 >= x0) ? 1 : -1;
-    yinc1 = yinc2 = (y1 >= y0) ? 1 : -1;
-    if (deltax >= deltay) {
-      xinc1 = 0;
-      yinc2 = 0;
-      den = deltax;
-      num = deltax / 2;
-      numadd = deltay;
-      numpixels = deltax;
-    } else {
-      xinc2 = 0;
-      yinc1 = 0;
-      den = deltay;
-      num = deltay / 2;
-      numadd = deltax;
-      numpixels = deltay;
+  // The cells of base_local_planner::LineIterator (line_iterator.h:38-139) from (x0, y0) to (x1, y1), both ends included:
+  // the longer axis advances with every cell, the shorter one whenever the running remainder - which starts at half the
+  // long extent - passes it.  visit(x, y) returns false to end the walk; the return value says whether it ran to the end.
+  template <class Visit>
+  __device__ static bool forEachLineCell(int x0, int y0, int x1, int y1, Visit&& visit) {
+    const int ex = x1 >= x0 ? x1 - x0 : x0 - x1, ey = y1 >= y0 ? y1 - y0 : y0 - y1;
+    const int sx = x1 >= x0 ? 1 : -1, sy = y1 >= y0 ? 1 : -1;
+    const bool along_x = ex >= ey;
+    const int long_ext = along_x ? ex : ey, short_ext = along_x ? ey : ex;
+    int rem = long_ext / 2, x = x0, y = y0;
+    for (int k = 0; k <= long_ext; ++k) {
+      if (!visit(x, y)) return false;
+      rem += short_ext;
+      const bool side = rem >= long_ext;
+      if (side) rem -= long_ext;
+      x += along_x ? sx : (side ? sx : 0);
+      y += along_x ? (side ? sy : 0) : sy;
     }
-    double line_cost = 0.0;
-    for (int curpixel = 0; curpixel <= numpixels; ++curpixel) {
-      const double pc = pointCost(x, y);
-      if (pc < 0) return -1;
-      if (line_cost < pc) line_cost = pc;
-      num += numadd;
-      if (num >= den) {
-        num -= den;
-        x += xinc1;
-        y += yinc1;
-      }
-      x += xinc2;
-      y += yinc2;
-    }
-    return line_cost;
+    return true;
+  }
+  // maximum cost over the line's cells, -1 as soon as one of them fails `fails(cost)`
+  template <class Fails>
+  __device__ double lineMax(int x0, int y0, int x1, int y1, Fails&& fails) const {
+    double worst = 0.0;
+    const bool clear = forEachLineCell(x0, y0, x1, y1, [&](int x, int y) {
+      const uint8_t cost = master[(uint32_t)y * g.nx + (uint32_t)x];
+      if (fails(cost)) return false;
+      if (worst < (double)cost) worst = (double)cost;
+      return true;
+    });
+    return clear ? worst : -1.0;
+  }
+  // CostmapModel::lineCost (costmap_model.cpp:104-125): a cell fails like pointCost
+  __device__ double lineCost(int x0, int x1, int y0, int y1) const {
+    return lineMax(x0, y0, x1, y1, [&](uint8_t cost) { return cost == kLethal || (cost == kNoInfo && !allow_unknown); });
   }
   // TrajectoryPlanner::pointCost / lineCost (trajectory_planner.cpp:388-472): the planner's own ray walk for headingDiff;
   // unlike CostmapModel::pointCost it fails on INSCRIBED cells too
   __device__ double planLineCost(int x0, int x1, int y0, int y1) const {
-    int deltax = x1 - x0, deltay = y1 - y0;
-    deltax = deltax < 0 ? -deltax : deltax;
-    deltay = deltay < 0 ? -deltay : deltay;
-    int x = x0, y = y0;
-    int xinc1, xinc2, yinc1, yinc2, den, num, numadd, numpixels;
-    xinc1 = xinc2 = (x1 >= x0) ? 1 : -1;
-    yinc1 = yinc2 = (y1 >= y0) ? 1 : -1;
-    if (deltax >= deltay) {
-      xinc1 = 0;
-      yinc2 = 0;
-      den = deltax;
-      num = deltax / 2;
-      numadd = deltay;
-      numpixels = deltax;
-    } else {
-      xinc2 = 0;
-      yinc1 = 0;
-      den = deltay;
-      num = deltay / 2;
-      numadd = deltax;
-      numpixels = deltay;
-    }
-    double line_cost = 0.0;
-    for (int curpixel = 0; curpixel <= numpixels; ++curpixel) {
-      const uint8_t cost = master[(uint32_t)y * g.nx + (uint32_t)x];
-      if (cost == kLethal || cost == kInscribed || (cost == kNoInfo && !allow_unknown)) return -1;
-      if (line_cost < (double)cost) line_cost = (double)cost;
-      num += numadd;
-      if (num >= den) {
-        num -= den;
-        x += xinc1;
-        y += yinc1;
-      }
-      x += xinc2;
-      y += yinc2;
-    }
-    return line_cost;
+    return lineMax(x0, y0, x1, y1, [&](uint8_t cost) { return cost == kLethal || cost == kInscribed || (cost == kNoInfo && !allow_unknown); });
   }
   // TrajectoryPlanner::headingDiff (:372-386): the farthest plan pose with a clear line of sight from the robot's cell
   __device__ double headingDiff(int cell_x, int cell_y, double x, double y, double heading, const double* plan, uint32_t n_plan) const {
