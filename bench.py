@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py — fleet throughput of the MI355X-native costmap + DWA hot path.
+"""bench.py - fleet throughput of the MI355X-native costmap + DWA hot path.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 launched by torch.distributed.run,
-one rank per GPU).  One *step* = one pass of the hot path over one batch: for every robot
-instance of the rank's fleet a LayeredCostmap::updateMap (LaserScan clearing + marking + merge +
-inflation) followed by a DWAPlanner::findBestPath (3 MapGrid wavefronts + rollout + six critics +
-selection).  Inputs are staged in HBM before the timed region.
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 launched by torch.distributed.run, one rank per GPU).
+One *step* = one control cycle of every robot of the rank's fleet, by SURVEY 8(d)'s protocol: the cycle's NEW LaserScan
+cloud, its pose / velocity and its plan are handed over from host memory (H2D), then LayeredCostmap::updateMap
+(clearing + marking + merge + inflation) and DWAPlanner::findBestPath (3 MapGrid wavefronts + rollout + six critics +
+selection), and the results come back to host memory (D2H).  The costmaps themselves stay resident in HBM.
 
-Workload (config.workload): BASELINE.json's metric is a whole-node throughput, quoted on the
-fleet configurations; configs[3] (2048 instances over 8 GPUs) does not fit one GPU, so at N=1 the
-workload is the largest single-GPU configuration, configs[2]: 256 batched robot instances on one
-MI355X, 400x400 costmaps, 32x32x16 samples, 20 sim steps, LaserScan update each cycle.  At N GPUs
-every rank runs the same 256 instances (weak scaling; N=8 is configs[3]).  The single-robot
-configs[1] latency is reported beside it in "single_robot".
+Workload (config.workload): BASELINE.json's metric is a whole-node throughput, quoted on the fleet configurations;
+configs[3] (2048 instances over 8 GPUs) does not fit one GPU, so at N=1 the workload is the largest single-GPU
+configuration, configs[2]: 256 batched robot instances on one MI355X, 400x400 costmaps, 32x32x16 samples, 20 sim steps,
+a new LaserScan every cycle.  At N GPUs every rank runs the same 256 instances (weak scaling; N=8 is configs[3]).
+
+The fleet runs as --groups G independent groups of 256 / G robots, each with its own HIP stream (a navgpu fleet = one
+stream; robots are independent, so any partition gives the same results).  While the host hands group g's next cycle
+over, the other groups' cycles are queued on the GPU: the PCIe transfers hide behind their kernels, and the
+latency-bound wavefront kernels of one group overlap the issue-bound scoring kernels of another.
 
 Prints ONE JSON line on rank 0.
 """
@@ -30,13 +33,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 T_STEPS, P_PERIM, G_GRIDS = 20, 32, 4
-BYTES_PER_TRAJ = 20 + T_STEPS * (P_PERIM + 1) + T_STEPS * G_GRIDS * 4  # = 1000 B (SURVEY §8d)
+BYTES_PER_TRAJ = 20 + T_STEPS * (P_PERIM + 1) + T_STEPS * G_GRIDS * 4  # = 1000 B (SURVEY 8d)
 BYTES_PER_BFS_CELL = 5       # 1 B costmap read + 4 B distance write, per grid
 BYTES_PER_INFL_CELL = 2
 BYTES_PER_MERGE_CELL = 3
+SCAN_CYCLES = 8              # distinct pre-marshalled LaserScan clouds per robot (the discs move from one to the next)
 
 
-def build_fleet(nav, n_inst, n_cells, seed0, device=0, vs=(32, 32, 16), footprint="square"):
+def build_fleet(nav, n_inst, n_cells, seed0, device=0, vs=(32, 32, 16), footprint="square", insts=None):
     from navigation_amd import _lib as N, synth
     fp = synth.FOOTPRINT5 if footprint == "poly5" else synth.FOOTPRINT
     fl = nav.Fleet(n_inst, n_cells, n_cells, synth.RES, layers=N.LAYER_STATIC | N.LAYER_OBSTACLE | N.LAYER_INFLATION,
@@ -46,13 +50,14 @@ def build_fleet(nav, n_inst, n_cells, seed0, device=0, vs=(32, 32, 16), footprin
     fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, synth.inscribed_radius(fp))
     cfg = synth.fleet_config(*vs)
     fl.configure_planner(cfg)
-    insts = [synth.make_instance(n_cells, seed0 + i) for i in range(n_inst)]
+    if insts is None:
+        insts = [synth.make_instance(n_cells, seed0 + i) for i in range(n_inst)]
     for i, ins in enumerate(insts):
         fl.add_static_map(np.where(ins["cells"] == 254, 100, 0).astype(np.int8), first=i, count=1)
     poses = np.array([[float(v) for v in ins["pos"]] for ins in insts])
     obs = []
     for i, ins in enumerate(insts):
-        pts = synth.laser_scan(ins, 0)
+        pts = cached_scan(synth, ins, 0)
         obs.append(dict(instance=i, points=pts, origin=(float(ins["pos"][0]), float(ins["pos"][1]), 0.3),
                         obstacle_range=2.5, raytrace_range=3.0))
     fl.stage_observations(poses, obs)
@@ -61,38 +66,113 @@ def build_fleet(nav, n_inst, n_cells, seed0, device=0, vs=(32, 32, 16), footprin
     fl.set_plan()
     fl._bench_host_inputs = (poses, obs, np.stack([i["pos"] for i in insts]), np.stack([i["vel"] for i in insts]),
                              np.stack([i["plan"] for i in insts]))
+    fl._bench_insts = insts
     return fl, insts, cfg
 
 
-def raw_inputs(fl):
-    """Pre-marshalled ctypes/numpy buffers of one cycle's inputs (so the PCIe-inclusive leg times the
-    C-ABI staging calls, not Python list handling)."""
-    from navigation_amd._lib import Observation, RobotState, OBS_MARKING, OBS_CLEARING
-    poses, obs, pos, vel, plans = fl._bench_host_inputs
-    arr = (Observation * len(obs))()
-    pts, off = [], 0
-    for k, o in enumerate(obs):
-        p = np.ascontiguousarray(o["points"], np.float32)
-        arr[k] = Observation(o["instance"], off, len(p), OBS_MARKING | OBS_CLEARING, o["origin"][0], o["origin"][1],
-                             o["origin"][2], o["obstacle_range"], o["raytrace_range"])
-        pts.append(p)
-        off += len(p)
-    allp = np.ascontiguousarray(np.concatenate(pts), np.float32)
-    n = len(pos)
-    states = (RobotState * n)()
-    k = plans.shape[1]
-    for i in range(n):
-        states[i].pos[:] = [float(v) for v in pos[i]]
-        states[i].vel[:] = [float(v) for v in vel[i]]
-        states[i].plan_first = i * k
-        states[i].plan_count = k
-    packed = np.ascontiguousarray(plans, np.float64).reshape(-1, 2)
-    return poses, arr, len(obs), allp, states, n, packed
+def step(fl, poses=None, k=0):
+    """One pass of the hot path over a fleet with RESIDENT scans and plans (legs and probes; the timed region uses
+    Group.cycle).  With `poses` (a PoseSchedule) the cycle first stages its own pose and velocity."""
+    if poses is not None:
+        fl.stage_poses(poses.pos[k % len(poses.pos)], poses.vel)
+    fl.update_map()
+    fl.planner_cycle()
+
+
+class PoseSchedule:
+    """Seeded per-cycle poses: the robot of cycle k stands at base + N(0, 2 cm) and is turned by N(0, 0.05 rad), so that
+    successive cycles differ (wavefront lengths, reach boxes, which samples collide)."""
+
+    def __init__(self, pos, vel, n_cycles, seed):
+        rs = np.random.RandomState(seed)
+        d = rs.normal(size=(n_cycles,) + pos.shape) * np.array([0.02, 0.02, 0.05])
+        self.pos = [np.ascontiguousarray(pos + d[k], np.float32) for k in range(n_cycles)]
+        self.vel = np.ascontiguousarray(vel, np.float32)
+
+
+_SCANS = {}
+
+
+def cached_scan(synth, ins, cycle):
+    """synth.laser_scan(ins, cycle) as float32, kept per (robot, cycle): the one-stream leg re-uses the groups' clouds."""
+    key = (ins["cells"].ctypes.data, cycle)
+    if key not in _SCANS:
+        _SCANS[key] = np.ascontiguousarray(synth.laser_scan(ins, cycle), np.float32)
+    return _SCANS[key]
+
+
+class Group:
+    """One stream's share of the fleet with everything a cycle hands over pre-marshalled (the timed loop calls the
+    C-ABI staging entry points on ready buffers: no Python list handling inside it)."""
+
+    def __init__(self, nav, fl, insts, seed, stub=False):
+        from navigation_amd._lib import OBS_CLEARING, OBS_MARKING, Observation, PlanResult, RobotState
+        from navigation_amd import synth
+        self.fl, self.n = fl, len(insts)
+        poses_h, _, pos, vel, plans = fl._bench_host_inputs
+        self.poses_h = np.ascontiguousarray(poses_h, np.float64)
+        self.sched = PoseSchedule(pos, vel, 64, seed)
+        self.plans_pk = np.ascontiguousarray(plans, np.float64).reshape(-1, 2)
+        k_plan = plans.shape[1]
+        # the scans of SCAN_CYCLES consecutive control cycles (3 moving discs + the static cells, synth.laser_scan)
+        self.scans = []
+        for c in range(SCAN_CYCLES):
+            arr = (Observation * self.n)()
+            pts, off = [], 0
+            for i, ins in enumerate(insts):
+                p = np.zeros((4, 3), np.float32) if stub else cached_scan(synth, ins, c)
+                arr[i] = Observation(i, off, len(p), OBS_MARKING | OBS_CLEARING, float(ins["pos"][0]), float(ins["pos"][1]), 0.3, 2.5, 3.0)
+                pts.append(p)
+                off += len(p)
+            self.scans.append((arr, np.ascontiguousarray(np.concatenate(pts), np.float32)))
+        self.states = []
+        for c in range(16):
+            st = (RobotState * self.n)()
+            for i in range(self.n):
+                st[i].pos[:] = [float(v) for v in self.sched.pos[c][i]]
+                st[i].vel[:] = [float(v) for v in vel[i]]
+                st[i].plan_first = i * k_plan
+                st[i].plan_count = k_plan
+            self.states.append(st)
+        self.rbuf = (PlanResult * self.n)()
+        self.rview = np.frombuffer(self.rbuf, dtype=np.dtype(PlanResult))
+        self.scored = 0      # trajectories scored by the cycles whose results have been read
+        self.pending = False  # a cycle is queued whose results have not been read yet
+        self.h2d_bytes = self.poses_h.nbytes + self.scans[0][1].nbytes + self.plans_pk.nbytes + self.n * (56 + 32)
+
+    def collect(self):
+        """Results of the queued cycle -> host (waits for the group's stream)."""
+        if self.pending:
+            self.fl.results_into(self.rbuf)
+            self.scored += int(self.rview["n_scored"].sum())
+            self.pending = False
+
+    def cycle(self, k, restage=True):
+        """One control cycle: results of the previous one, hand over cycle k's inputs, queue updateMap + findBestPath."""
+        self.collect()
+        if restage:
+            arr, pts = self.scans[k % SCAN_CYCLES]
+            self.fl.stage_observations_raw(self.poses_h, arr, self.n, pts)
+            self.fl.stage_planner_raw(self.states[k % len(self.states)], self.n, self.plans_pk)
+        else:
+            self.fl.stage_poses(self.sched.pos[k % len(self.sched.pos)], self.sched.vel)
+        self.fl.update_map()
+        self.fl.planner_cycle()
+        self.pending = True
+
+
+def run_cycles(groups, k0, n, restage=True):
+    for k in range(k0, k0 + n):
+        for g in groups:
+            g.cycle(k, restage)
+    for g in groups:
+        g.collect()
+    return k0 + n
 
 
 def hbm_traffic_from_profiles(kernel):
-    """HBM bytes per launch of `kernel` as measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this
-    exact workload (bench.py cannot collect PMC counters itself); newest profiles/*_hbm_traffic.json."""
+    """HBM bytes per launch of `kernel` as measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this workload (one
+    full-fleet launch per kernel: tools/collect_profiles.sh runs --groups 1); newest profiles/*_hbm_traffic.json."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
     if not files:
@@ -101,6 +181,18 @@ def hbm_traffic_from_profiles(kernel):
         d = json.load(open(files[-1]))
         # MI355X_MICROARCH.md (HBM): gfx950 FETCH_SIZE tallies 128-B read requests at 64 B -> doubled; WRITE_SIZE is exact
         return d["kernels"][kernel]["hbm_bytes_fetch_x2"], os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
+def pmc_summary_from_profiles():
+    """Newest profiles/*_pmc_summary.json (tools/collect_profiles.sh + tools/pmc_summary.py): the measured issue roofline."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    try:
+        return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
 
@@ -186,25 +278,49 @@ def configs4_leg(nav, device, n_robots=64, n_cells=1000, steps=10):
             "kernel_ms": {k: round(v[0] / v[1], 4) for k, v in pr.items() if v[1]}}
 
 
-def step(fl, poses=None, k=0):
-    """One pass of the hot path over the fleet.  With `poses` (a PoseSchedule) the cycle first stages its own pose and
-    velocity (24 B per robot, navgpu_planner_stage_poses) - everything else (costmaps, scans, plans) is resident in HBM."""
-    if poses is not None:
-        fl.stage_poses(poses.pos[k % len(poses.pos)], poses.vel)
+def inflation_reference_order_leg(nav, insts, n_cells, device):
+    """SURVEY a10 in the reference's own order (priority_queue_order = 1: InflationLayer::updateCosts' priority-queue walk,
+    byte-identical to the reference) on the contract workload: static + obstacle + inflation layers, a new scan per cycle,
+    the per-cycle update windows.  ms per costmap update of the whole fleet."""
+    from navigation_amd import _lib as N, synth
+    n_inst = len(insts)
+    fl = nav.Fleet(n_inst, n_cells, n_cells, synth.RES, layers=N.LAYER_STATIC | N.LAYER_OBSTACLE | N.LAYER_INFLATION, max_points=720,
+                   max_observations=1, device=device)
+    fl.configure_obstacle()
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.configure_inflation(synth.INFLATION_RADIUS, synth.COST_SCALING, synth.inscribed_radius(synth.FOOTPRINT), priority_queue_order=True)
+    for i, ins in enumerate(insts):
+        fl.add_static_map(np.where(ins["cells"] == 254, 100, 0).astype(np.int8), first=i, count=1)
+    poses = np.array([[float(v) for v in ins["pos"]] for ins in insts])
+
+    def stage(k):
+        fl.stage_observations(poses, [dict(instance=i, points=cached_scan(synth, ins, k), origin=(float(ins["pos"][0]), float(ins["pos"][1]), 0.3),
+                                           obstacle_range=2.5, raytrace_range=3.0) for i, ins in enumerate(insts)])
+    stage(0)
+    t0 = time.perf_counter()
     fl.update_map()
-    fl.planner_cycle()
-
-
-class PoseSchedule:
-    """Seeded per-cycle poses: the robot of cycle k stands at base + N(0, 2 cm) and is turned by N(0, 0.05 rad), so that
-    successive cycles differ (wavefront lengths, reach boxes, which samples collide) and last cycle's level counts are
-    no perfect predictor for the longest-first dispatch of this one."""
-
-    def __init__(self, pos, vel, n_cycles, seed):
-        rs = np.random.RandomState(seed)
-        d = rs.normal(size=(n_cycles,) + pos.shape) * np.array([0.02, 0.02, 0.05])
-        self.pos = [np.ascontiguousarray(pos + d[k], np.float32) for k in range(n_cycles)]
-        self.vel = np.ascontiguousarray(vel, np.float32)
+    fl.sync()
+    first_ms = (time.perf_counter() - t0) * 1e3
+    stage(1)
+    fl.update_map()  # (the inflation layer's second update still covers the whole map: last cycle's box)
+    fl.sync()
+    ms, cells = [], 0
+    for k in range(2, 5):
+        stage(k)
+        fl.sync()
+        t0 = time.perf_counter()
+        fl.update_map()
+        fl.sync()
+        ms.append((time.perf_counter() - t0) * 1e3)
+        b = fl.bounds()
+        cells = int(((b[:, 1] - b[:, 0]) * (b[:, 3] - b[:, 2])).sum())
+    fl.close()
+    ms.sort()
+    return {"workload": f"{n_inst} robots, {n_cells}x{n_cells}, static + obstacle + inflation, new scan per cycle, priority_queue_order = 1",
+            "ms_per_update_per_cycle_windows": ms[len(ms) // 2], "window_cells_per_update": cells,
+            "cells_per_s": cells / (ms[len(ms) // 2] * 1e-3), "ms_first_update_whole_maps": first_ms,
+            "note": "byte-identical to the reference's std::priority_queue walk (tests: test_inflate_reference_priority_queue_order); one lane per "
+                    "robot walks the heap, 256 robots side by side; the default mode (exact transform, >= the reference everywhere) is what `value` uses"}
 
 
 def host_cores():
@@ -220,18 +336,6 @@ def host_cores():
         pass
     eff = n if quota is None else max(1, min(n, int(quota + 0.5)))
     return eff, n, quota
-
-
-def pmc_summary_from_profiles():
-    """Newest profiles/*_pmc_summary.json (tools/collect_profiles.sh): VALU-busy fraction etc. per device kernel."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    if not files:
-        return None, None
-    try:
-        return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
-    except Exception:
-        return None, None
 
 
 def spawn_ranks(n, argv):
@@ -290,23 +394,80 @@ def cpu_baseline(insts_sample, cfg, n_cells, masters):
                 seconds=round(dt + dti, 2))
 
 
+class _StubFleet:
+    """Host-only stand-in for navigation_amd.Fleet (--stub-fleet: tests/test_distributed_counters.py drives bench.py's N > 1
+    code path - rank bookkeeping, counter all-reduce, the JSON line - under gloo on a box without a GPU).  It computes
+    nothing: a cycle is a short sleep and every robot "scores" 17 000 trajectories."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def _noop(self, *a, **k):
+        return None
+
+    stage_observations_raw = stage_planner_raw = stage_poses = update_map = sync = profile = profile_reset = profile_select = close = _noop
+    set_bounded_map_grids = stage_planner = inflate = upload = _noop
+
+    def planner_cycle(self):
+        time.sleep(0.0005)
+
+    def results_into(self, buf):
+        for r in buf:
+            r.n_scored = 17000
+        return buf
+
+    def profile_read(self):
+        return {k: (0.05, 1) for k in ("k_obstacle", "k_merge", "k_inflate", "k_bfs", "k_score", "k_select")}
+
+    def bounds(self):
+        return np.tile(np.array([[100, 240, 100, 240]], np.int32), (self.n, 1))
+
+    def wavefront_boxes(self):
+        return np.tile(np.array([[170, 230, 170, 230]], np.int32), (self.n, 1))
+
+
+def stub_group_fleet(n, n_cells, seed0):
+    from navigation_amd import synth
+    insts = [dict(pos=np.array([10.0, 10.0, 0.1 * i], np.float32), vel=np.array([0.2, 0.0, 0.0], np.float32),
+                  plan=np.stack([10.0 + 0.04 * np.arange(200), np.full(200, 10.0)], 1)) for i in range(n)]
+    fl = _StubFleet(n)
+    fl._bench_host_inputs = (np.array([[10.0, 10.0, 0.0]] * n), None, np.stack([i["pos"] for i in insts]), np.stack([i["vel"] for i in insts]),
+                             np.stack([i["plan"] for i in insts]))
+    fl._bench_insts = insts
+    return fl, insts, synth.fleet_config()
+
+
+def device_identity(torch, local_rank, stub):
+    """What tells two ranks on ONE device apart from two ranks on two: PCI domain:bus:device of the rank's GPU."""
+    if stub:
+        return f"stub:{local_rank}"
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        if hasattr(p, "pci_bus_id"):
+            return f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{getattr(p, 'pci_device_id', 0):02x}"
+        return str(getattr(p, "uuid", local_rank))
+    except Exception:
+        return f"cuda:{local_rank}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--instances", type=int, default=256, help="robot instances per GPU")
+    ap.add_argument("--groups", type=int, default=4, help="independent groups (= HIP streams) the rank's fleet runs as; 1 = one stream, serial")
     ap.add_argument("--total-instances", type=int, default=0,
                     help="strong scaling (SURVEY 8e: 2048 robots over the node): this many robots in all, split over the ranks by "
                          "navigation_amd.sharding.shard_range; 0 = --instances per GPU (weak scaling, the contract workload)")
     ap.add_argument("--size", type=int, default=400, help="costmap cells per side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-single", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="leave the supplementary legs out (profiling runs)")
     ap.add_argument("--vsamples", default="32,32,16", help="vx,vy,vtheta samples (exploration; the contract workload is 32,32,16)")
     ap.add_argument("--footprint", default="square", choices=["square", "poly5"], help="poly5: costmap_params.yaml's 5-vertex polygon")
-    ap.add_argument("--fixed-poses", action="store_true", help="every cycle sees the same poses (A/B only; the default perturbs them per cycle)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-process rehearsal on a box with ONE GPU: every rank uses device 0, collectives over gloo")
+    ap.add_argument("--stub-fleet", action="store_true", help="host-only stand-in for the fleet (CPU tests of the N > 1 code path; computes nothing)")
     args = ap.parse_args()
 
     # ---- N ranks.  Nothing above or below this block has touched torch / HIP yet.
@@ -322,273 +483,357 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    stub = args.stub_fleet
+    host_side = stub or args.rehearse_on_one_gpu  # collectives over gloo on CPU tensors
     dist = None
-    if args.rehearse_on_one_gpu:
+    if args.rehearse_on_one_gpu or stub:
         local_rank = 0
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if args.rehearse_on_one_gpu:
+        if not stub:
+            torch.cuda.set_device(local_rank)
+        if host_side:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
+    elif not stub:
         torch.cuda.set_device(local_rank)
     import navigation_amd as nav
     from navigation_amd import _lib as N, synth
 
-    nav.lib()  # fails loudly if the HIP extension is missing
+    if not stub:
+        nav.lib()  # fails loudly if the HIP extension is missing
     n_inst, n_cells = args.instances, args.size
     seed0 = rank * n_inst
     if args.total_instances:
         from navigation_amd.sharding import shard_range
         seed0, n_inst = shard_range(args.total_instances, rank, world)
     vs = tuple(int(v) for v in args.vsamples.split(","))
-    fl, insts, cfg = build_fleet(nav, n_inst, n_cells, seed0=seed0, device=local_rank, vs=vs, footprint=args.footprint)
-    _, _, pos_h, vel_h, plans_h = fl._bench_host_inputs
-    poses = None if args.fixed_poses else PoseSchedule(pos_h, vel_h, 64, seed=4242 + rank)
+    G = max(1, min(args.groups, n_inst))
+    from navigation_amd.sharding import shard_range as split
+    groups, insts, cfg = [], [], None
+    for gi in range(G):
+        g0, gn = split(n_inst, gi, G)
+        if stub:
+            fl, gi_insts, cfg = stub_group_fleet(gn, n_cells, seed0 + g0)
+        else:
+            fl, gi_insts, cfg = build_fleet(nav, gn, n_cells, seed0=seed0 + g0, device=local_rank, vs=vs, footprint=args.footprint)
+        groups.append(Group(nav, fl, gi_insts, seed=4242 + rank * 64 + gi, stub=stub))
+        insts += gi_insts
+
+    def sync_all():
+        for g in groups:
+            g.fl.sync()
 
     def barrier():
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
-    kk = 0  # running cycle number: every cycle of the run takes the next pose of the schedule
-    for _ in range(args.warmup):
-        step(fl, poses, kk)
-        kk += 1
-    fl.sync()
-    # every kernel bracketed by HIP events over a few untimed steps: finds the dominant kernel and gives the others'
-    # durations; the timed region then brackets the dominant kernel only (each pair of events costs the stream a few
-    # microseconds: 47 us per step with all six regions bracketed)
-    fl.profile_select(None)
-    fl.profile(True)
-    fl.profile_reset()
-    pre_steps = max(3, min(10, args.steps))
-    for _ in range(pre_steps):
-        step(fl, poses, kk)
-        kk += 1
-    prof_all = fl.profile_read()
-    dom_pre = max(prof_all, key=lambda k: prof_all[k][0])
-    fl.profile_select([dom_pre])
-    fl.profile_reset()
+    # ---- who runs where (an N-rank run on fewer than N devices is a rehearsal and must say so)
+    ident = device_identity(torch, local_rank, stub)
+    ranks_seen = [(rank, local_rank, ident)]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, local_rank, ident))
+        ranks_seen = sorted(gathered)
+    ids = [r[2] for r in ranks_seen]
+    if len(set(ids)) != len(ids) and not (args.rehearse_on_one_gpu or stub):
+        if rank == 0:
+            print(f"bench.py: {world} ranks share devices {ids}: pass --rehearse-on-one-gpu for a plumbing rehearsal", file=sys.stderr)
+        if dist is not None:
+            dist.destroy_process_group()
+        sys.exit(3)
+
+    kk = run_cycles(groups, 0, args.warmup)
+    # ---- every kernel bracketed by HIP events over a few untimed cycles of the WHOLE fleet on ONE stream (one launch of 256
+    # robots per kernel and cycle, nothing overlapping): finds the dominant kernel and gives every kernel's duration alone -
+    # the figures earlier rounds reported and the ones a per-kernel roofline can be read against.  (A group's launches cannot
+    # stand in for it: a latency-bound kernel takes as long for 64 robots as for 256.)
+    pre_steps = max(3, min(6, args.steps))
+    one_stream = None
+    if G > 1:
+        if stub:
+            f1, i1, _ = stub_group_fleet(n_inst, n_cells, seed0)
+        else:
+            f1, i1, _ = build_fleet(nav, n_inst, n_cells, seed0=seed0, device=local_rank, vs=vs, footprint=args.footprint, insts=insts)
+        g1 = Group(nav, f1, i1, seed=4242 + rank * 64, stub=stub)
+    else:
+        f1, g1 = groups[0].fl, groups[0]
+    k1 = run_cycles([g1], 0, 3)
+    f1.profile_select(None)
+    f1.profile(True)
+    f1.profile_reset()
+    k1 = run_cycles([g1], k1, pre_steps)
+    serial = {name: (ms / cnt if cnt else 0.0) for name, (ms, cnt) in f1.profile_read().items()}
+    f1.profile(False)
+    if G > 1:
+        f1.sync()
+        t1 = time.perf_counter()
+        k1 = run_cycles([g1], k1, 20)
+        f1.sync()
+        d1 = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        k1 = run_cycles([g1], k1, 20, restage=False)
+        f1.sync()
+        d2 = time.perf_counter() - t1
+        one_stream = {"ms_per_step": d1 / 20 * 1e3, "ms_per_step_resident_inputs": d2 / 20 * 1e3,
+                      "note": "--groups 1: the whole fleet on one stream, every cycle's hand-over serial with its kernels"}
+        f1.close()
+    dom = max(serial, key=lambda k: serial[k])
+    for g in groups:
+        g.fl.profile_select([dom])  # each bracketed launch costs its stream a few microseconds: the timed region brackets one kernel
+        g.fl.profile(True)
+        g.fl.profile_reset()
+        g.scored = 0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(fl, poses, kk)
-        kk += 1
-    fl.sync()
-    barrier()
+    kk = run_cycles(groups, kk, args.steps)
+    sync_all()
     elapsed = time.perf_counter() - t0
-    prof = dict(prof_all)
-    prof[dom_pre] = fl.profile_read()[dom_pre]  # the dominant kernel: measured live over the timed region
-    fl.profile(False)
-    fl.profile_select(None)
-
-    res = fl.results()
-    scored = sum(r.n_scored for r in res)
-    boxes = fl.bounds()
+    barrier()
+    scored_run = sum(g.scored for g in groups)  # every cycle's own count (the perturbed poses change it from cycle to cycle)
+    dom_ms, dom_n = 0.0, 0
+    for g in groups:
+        ms, cnt = g.fl.profile_read()[dom]
+        dom_ms += ms
+        dom_n += cnt
+        g.fl.profile(False)
+        g.fl.profile_select(None)
+    boxes = np.concatenate([g.fl.bounds() for g in groups])
     win_cells = int(((boxes[:, 1] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 2])).sum())
-    # what a bounded wavefront has to move: its region's distances; the region = the robot's box + 2 cells,
-    # whole 32-cell words
-    wb = fl.wavefront_boxes().astype(np.int64)
+    wb = np.concatenate([g.fl.wavefront_boxes() for g in groups]).astype(np.int64)
     reg_rows = np.minimum(wb[:, 3] + 2, n_cells - 1) - np.maximum(wb[:, 2] - 2, 0) + 1
     reg_words = np.minimum(wb[:, 1] + 2, n_cells - 1) // 32 - np.maximum(wb[:, 0] - 2, 0) // 32 + 1
     region_cells = int((reg_rows * reg_words * 32).sum())
 
     # the only collective: throughput counters over RCCL (navigation_amd/sharding.py, gloo-tested on CPU)
     from navigation_amd.sharding import reduce_counters
-    elapsed_max, (total_scored, total_win) = reduce_counters(dist, elapsed, [scored, win_cells],
-                                                             device="cpu" if args.rehearse_on_one_gpu else "cuda")
+    elapsed_max, (total_scored, total_win) = reduce_counters(dist, elapsed, [scored_run, win_cells * args.steps], device="cpu" if host_side else "cuda")
+    per_rank_ms = [elapsed / args.steps * 1e3]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, elapsed / args.steps * 1e3)
+        per_rank_ms = gathered
 
     out = None
     if rank == 0:
         ms_per_step = elapsed_max / args.steps * 1e3
-        traj_per_s = total_scored * args.steps / elapsed_max
-        dom = dom_pre
-        avg_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()}
+        traj_per_s = total_scored / elapsed_max
+        scored_step = scored_run / args.steps
         bitmap = n_cells * ((n_cells + 31) // 32) * 4
-        alg_bytes = {
-            "k_score": BYTES_PER_TRAJ * scored,
-            # bounded search: costmap bytes once per robot -> traversable bitmap (k_free_bits), the bitmap read twice per
-            # grid, 4 B per cell of the region written.  (SURVEY 8d's 5 B x every cell is the WHOLE-grid search's figure
-            # and is used for the whole_grid_wavefronts leg only.)
+        alg_bytes = {  # per STEP (all groups' launches of the kernel)
+            "k_score": BYTES_PER_TRAJ * scored_step,
+            # bounded search: costmap bytes once per robot -> traversable bitmap, the bitmap read twice per grid, 4 B per cell of
+            # the region written.  (SURVEY 8d's 5 B x every cell is the WHOLE-grid search's figure: whole_grid_wavefronts leg.)
             "k_bfs": n_inst * (n_cells * n_cells + bitmap + 3 * 2 * bitmap) + 3 * 4 * region_cells,
             "k_inflate": BYTES_PER_INFL_CELL * win_cells,
             "k_merge": BYTES_PER_MERGE_CELL * win_cells,
             "k_obstacle": 0.0, "k_select": 0.0,
         }
         contract = (n_inst, n_cells) == (256, 400) and vs == (32, 32, 16) and args.footprint == "square"
-        achieved = alg_bytes[dom] / (avg_ms[dom] * 1e-3) / 1e9 if avg_ms[dom] > 0 else 0.0
+        launch_ms = dom_ms / dom_n if dom_n else 0.0            # one group's launch, measured live over the timed region
+        launch_bytes = alg_bytes[dom] / G
+        achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        achieved_serial = alg_bytes[dom] / (serial[dom] * 1e-3) / 1e9 if serial[dom] > 0 else 0.0
         traffic, traffic_src = hbm_traffic_from_profiles(dom) if contract else (None, None)
         pmc, pmc_src = pmc_summary_from_profiles() if contract else (None, None)
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "achieved_is": "ALGORITHMIC bytes (SURVEY 8d: 1000 B per scored trajectory) / launch time - a figure of merit, not HBM utilisation",
-                "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": avg_ms[dom],
+                "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic / G if traffic else None), "traffic_source": traffic_src,
+                "achieved_is": "ALGORITHMIC bytes (SURVEY 8d: 1000 B per scored trajectory) of one launch / its duration, HIP events on the launch's own "
+                               f"stream over the timed region - where {G} groups' kernels share the GPU, so a launch runs beside other streams' wavefront / "
+                               "scoring kernels and takes longer than alone (roofline.alone); a figure of merit, not HBM utilisation",
+                "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_ms": launch_ms, "launches_timed": dom_n,
+                "alone": {"achieved": achieved_serial, "frac": achieved_serial / HBM_PEAK_GBS, "avg_launch_ms": serial[dom],
+                          "algorithmic_bytes_per_launch": alg_bytes[dom],
+                          "note": f"one launch over the whole fleet on one stream with nothing else on the GPU ({pre_steps} untimed cycles): the per-kernel figure"},
                 "frac_vs_measured_copy_peak_6290": achieved / 6290.0}
-        if traffic and avg_ms[dom] > 0:
-            roof["hbm_measured"] = {"GBps": traffic / (avg_ms[dom] * 1e-3) / 1e9, "frac_of_peak": traffic / (avg_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "bytes_per_launch": traffic, "note": "PMC FETCH_SIZE x2 + WRITE_SIZE (gfx950 correction), separate passes"}
+        if traffic and serial[dom] > 0:
+            roof["hbm_measured"] = {"GBps": traffic / (serial[dom] * 1e-3) / 1e9, "frac_of_peak": traffic / (serial[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "bytes_per_launch": traffic, "note": "PMC FETCH_SIZE x2 + WRITE_SIZE (gfx950 correction), separate passes, --groups 1"}
         if pmc and dom in pmc.get("regions", {}):
             v = pmc["regions"][dom]
-            roof["bound"] = v.get("bound", "valu")
-            roof["valu_busy"] = v.get("valu_busy")
-            roof["valu"] = dict(v, source=pmc_src)
+            roof["bound"] = v.get("bound", "latency")
+            roof["frac_issue"] = v.get("valu_issue_util")
+            roof["issue"] = {"valu_util": v.get("valu_issue_util"), "salu_util": v.get("salu_util"), "wait_any": v.get("wait_any"),
+                             "wait_inst_any": v.get("wait_inst_any"), "active": v.get("active"), "lds_bank_conflict": v.get("lds_bank_conflict"),
+                             "insts_valu": v.get("insts_valu"), "insts_salu": v.get("insts_salu"), "kernel_time_ns": v.get("kernel_time_ns"),
+                             "t_issue_ns": pmc.get("t_issue_ns"), "source": pmc_src,
+                             "note": "measured issue roofline of the full-fleet launch (--groups 1): SQ_INSTS_VALU x the box's own VALU issue time / "
+                                     "(1024 SIMDs x kernel time); wait shares of the resident waves' cycles (tools/pmc_summary.py)"}
+        costmap_ms = serial.get("k_obstacle", 0) + serial.get("k_merge", 0) + serial.get("k_inflate", 0)
         out = {
             "metric": "scored trajectories/sec (whole node) + costmap inflation cells/sec, 400x400 map",
             "value": traj_per_s, "unit": "trajectories/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if args.total_instances else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"configs[2]: {n_inst} batched robot instances per MI355X, {n_cells}x{n_cells} costmaps "
-                                   f"+ inflation, 32x32x16 velocity samples, 20 sim steps, LaserScan (720 beams) update "
-                                   f"each cycle; " + (f"{args.total_instances} instances in all, split over the ranks (strong scaling)" if args.total_instances
-                                                      else f"N GPUs = N x {n_inst} instances (N=8 is configs[3])"),
-                       "instances_per_gpu": n_inst, "costmap": f"{n_cells}x{n_cells}@0.05", "vsamples": "x".join(str(v) for v in vs),
+            "config": {"workload": f"configs[2]: {n_inst} batched robot instances per MI355X, {n_cells}x{n_cells} costmaps + inflation, 32x32x16 "
+                                   f"velocity samples, 20 sim steps, a NEW LaserScan (720 beams, 3 moving discs) every cycle; "
+                                   + (f"{args.total_instances} instances in all, split over the ranks (strong scaling)" if args.total_instances
+                                      else f"N GPUs = N x {n_inst} instances (N=8 is configs[3])"),
+                       "instances_per_gpu": n_inst, "groups_per_gpu": G, "costmap": f"{n_cells}x{n_cells}@0.05", "vsamples": "x".join(str(v) for v in vs),
                        "sim_steps": T_STEPS, "critics": "oscillation+obstacle+goal_front+alignment+path+goal",
-                       "parallelism": f"fleet-shard x{world}"},
-            "value_is": "costmaps, scans and plans resident in HBM; every timed cycle stages its own (perturbed) pose + velocity, "
-                        "24 B per robot H2D, and its results land in pinned host memory; the fully PCIe-inclusive rate "
-                        "(scans + plans + poses re-staged every cycle) is pcie_inclusive",
-            "poses": "fixed" if poses is None else "per-cycle N(0, 2 cm / 0.05 rad) around the base pose, seeded",
+                       "parallelism": f"fleet-shard x{world}, {G} stream groups per GPU"},
+            "value_is": "SURVEY 8(d)'s protocol: every timed cycle hands over its own new scan cloud, pose / velocity and plan from host memory "
+                        f"(H2D, {sum(g.h2d_bytes for g in groups)} B per step) and reads its results back (D2H); costmaps resident.  The transfers of one "
+                        "group hide behind the other groups' kernels; resident_inputs is the same loop without them",
+            "poses": "per-cycle N(0, 2 cm / 0.05 rad) around the base pose, seeded",
             "per_instance_trajectories_per_s": traj_per_s / (n_inst * world),
-            "inflation_cells_per_s": total_win * args.steps / elapsed_max,
-            "inflation_window_cells_per_step": total_win,
-            "trajectories_per_step": total_scored,
-            "kernel_ms": {k: round(avg_ms[k], 4) for k in avg_ms},
-            "kernel_ms_source": f"HIP events on the library's stream: {dom} over the {args.steps} timed steps, the others over {pre_steps} untimed steps before them",
+            "inflation_cells_per_s": (total_win / args.steps / world) / (costmap_ms * 1e-3) * world if costmap_ms > 0 else None,
+            "inflation_cells_per_s_is": "SURVEY 8(d) M2: update-window cells per second of obstacle-merge + inflation time (k_obstacle + k_merge + k_inflate, whole-fleet launches alone)",
+            "inflation_window_cells_per_step": total_win / args.steps,
+            "trajectories_per_step": total_scored / args.steps,
+            "kernel_ms": {k: round(serial[k], 4) for k in serial},
+            "kernel_ms_source": f"HIP events, {pre_steps} untimed cycles of the whole fleet on ONE stream (one launch of {n_inst} robots per kernel and cycle, nothing "
+                                f"overlapping); in the timed region the {G} groups' launches run side by side: sum {sum(serial.values()):.3f} ms vs step {ms_per_step:.3f} ms",
             "roofline": roof,
+            "ranks_seen": [{"rank": r[0], "local_rank": r[1], "device": r[2]} for r in ranks_seen],
+            "per_rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms), "all": [round(v, 4) for v in per_rank_ms]},
         }
-        # every kernel against the same roofline, and the whole step as SURVEY 8(d) defines it
+        if args.rehearse_on_one_gpu or stub:
+            out["rehearsal"] = "all ranks on one device / host-only stand-in: a plumbing check, not a scaling figure"
         per_kernel = {}
-        for k in avg_ms:
-            if avg_ms[k] > 0 and alg_bytes.get(k, 0) > 0:
-                gbs = alg_bytes[k] / (avg_ms[k] * 1e-3) / 1e9
+        for k in serial:
+            if serial[k] > 0 and alg_bytes.get(k, 0) > 0:
+                gbs = alg_bytes[k] / (serial[k] * 1e-3) / 1e9
                 tk, _ = hbm_traffic_from_profiles(k) if contract else (None, None)
-                per_kernel[k] = {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms": avg_ms[k], "traffic": tk,
+                per_kernel[k] = {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms_alone": serial[k], "traffic": tk,
                                  "algorithmic_bytes_per_launch": alg_bytes[k]}
                 if pmc and k in pmc.get("regions", {}):
-                    per_kernel[k]["valu_busy"] = pmc["regions"][k].get("valu_busy")
+                    per_kernel[k]["frac_issue"] = pmc["regions"][k].get("valu_issue_util")
+                    per_kernel[k]["bound"] = pmc["regions"][k].get("bound")
         out["roofline_all"] = per_kernel
         step_bytes = sum(alg_bytes.values())
         out["roofline_step"] = {"algorithmic_bytes_per_step": step_bytes, "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9,
                                 "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"}
     # ---- extra legs on rank 0 at N=1 only
-    if rank == 0 and world == 1:
-        # per-cycle latency of the same step, one cycle in flight at a time (median / p99 over >= 50 cycles)
-        lat = []
-        for _ in range(max(60, args.steps)):
-            tc = time.perf_counter()
-            step(fl, poses, kk)
-            kk += 1
-            fl.sync()
-            lat.append((time.perf_counter() - tc) * 1e3)
-        lat.sort()
-        out["cycle_latency"] = {"cycles": len(lat), "ms_median": lat[len(lat) // 2], "ms_p99": lat[min(len(lat) - 1, int(0.99 * len(lat)))],
-                                "ms_min": lat[0], "ms_max": lat[-1], "note": "stage pose -> updateMap -> findBestPath -> results visible, synchronised every cycle"}
-        # the same step with every MapGrid wavefront run over the whole costmap, as the reference does (the default stops a
-        # search once the box its robot's samples can reach is settled; planner results are identical, tests/test_gpu_parity.py)
-        if not args.no_single:  # (the profiling runs of tools/collect_profiles.sh leave it out: one kind of launch per kernel)
-            lv_bounded = fl.wavefront_levels().mean(axis=0)
-            fl.set_bounded_map_grids(False)
-            fl.stage_planner(pos_h, vel_h, plans_h)
-            for _ in range(3):
-                step(fl, poses, kk)
-                kk += 1
-            fl.sync()
-            fl.profile(True)
-            fl.profile_reset()
-            k2 = 20
-            t1 = time.perf_counter()
-            for _ in range(k2):
-                step(fl, poses, kk)
-                kk += 1
-            fl.sync()
-            dt = time.perf_counter() - t1
-            pk = fl.profile_read()["k_bfs"]
-            fl.profile(False)
-            lv_whole = fl.wavefront_levels().mean(axis=0)
-            wg_ms = pk[0] / max(pk[1], 1)
-            wg_bytes = BYTES_PER_BFS_CELL * 3 * n_cells * n_cells * n_inst
-            out["whole_grid_wavefronts"] = {"ms_per_step": dt / k2 * 1e3, "trajectories_per_s": scored * k2 / dt, "k_bfs_ms": wg_ms,
-                                            "levels_path_goal_front": [float(v) for v in lv_whole],
-                                            "roofline": {"algorithmic_bytes_per_launch": wg_bytes, "achieved": wg_bytes / (wg_ms * 1e-3) / 1e9,
-                                                         "frac": wg_bytes / (wg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
-                                                         "note": "SURVEY 8d: 5 B per cell and grid"}}
-            out["bounded_wavefronts"] = {"enabled": True, "levels_path_goal_front": [float(v) for v in lv_bounded],
-                                         "region_cells_per_robot": region_cells / n_inst,
-                                         "note": "value / ms_per_step are measured with bounded wavefronts (library default)"}
-            fl.set_bounded_map_grids(True)
-            fl.stage_planner(pos_h, vel_h, plans_h)
-            step(fl)
-            fl.sync()
-        # full-window inflation throughput (the BASELINE.md probe shape)
-        raw = np.stack([i["cells"] for i in insts])
-        fl.upload(N.GRID_MASTER, raw)
-        full = [[0, 0, n_cells, n_cells]] * n_inst
-        fl.inflate(boxes=full)
-        fl.sync()
-        fl.profile(True)
-        fl.profile_reset()
-        reps = 10
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            fl.inflate(boxes=full)
-        fl.sync()
-        dt = time.perf_counter() - t1
-        pk = fl.profile_read()["k_inflate"]
-        fl.profile(False)
-        out["inflation_full_window"] = {"cells_per_s": reps * n_inst * n_cells * n_cells / dt,
-                                        "kernel_ms": pk[0] / max(pk[1], 1),
-                                        "achieved_GBps": BYTES_PER_INFL_CELL * n_inst * n_cells * n_cells / (pk[0] / max(pk[1], 1) * 1e-3) / 1e9}
-        # PCIe-inclusive rate (SURVEY 8d's timing protocol): every cycle re-stages ALL its inputs from pageable host
-        # memory (scan clouds, plans, poses: H2D) and reads the results (D2H) through the C-ABI.
-        poses_h, obs_arr, n_obs, pts_h, states_h, n_st, plans_pk = raw_inputs(fl)
-        sched = []
-        for k in range(8):  # a few pre-marshalled pose sets so that these cycles differ too
-            st_k = (type(states_h[0]) * n_st)()
-            C.memmove(st_k, states_h, C.sizeof(states_h))
-            if poses is not None:
-                for i in range(n_st):
-                    st_k[i].pos[:] = [float(v) for v in poses.pos[k][i]]
-            sched.append(st_k)
-        fl.stage_observations_raw(poses_h, obs_arr, n_obs, pts_h)
-        fl.stage_planner_raw(states_h, n_st, plans_pk)
-        step(fl)
-        fl.sync()
-        kp = 300  # enough cycles for a p99 that is not the maximum
+    if rank == 0 and world == 1 and not stub:
+        # PCIe-inclusive cycle times of the same loop: the host's view of one step (all groups queued, results of the previous one read)
         import gc
         gc.collect()
         gc.disable()
-        t1 = time.perf_counter()
-        from navigation_amd._lib import PlanResult
-        rbuf = (PlanResult * n_st)()  # reused: no per-cycle Python allocation (see Fleet.results_into)
         cyc = []
-        n_sc = 0
-        for k in range(kp):
+        for _ in range(300):
             tc = time.perf_counter()
-            fl.stage_observations_raw(poses_h, obs_arr, n_obs, pts_h)
-            fl.stage_planner_raw(sched[k % len(sched)], n_st, plans_pk)
-            step(fl)
-            rr = fl.results_into(rbuf)
+            for g in groups:
+                g.cycle(kk)
+            kk += 1
             cyc.append(time.perf_counter() - tc)
-        dp = time.perf_counter() - t1
+        for g in groups:
+            g.collect()
         gc.enable()
-        n_sc = sum(r.n_scored for r in rr)
-        h2d = poses_h.nbytes + pts_h.nbytes + plans_pk.nbytes + n_obs * 56 + n_st * 32
-        worst = int(np.argmax(cyc))
-        worst_ms = cyc[worst] * 1e3
         cyc.sort()
-        out["pcie_inclusive"] = {"trajectories_per_s": n_sc * kp / dp, "ms_per_step": dp / kp * 1e3,
-                                 "cycle_ms_median": cyc[len(cyc) // 2] * 1e3, "cycle_ms_p99": cyc[min(len(cyc) - 1, int(0.99 * len(cyc)))] * 1e3,
-                                 "cycle_ms_max": worst_ms, "worst_cycle_index": worst, "cycles": kp, "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": n_st * 72,
-                                 "note": "caller buffers are pageable; the library stages them through pinned mirrors"}
-        fl.upload(N.GRID_MASTER, raw)
-        fl.inflate(boxes=full)
-        masters = fl.master(0, min(n_inst, 32))
+        out["pcie_inclusive"] = {"ms_per_step": sum(cyc) / len(cyc) * 1e3, "cycle_ms_median": cyc[len(cyc) // 2] * 1e3,
+                                 "cycle_ms_p99": cyc[min(len(cyc) - 1, int(0.99 * len(cyc)))] * 1e3, "cycle_ms_max": cyc[-1] * 1e3, "cycles": len(cyc),
+                                 "h2d_bytes_per_step": sum(g.h2d_bytes for g in groups), "d2h_bytes_per_step": n_inst * 72,
+                                 "note": "= the protocol of `value` (the timed region), host-side time per step over 300 more cycles; caller buffers are pageable, "
+                                         "the library stages them through pinned mirrors"}
+        # the same loop with scans and plans resident (only pose + velocity, 24 B per robot, staged per cycle)
+        for g in groups:
+            g.scored = 0
+        sync_all()
+        t1 = time.perf_counter()
+        kk = run_cycles(groups, kk, args.steps, restage=False)
+        sync_all()
+        dt = time.perf_counter() - t1
+        out["resident_inputs"] = {"ms_per_step": dt / args.steps * 1e3, "trajectories_per_s": sum(g.scored for g in groups) / dt,
+                                  "note": "scans and plans stay in HBM, every cycle stages its pose and velocity only"}
+        out["value_over_resident"] = out["resident_inputs"]["ms_per_step"] / ms_per_step
+        # latency of one control cycle of the whole fleet, nothing else in flight (median / p99)
+        lat = []
+        for _ in range(max(60, args.steps)):
+            tc = time.perf_counter()
+            for g in groups:
+                g.cycle(kk)
+            for g in groups:
+                g.collect()
+            kk += 1
+            lat.append((time.perf_counter() - tc) * 1e3)
+        lat.sort()
+        out["cycle_latency"] = {"cycles": len(lat), "ms_median": lat[len(lat) // 2], "ms_p99": lat[min(len(lat) - 1, int(0.99 * len(lat)))],
+                                "ms_min": lat[0], "ms_max": lat[-1],
+                                "note": "hand over scan + pose + plan -> updateMap -> findBestPath -> results on the host, synchronised every cycle"}
+        if one_stream:
+            out["one_stream"] = one_stream
+        # the same latency with scans and plans resident (pose + velocity staged only): round 2's cycle_latency protocol
+        lat = []
+        for _ in range(max(60, args.steps)):
+            tc = time.perf_counter()
+            for g in groups:
+                g.cycle(kk, restage=False)
+            for g in groups:
+                g.collect()
+            kk += 1
+            lat.append((time.perf_counter() - tc) * 1e3)
+        lat.sort()
+        out["cycle_latency_resident_inputs"] = {"cycles": len(lat), "ms_median": lat[len(lat) // 2], "ms_p99": lat[min(len(lat) - 1, int(0.99 * len(lat)))]}
+        # the same step with every MapGrid wavefront run over the whole costmap, as the reference does (the default stops a
+        # search once the box its robot's samples can reach is settled; planner results are identical, tests/test_gpu_parity.py)
         if not args.no_single:
+            lv_bounded = np.concatenate([g.fl.wavefront_levels() for g in groups]).mean(axis=0)
+            for g in groups:
+                g.fl.set_bounded_map_grids(False)
+                g.fl.profile_select(["k_bfs"])
+            kk = run_cycles(groups, kk, 3)
+            for g in groups:
+                g.fl.profile(True)
+                g.fl.profile_reset()
+            k2 = 10
+            wg_ms = 0.0
+            for _ in range(k2):  # one group at a time: the wavefront kernel alone on the GPU
+                for g in groups:
+                    g.cycle(kk)
+                    g.collect()
+                kk += 1
+            for g in groups:
+                ms, cnt = g.fl.profile_read()["k_bfs"]
+                wg_ms += ms / max(cnt, 1)
+                g.fl.profile(False)
+                g.fl.profile_select(None)
+            sync_all()
+            t1 = time.perf_counter()
+            kk = run_cycles(groups, kk, 20)
+            sync_all()
+            dt = time.perf_counter() - t1
+            lv_whole = np.concatenate([g.fl.wavefront_levels() for g in groups]).mean(axis=0)
+            wg_bytes = BYTES_PER_BFS_CELL * 3 * n_cells * n_cells * n_inst
+            out["whole_grid_wavefronts"] = {"ms_per_step": dt / 20 * 1e3, "k_bfs_ms": wg_ms,
+                                            "levels_path_goal_front": [float(v) for v in lv_whole],
+                                            "roofline": {"algorithmic_bytes_per_step": wg_bytes, "achieved": wg_bytes / (wg_ms * 1e-3) / 1e9,
+                                                         "frac": wg_bytes / (wg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
+                                                         "note": "SURVEY 8d: 5 B per cell and grid; k_bfs_ms = the groups' launches alone, summed"}}
+            out["bounded_wavefronts"] = {"enabled": True, "levels_path_goal_front": [float(v) for v in lv_bounded],
+                                         "region_cells_per_robot": region_cells / n_inst,
+                                         "note": "value / ms_per_step are measured with bounded wavefronts (library default)"}
+            for g in groups:
+                g.fl.set_bounded_map_grids(True)
+            kk = run_cycles(groups, kk, 1)
+        # full-window inflation throughput (the BASELINE.md probe shape)
+        full_ms, reps = 0.0, 10
+        t1 = time.perf_counter()
+        for g in groups:
+            raw = np.stack([i["cells"] for i in g.fl._bench_insts])
+            g.fl.upload(N.GRID_MASTER, raw)
+            full = [[0, 0, n_cells, n_cells]] * g.n
+            g.fl.inflate(boxes=full)
+            g.fl.sync()
+            g.fl.profile(True)
+            g.fl.profile_reset()
+            for _ in range(reps):
+                g.fl.inflate(boxes=full)
+            g.fl.sync()
+            pk = g.fl.profile_read()["k_inflate"]
+            g.fl.profile(False)
+            full_ms += pk[0] / max(pk[1], 1)
+        out["inflation_full_window"] = {"cells_per_s": n_inst * n_cells * n_cells / (full_ms * 1e-3), "kernel_ms": full_ms,
+                                        "achieved_GBps": BYTES_PER_INFL_CELL * n_inst * n_cells * n_cells / (full_ms * 1e-3) / 1e9}
+        masters = groups[0].fl.master(0, min(groups[0].n, 32))
+        if not args.no_single:
+            out["inflation_reference_order"] = inflation_reference_order_leg(nav, insts, n_cells, local_rank)
             f1, i1, c1 = build_fleet(nav, 1, n_cells, seed0=0, device=local_rank)
             p1 = PoseSchedule(f1._bench_host_inputs[2], f1._bench_host_inputs[3], 64, seed=7)
             for k in range(3):
@@ -605,16 +850,16 @@ def main():
                                    "ms_per_cycle": d1 / k1 * 1e3, "trajectories_per_s": r1.n_scored * k1 / d1,
                                    "n_scored": r1.n_scored}
             f1.close()
-        if not args.no_single:
             out["legacy_trajectory_planner"] = legacy_leg(nav, insts, n_cells, masters, not args.no_cpu_baseline, local_rank)
             out["configs4_one_gpu_share"] = configs4_leg(nav, local_rank)
         if not args.no_cpu_baseline:
-            ns = min(n_inst, 32)
+            ns = min(len(masters), 32)
             out["cpu_baseline"] = cpu_baseline(insts[:ns], cfg, n_cells, masters[:ns])
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))
-    fl.close()
+    for g in groups:
+        g.fl.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

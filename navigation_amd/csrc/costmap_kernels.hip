@@ -1063,11 +1063,23 @@ __global__ __launch_bounds__(256) void k_inflate_bits(CostmapDev cm, uint32_t fi
 // order in which std::priority_queue<CellData> pops equal distances (SURVEY 7 hard part 1), i.e. on libstdc++'s
 // push_heap / pop_heap (bits/stl_heap.h: __push_heap, __adjust_heap), which are deterministic sift-up / sift-down
 // loops; they are restated below verbatim in structure, with the reference's comparison (inflation_layer.h:82-85:
-// a < b  <=>  a.distance_ > b.distance_) on the reference's own keys (cached_distances_ = host hypot()).  The walk
-// is sequential by nature: one lane per robot does it, the other lanes of its wave only clear seen_.  Byte-identical
-// to the reference; two to three orders of magnitude slower than k_inflate_bits, and not what bench.py measures.
+// a < b  <=>  a.distance_ > b.distance_).  The keys are the RANKS of the reference's cached_distances_ (host hypot())
+// among their distinct values - same order, same ties, two bytes instead of a double - so a heap entry is 8 bytes:
+// cell index, rank, and the source as a signed offset from the cell.
+// The walk is sequential by nature: one lane per robot does it.  What makes it usable in a control loop is where its
+// state lives (a pop is a chain of ~log2(n) dependent reads: 50 ns each from LDS, 0.5 us from HBM): the two tables,
+// seen_ as a bitmap of the window and the window's cost bytes (loaded and written back by the whole wave) in LDS, and
+// whatever is left of 150 KB for the top of the heap (14 000 entries for a control cycle's window; every sift passes
+// through the top levels), the rest of it in HBM.  The window is the
+// box + 2 R + 1 cells: seeds come from box + R (:204-212) and reach R further; a neighbour's seen_ flag is read before
+// its distance is tested (:280-286), one cell beyond that.  Larger windows fall back to global memory piece by piece
+// (bitmap up to 163 840 cells, bytes up to 65 536).  Byte-identical to the reference.
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t kPqSeenWords = 5120, kPqWinBytes = 65536;  // largest window whose seen_ bitmap / cost bytes live in LDS
+constexpr size_t kPqLdsBytes = 150 * 1024;                    // one workgroup per CU: the rest of it is the heap's top
+constexpr uint32_t kPqTabEntries = 66 * 66;
 __global__ __launch_bounds__(64) void k_inflate_pq(CostmapDev cm, uint32_t first, const int32_t* boxes) {
+  extern __shared__ __align__(16) uint8_t pq_sm[];
   const uint32_t inst = first + blockIdx.x;
   const uint32_t tid = threadIdx.x;
   int min_i, min_j, max_i, max_j;
@@ -1085,92 +1097,170 @@ __global__ __launch_bounds__(64) void k_inflate_pq(CostmapDev cm, uint32_t first
     max_j = st->box[3];
   }
   uint8_t* master = cm.master + (size_t)inst * cm.cells_padded;
-  uint8_t* seen = cm.pq_seen + (size_t)inst * cm.cells_padded;
-  PqCell* heap = cm.pq_heap + (size_t)inst * cm.pq_cap;
+  uint8_t* seen_g = cm.pq_seen + (size_t)inst * cm.cells_padded;
+  PqCell* heap_g = cm.pq_heap + (size_t)inst * cm.pq_cap;
   const uint32_t size_x = cm.nx, size_y = cm.ny;
   const int R = (int)cm.R;
   const uint32_t n = cm.R + 2;  // stride of the caches
-  // memset(seen_, false, ...) (:198)
-  for (uint32_t i = tid * 16; i < cm.cells_padded; i += 64 * 16) *reinterpret_cast<uint4*>(seen + i) = make_uint4(0, 0, 0, 0);
-  __syncthreads();
-  if (tid != 0) return;
   min_i = max(0, min_i - R);  // :204-212
   min_j = max(0, min_j - R);
   max_i = min((int)size_x, max_i + R);
   max_j = min((int)size_y, max_j + R);
-  long len = 0;  // inflation_queue_.size()
-  // std::push_heap: __push_heap(first, holeIndex, topIndex = 0, value, comp)
-  auto pushHeap = [&](long hole, const PqCell& value) {
-    long parent = (hole - 1) / 2;
-    while (hole > 0 && heap[parent].distance > value.distance) {
-      heap[hole] = heap[parent];
-      hole = parent;
-      parent = (hole - 1) / 2;
-    }
-    heap[hole] = value;
-  };
-  auto enqueue = [&](uint32_t index, uint32_t mx, uint32_t my, uint32_t sx, uint32_t sy) {  // :277-293
-    if (seen[index]) return;
-    const uint32_t dx = mx > sx ? mx - sx : sx - mx, dy = my > sy ? my - sy : sy - my;
-    const double distance = cm.dist_lut[dx * n + dy];
-    if (distance > (double)cm.R) return;
-    if ((uint64_t)len >= cm.pq_cap) return;  // cannot happen: capacity = 4 pushes per cell + the seeds
-    PqCell c;
-    c.distance = distance;
-    c.index = index;
-    c.src_x = (uint16_t)sx;
-    c.src_y = (uint16_t)sy;
-    pushHeap(len++, c);  // priority_queue::push = push_back + push_heap
-  };
-  for (int j = min_j; j < max_j; j++)  // :214-226
-    for (int i = min_i; i < max_i; i++) {
-      const uint32_t index = (uint32_t)j * size_x + (uint32_t)i;
-      if (master[index] == kLethal) enqueue(index, i, j, i, j);
-    }
-  while (len > 0) {  // :228-266
-    const PqCell cur = heap[0];  // top()
-    // priority_queue::pop = pop_heap + pop_back; std::pop_heap acts only on more than one element
-    if (len > 1) {
-      const PqCell value = heap[len - 1];
-      const long l = len - 1;  // __adjust_heap(first, 0, l, value)
-      long hole = 0, child = 0;
-      while (child < (l - 1) / 2) {
-        child = 2 * (child + 1);
-        if (heap[child].distance > heap[child - 1].distance) child--;  // comp(first + secondChild, first + (secondChild - 1))
-        heap[hole] = heap[child];
-        hole = child;
-      }
-      if ((l & 1) == 0 && child == (l - 2) / 2) {
-        child = 2 * (child + 1);
-        heap[hole] = heap[child - 1];
-        hole = child - 1;
-      }
-      pushHeap(hole, value);
-    }
-    --len;
-    const uint32_t index = cur.index;
-    if (seen[index]) continue;
-    seen[index] = 1;
-    const uint32_t my = index / size_x, mx = index - my * size_x, sx = cur.src_x, sy = cur.src_y;
-    const uint32_t dx = mx > sx ? mx - sx : sx - mx, dy = my > sy ? my - sy : sy - my;
-    const uint8_t cost = cm.lut[dx * n + dy];  // costLookup (within the radius the table is cached_costs_)
-    const uint8_t old_cost = master[index];
-    if (old_cost == kNoInfo && cost >= kInscribed)
-      master[index] = cost;
-    else
-      master[index] = old_cost > cost ? old_cost : cost;
-    if (mx > 0) enqueue(index - 1, mx - 1, my, sx, sy);
-    if (my > 0) enqueue(index - size_x, mx, my - 1, sx, sy);
-    if (mx < size_x - 1) enqueue(index + 1, mx + 1, my, sx, sy);
-    if (my < size_y - 1) enqueue(index + size_x, mx, my + 1, sx, sy);
+  if (max_i <= min_i || max_j <= min_j) return;  // (uniform) no seed row / column: the loops below never run
+  // everything the walk can touch
+  const int wx0 = max(0, min_i - R - 1), wy0 = max(0, min_j - R - 1), wx1 = min((int)size_x, max_i + R + 1), wy1 = min((int)size_y, max_j + R + 1);
+  const uint32_t ww = (uint32_t)(wx1 - wx0), wh = (uint32_t)(wy1 - wy0), wcells = ww * wh;
+  const bool seen_lds = wcells <= kPqSeenWords * 32u, win_lds = wcells <= kPqWinBytes;
+  // LDS: rank and cost tables | seen_ bitmap | window bytes | heap top (whatever is left)
+  uint16_t* rank = reinterpret_cast<uint16_t*>(pq_sm);
+  uint8_t* lut_l = pq_sm + kPqTabEntries * 2;
+  const uint32_t seen_off = (kPqTabEntries * 3 + 15u) & ~15u;
+  uint32_t* seen_l = reinterpret_cast<uint32_t*>(pq_sm + seen_off);
+  const uint32_t win_off = seen_off + (seen_lds ? (((wcells + 31) / 32 * 4 + 15u) & ~15u) : 0u);
+  uint8_t* win_l = pq_sm + win_off;
+  const uint32_t heap_off = win_off + (win_lds ? ((wcells + 15u) & ~15u) : 0u);
+  PqCell* heap_l = reinterpret_cast<PqCell*>(pq_sm + heap_off);
+  const long heap_lds = (long)((kPqLdsBytes - heap_off) / sizeof(PqCell));
+  for (uint32_t i = tid; i < n * n; i += 64) {
+    rank[i] = reinterpret_cast<const uint16_t*>(cm.dist_lut)[i];
+    lut_l[i] = cm.lut[i];
   }
+  // memset(seen_, false, ...) (:198), and the window's bytes
+  if (seen_lds) {
+    for (uint32_t i = tid; i < (wcells + 31) / 32; i += 64) seen_l[i] = 0;
+  } else {
+    for (uint32_t i = tid * 16; i < cm.cells_padded; i += 64 * 16) *reinterpret_cast<uint4*>(seen_g + i) = make_uint4(0, 0, 0, 0);
+  }
+  if (win_lds)
+    for (uint32_t i = tid; i < wcells; i += 64) {
+      const uint32_t y = i / ww, x = i - y * ww;
+      win_l[i] = master[(uint32_t)(wy0 + (int)y) * size_x + (uint32_t)(wx0 + (int)x)];
+    }
+  __syncthreads();
+  if (tid == 0) {
+    long len = 0;  // inflation_queue_.size()
+    auto hget = [&](long i) -> PqCell { return i < heap_lds ? heap_l[i] : heap_g[i]; };
+    auto hset = [&](long i, const PqCell& v) {
+      if (i < heap_lds)
+        heap_l[i] = v;
+      else
+        heap_g[i] = v;
+    };
+    auto widx = [&](uint32_t mx, uint32_t my) { return (my - (uint32_t)wy0) * ww + (mx - (uint32_t)wx0); };
+    auto seenGet = [&](uint32_t index, uint32_t mx, uint32_t my) -> bool {
+      if (seen_lds) {
+        const uint32_t w = widx(mx, my);
+        return (seen_l[w >> 5] >> (w & 31)) & 1u;
+      }
+      return seen_g[index] != 0;
+    };
+    auto seenSet = [&](uint32_t index, uint32_t mx, uint32_t my) {
+      if (seen_lds) {
+        const uint32_t w = widx(mx, my);
+        seen_l[w >> 5] |= 1u << (w & 31);
+      } else {
+        seen_g[index] = 1;
+      }
+    };
+    // std::push_heap: __push_heap(first, holeIndex, topIndex = 0, value, comp)
+    auto pushHeap = [&](long hole, const PqCell& value) {
+      long parent = (hole - 1) / 2;
+      while (hole > 0) {
+        const PqCell pv = hget(parent);
+        if (!(pv.rank > value.rank)) break;
+        hset(hole, pv);
+        hole = parent;
+        parent = (hole - 1) / 2;
+      }
+      hset(hole, value);
+    };
+    // enqueue (:277-293) in two halves: what it READS (the neighbour's seen_ flag, the cached distance) does not depend on
+    // the queue, so the four neighbours' reads are issued together; the push itself stays in the reference's order
+    auto probe = [&](bool in_map, uint32_t index, uint32_t mx, uint32_t my, uint32_t sx, uint32_t sy) -> uint32_t {  // rank, or 0xFFFF = no push
+      if (!in_map) return 0xFFFFu;
+      const uint32_t dx = mx > sx ? mx - sx : sx - mx, dy = my > sy ? my - sy : sy - my;
+      const uint32_t r = rank[dx * n + dy];  // 0xFFFF: distance > cell_inflation_radius_ (:286)
+      return seenGet(index, mx, my) ? 0xFFFFu : r;
+    };
+    auto push = [&](uint32_t r, uint32_t index, uint32_t mx, uint32_t my, uint32_t sx, uint32_t sy) {
+      if (r == 0xFFFFu) return;
+      if ((uint64_t)len >= cm.pq_cap) return;  // cannot happen: capacity = 4 pushes per cell + the seeds
+      PqCell c;
+      c.index = index;
+      c.rank = (uint16_t)r;
+      c.sdx = (int8_t)((int)sx - (int)mx);
+      c.sdy = (int8_t)((int)sy - (int)my);
+      pushHeap(len++, c);  // priority_queue::push = push_back + push_heap
+    };
+    auto enqueue = [&](uint32_t index, uint32_t mx, uint32_t my, uint32_t sx, uint32_t sy) { push(probe(true, index, mx, my, sx, sy), index, mx, my, sx, sy); };
+    for (int j = min_j; j < max_j; j++)  // :214-226
+      for (int i = min_i; i < max_i; i++) {
+        const uint32_t index = (uint32_t)j * size_x + (uint32_t)i;
+        const uint8_t c0 = win_lds ? win_l[widx((uint32_t)i, (uint32_t)j)] : master[index];
+        if (c0 == kLethal) enqueue(index, i, j, i, j);
+      }
+    while (len > 0) {  // :228-266
+      const PqCell cur = hget(0);  // top()
+      // priority_queue::pop = pop_heap + pop_back; std::pop_heap acts only on more than one element
+      if (len > 1) {
+        const PqCell value = hget(len - 1);
+        const long l = len - 1;  // __adjust_heap(first, 0, l, value)
+        long hole = 0, child = 0;
+        while (child < (l - 1) / 2) {
+          child = 2 * (child + 1);
+          const PqCell a = hget(child), b = hget(child - 1);
+          if (a.rank > b.rank) {  // comp(first + secondChild, first + (secondChild - 1))
+            child--;
+            hset(hole, b);
+          } else {
+            hset(hole, a);
+          }
+          hole = child;
+        }
+        if ((l & 1) == 0 && child == (l - 2) / 2) {
+          child = 2 * (child + 1);
+          hset(hole, hget(child - 1));
+          hole = child - 1;
+        }
+        pushHeap(hole, value);
+      }
+      --len;
+      const uint32_t index = cur.index;
+      const uint32_t my = index / size_x, mx = index - my * size_x;
+      if (seenGet(index, mx, my)) continue;
+      seenSet(index, mx, my);
+      const uint32_t sx = (uint32_t)((int)mx + cur.sdx), sy = (uint32_t)((int)my + cur.sdy);
+      const uint32_t dx = mx > sx ? mx - sx : sx - mx, dy = my > sy ? my - sy : sy - my;
+      const uint8_t cost = lut_l[dx * n + dy];  // costLookup (within the radius the table is cached_costs_)
+      uint8_t* cellp = win_lds ? &win_l[widx(mx, my)] : &master[index];
+      const uint8_t old_cost = *cellp;
+      if (old_cost == kNoInfo && cost >= kInscribed)
+        *cellp = cost;
+      else
+        *cellp = old_cost > cost ? old_cost : cost;
+      const uint32_t r0 = probe(mx > 0, index - 1, mx - 1, my, sx, sy), r1 = probe(my > 0, index - size_x, mx, my - 1, sx, sy),
+                     r2 = probe(mx < size_x - 1, index + 1, mx + 1, my, sx, sy), r3 = probe(my < size_y - 1, index + size_x, mx, my + 1, sx, sy);
+      push(r0, index - 1, mx - 1, my, sx, sy);
+      push(r1, index - size_x, mx, my - 1, sx, sy);
+      push(r2, index + 1, mx + 1, my, sx, sy);
+      push(r3, index + size_x, mx, my + 1, sx, sy);
+    }
+  }
+  __syncthreads();
+  if (win_lds)
+    for (uint32_t i = tid; i < wcells; i += 64) {
+      const uint32_t y = i / ww, x = i - y * ww;
+      master[(uint32_t)(wy0 + (int)y) * size_x + (uint32_t)(wx0 + (int)x)] = win_l[i];
+    }
 }
 
 void launch_inflate(const CostmapDev& cm, uint32_t first, uint32_t count, const int32_t* boxes, hipStream_t s) {
   if (!cm.infl_enabled) return;
   const int R = (int)cm.R;
   if (cm.infl_pq) {
-    hipLaunchKernelGGL(k_inflate_pq, dim3(count), dim3(64), 0, s, cm, first, boxes);
+    if (!cm.pq_heap || !cm.pq_seen || !cm.dist_lut) return;  // (a reconfigure that could not allocate them keeps the previous mode: navgpu_inflation_configure)
+    hipFuncSetAttribute((const void*)k_inflate_pq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPqLdsBytes);
+    hipLaunchKernelGGL(k_inflate_pq, dim3(count), dim3(64), kPqLdsBytes, s, cm, first, boxes);
     return;
   }
   if (cm.lut2_ok && R >= 1 && R <= 14) {

@@ -49,12 +49,14 @@ struct ObsCsr {  // one observation, device form
   double obstacle_range, raytrace_range;
 };
 
-// CellData of inflation_layer.h:55-80 as the heap stores it (x_, y_ follow from index_)
+// CellData of inflation_layer.h:55-80 as the heap stores it: the key is the RANK of distance_ among the distinct cached
+// distances (same order, same ties), the source a signed offset from the cell (x_, y_ follow from index_)
 struct PqCell {
-  double distance;
   uint32_t index;
-  uint16_t src_x, src_y;
+  uint16_t rank;
+  int8_t sdx, sdy;
 };
+static_assert(sizeof(PqCell) == 8, "heap entry");
 struct CostmapDev {
   uint32_t nx, ny, cells, cells_padded;
   double res;
@@ -79,7 +81,7 @@ struct CostmapDev {
   int32_t lut2_ok;
   // reference-order mode (navgpu_inflation_params::priority_queue_order): InflationLayer's own priority-queue walk
   int32_t infl_pq;
-  double* dist_lut;    // (R+2)^2 cached_distances_ = hypot(i, j), host libm
+  double* dist_lut;    // (R+2)^2 uint16 ranks of cached_distances_ = hypot(i, j) (host libm) among their distinct values; 0xFFFF beyond the radius
   uint8_t* pq_seen;    // [n][cells] seen_
   PqCell* pq_heap;     // [n][pq_cap] the binary heap std::priority_queue<CellData> keeps
   uint64_t pq_cap;

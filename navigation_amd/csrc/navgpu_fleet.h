@@ -70,7 +70,10 @@ struct navgpu_fleet {
   float* hp_pts = nullptr;
   double *hp_fpw = nullptr, *hp_pose = nullptr, *hp_plan = nullptr, *hp_front = nullptr;
   int32_t *hp_shift = nullptr, *hp_align = nullptr;
-  uint32_t* hp_reach = nullptr;
+  uint32_t *hp_reach = nullptr, *hp_fpn = nullptr;
+  // the two staging blocks (device / pinned host, same layout): the pointers above and cm.pose ... / pl.state ... point into them
+  uint8_t *cm_stage_dev = nullptr, *cm_stage_host = nullptr, *pl_stage_dev = nullptr, *pl_stage_host = nullptr;
+  size_t cm_stage_bytes = 0, pl_stage_bytes = 0;
   // bounded MapGrid wavefronts (navgpu_planner_set_bounded_map_grids): which robots hold grids that are exact inside
   // their box only, that box, and whether the inputs of the cycle that made them are still the staged ones
   bool bounded_grids = true;

@@ -95,13 +95,42 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   A(cm.lut, 66 * 66);
   A(cm.lut2, 256);
   A(cm.state, n);
-  A(cm.pose, (size_t)n * 3);
-  A(cm.fp_world, (size_t)n * kMaxFootprint * 2);
-  A(cm.fp_n, n);
-  A(cm.obs, (size_t)n * cm.max_obs);
-  A(cm.obs_count, n);
-  A(cm.points, (size_t)n * cm.max_points * 3);
   A(cm.shift, (size_t)n * 2);
+  // What a cycle hands over lives in two blocks, laid out alike in device memory and in a pinned host mirror: a stage call
+  // that covers the whole fleet is ONE host-to-device copy per block (a dozen small copies cost the stream ~40 us and the
+  // host as many runtime calls); partial ranges copy array by array.
+  {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+      const size_t at = off;
+      off = (off + bytes + 255) & ~(size_t)255;
+      return at;
+    };
+    const size_t o_pose = take(sizeof(double) * 3 * n), o_fpw = take(sizeof(double) * 2 * kMaxFootprint * n), o_fpn = take(sizeof(uint32_t) * n),
+                 o_obs = take(sizeof(ObsCsr) * (size_t)n * cm.max_obs), o_cnt = take(sizeof(uint32_t) * n),
+                 o_pts = take(sizeof(float) * 3 * (size_t)n * cm.max_points);
+    f->cm_stage_bytes = off;
+    uint8_t *d = nullptr, *h = nullptr;
+    A(d, off);
+    if ((rc = f->allocPinned(&h, off)) != 0) {
+      navgpu_fleet_destroy(f);
+      return rc;
+    }
+    f->cm_stage_dev = d;
+    f->cm_stage_host = h;
+    cm.pose = reinterpret_cast<double*>(d + o_pose);
+    cm.fp_world = reinterpret_cast<double*>(d + o_fpw);
+    cm.fp_n = reinterpret_cast<uint32_t*>(d + o_fpn);
+    cm.obs = reinterpret_cast<ObsCsr*>(d + o_obs);
+    cm.obs_count = reinterpret_cast<uint32_t*>(d + o_cnt);
+    cm.points = reinterpret_cast<float*>(d + o_pts);
+    f->hp_pose = reinterpret_cast<double*>(h + o_pose);
+    f->hp_fpw = reinterpret_cast<double*>(h + o_fpw);
+    f->hp_fpn = reinterpret_cast<uint32_t*>(h + o_fpn);
+    f->hp_obs = reinterpret_cast<ObsCsr*>(h + o_obs);
+    f->hp_cnt = reinterpret_cast<uint32_t*>(h + o_cnt);
+    f->hp_pts = reinterpret_cast<float*>(h + o_pts);
+  }
   if (d->rolling_window) {
     if (d->layers & NAVGPU_LAYER_STATIC) {  // StaticLayer::updateCosts' rolling branch: a transform per robot, identity until set
       A(cm.stat_tf, (size_t)n * 12);
@@ -122,19 +151,8 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
     navgpu_fleet_destroy(f);                       \
     return rc;                                     \
   }
-  AP(f->hp_obs, (size_t)n * cm.max_obs);
-  AP(f->hp_cnt, n);
   AP(f->hp_used, n);
-  AP(f->hp_pts, (size_t)n * cm.max_points * 3);
-  AP(f->hp_fpw, (size_t)n * kMaxFootprint * 2);
-  AP(f->hp_pose, (size_t)n * 3);
   AP(f->hp_shift, (size_t)n * 2);
-  AP(f->hp_state, n);
-  AP(f->hp_plan, (size_t)n * f->desc.max_plan * 2);
-  AP(f->hp_plan_cnt, n);
-  AP(f->hp_front, (size_t)n * 2);
-  AP(f->hp_align, n);
-  AP(f->hp_reach, n);
   AP(f->hp_result, n);
   f->pl.result = f->hp_result;  // k_select writes results straight into pinned host memory (72 B per robot)
 #undef AP
@@ -152,12 +170,37 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   pl.master = cm.master;
   pl.max_plan = f->desc.max_plan;
   pl.max_sim_steps = f->desc.max_sim_steps;
-  A(pl.state, n);
-  A(pl.front_last, (size_t)n * 2);
-  A(pl.align_on, n);
-  A(pl.bfs_reach, n);
-  A(pl.plan, (size_t)n * pl.max_plan * 2);
-  A(pl.plan_count, n);
+  {  // the planner's staged inputs: second block (see above)
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+      const size_t at = off;
+      off = (off + bytes + 255) & ~(size_t)255;
+      return at;
+    };
+    const size_t o_state = take(sizeof(navgpu_robot_state) * n), o_front = take(sizeof(double) * 2 * n), o_align = take(sizeof(int32_t) * n),
+                 o_reach = take(sizeof(uint32_t) * n), o_pcnt = take(sizeof(uint32_t) * n), o_plan = take(sizeof(double) * 2 * (size_t)n * pl.max_plan);
+    f->pl_stage_bytes = off;
+    uint8_t *d = nullptr, *h = nullptr;
+    A(d, off);
+    if ((rc = f->allocPinned(&h, off)) != 0) {
+      navgpu_fleet_destroy(f);
+      return rc;
+    }
+    f->pl_stage_dev = d;
+    f->pl_stage_host = h;
+    pl.state = reinterpret_cast<navgpu_robot_state*>(d + o_state);
+    pl.front_last = reinterpret_cast<double*>(d + o_front);
+    pl.align_on = reinterpret_cast<int32_t*>(d + o_align);
+    pl.bfs_reach = reinterpret_cast<uint32_t*>(d + o_reach);
+    pl.plan_count = reinterpret_cast<uint32_t*>(d + o_pcnt);
+    pl.plan = reinterpret_cast<double*>(d + o_plan);
+    f->hp_state = reinterpret_cast<navgpu_robot_state*>(h + o_state);
+    f->hp_front = reinterpret_cast<double*>(h + o_front);
+    f->hp_align = reinterpret_cast<int32_t*>(h + o_align);
+    f->hp_reach = reinterpret_cast<uint32_t*>(h + o_reach);
+    f->hp_plan_cnt = reinterpret_cast<uint32_t*>(h + o_pcnt);
+    f->hp_plan = reinterpret_cast<double*>(h + o_plan);
+  }
   A(pl.fp_spec, (size_t)n * kMaxFootprint * 2);
   A(pl.fp_n, n);
   A(pl.axis_count, (size_t)n * 4);
@@ -579,11 +622,19 @@ int navgpu_inflation_configure(navgpu_fleet* f, const navgpu_inflation_params* p
   // priority queue's storage - every cell is pushed at most once by each of its four neighbours, plus once as a seed.
   // Everything that can fail (limits, allocations) comes BEFORE the first write to the configuration in use: a failed
   // reconfigure leaves the previous one intact.
-  std::vector<double> dist_lut((size_t)n * n);
+  std::vector<uint16_t> dist_lut((size_t)n * n);
   const int want_pq = p->priority_queue_order ? 1 : 0;
   if (want_pq) {
+    // the heap only ever COMPARES cached_distances_ (inflation_layer.h:82-85) and tests them against the cell radius
+    // (inflation_layer.cpp:286): their ranks among the distinct values carry exactly that, in two bytes
+    std::vector<double> d((size_t)n * n);
     for (uint32_t i = 0; i < n; ++i)
-      for (uint32_t j = 0; j < n; ++j) dist_lut[(size_t)i * n + j] = hypot(i, j);
+      for (uint32_t j = 0; j < n; ++j) d[(size_t)i * n + j] = hypot(i, j);
+    std::vector<double> uniq(d);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    for (size_t k = 0; k < d.size(); ++k)
+      dist_lut[k] = d[k] > (double)R ? (uint16_t)0xFFFFu : (uint16_t)(std::lower_bound(uniq.begin(), uniq.end(), d[k]) - uniq.begin());
     if (cm.nx > 65535 || cm.ny > 65535) return NAVGPU_ERR_CAPACITY;
     int rc;
     if (!cm.dist_lut && (rc = f->alloc(&cm.dist_lut, (size_t)66 * 66))) return rc;
@@ -621,7 +672,7 @@ int navgpu_inflation_configure(navgpu_fleet* f, const navgpu_inflation_params* p
   HIP_TRY(waitStream(f->stream));
   HIP_TRY(hipMemcpyAsync(cm.lut, lut.data(), lut.size(), hipMemcpyHostToDevice, f->stream));
   HIP_TRY(hipMemcpyAsync(cm.lut2, lut2.data(), lut2.size(), hipMemcpyHostToDevice, f->stream));
-  if (want_pq) HIP_TRY(hipMemcpyAsync(cm.dist_lut, dist_lut.data(), sizeof(double) * dist_lut.size(), hipMemcpyHostToDevice, f->stream));
+  if (want_pq) HIP_TRY(hipMemcpyAsync(cm.dist_lut, dist_lut.data(), sizeof(uint16_t) * dist_lut.size(), hipMemcpyHostToDevice, f->stream));
   HIP_TRY(waitStream(f->stream));
   cm.infl_pq = want_pq;
   cm.lut2_ok = lut2_ok ? 1 : 0;
@@ -786,12 +837,17 @@ int navgpu_costmap_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
       f->hp_fpw[((size_t)i * kMaxFootprint + v) * 2 + 1] = y + (sx * sin_th + sy * cos_th);
     }
   }
-  HIP_TRY(hipMemcpyAsync(cm.pose + (size_t)first * 3, f->hp_pose + (size_t)first * 3, sizeof(double) * 3 * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(cm.obs + (size_t)first * cm.max_obs, f->hp_obs + (size_t)first * cm.max_obs, sizeof(ObsCsr) * (size_t)count * cm.max_obs, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(cm.obs_count + first, f->hp_cnt + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(cm.points + (size_t)first * cm.max_points * 3, f->hp_pts + (size_t)first * cm.max_points * 3, sizeof(float) * 3 * (size_t)count * cm.max_points, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(cm.fp_world + (size_t)first * kMaxFootprint * 2, f->hp_fpw + (size_t)first * kMaxFootprint * 2, sizeof(double) * 2 * kMaxFootprint * (size_t)count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(cm.fp_n + first, &f->h_fp_n[first], sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
+  memcpy(f->hp_fpn + first, &f->h_fp_n[first], sizeof(uint32_t) * count);
+  if (first == 0 && count == f->desc.n_instances) {  // the whole fleet: one copy of the block
+    HIP_TRY(hipMemcpyAsync(f->cm_stage_dev, f->cm_stage_host, f->cm_stage_bytes, hipMemcpyHostToDevice, f->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(cm.pose + (size_t)first * 3, f->hp_pose + (size_t)first * 3, sizeof(double) * 3 * count, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(cm.obs + (size_t)first * cm.max_obs, f->hp_obs + (size_t)first * cm.max_obs, sizeof(ObsCsr) * (size_t)count * cm.max_obs, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(cm.obs_count + first, f->hp_cnt + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(cm.points + (size_t)first * cm.max_points * 3, f->hp_pts + (size_t)first * cm.max_points * 3, sizeof(float) * 3 * (size_t)count * cm.max_points, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(cm.fp_world + (size_t)first * kMaxFootprint * 2, f->hp_fpw + (size_t)first * kMaxFootprint * 2, sizeof(double) * 2 * kMaxFootprint * (size_t)count, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(cm.fp_n + first, f->hp_fpn + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
+  }
   return NAVGPU_OK;  // copies stay in flight on the fleet's stream; the kernels are ordered behind them
 }
 
@@ -1113,12 +1169,16 @@ int navgpu_planner_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
     f->hp_reach[i] = bfsReachCells(f, s, gx, gy);
   }
   f->touchInputs(first, count);
-  HIP_TRY(hipMemcpyAsync(pl.state + first, f->hp_state + first, sizeof(navgpu_robot_state) * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(pl.plan + (size_t)first * pl.max_plan * 2, f->hp_plan + (size_t)first * pl.max_plan * 2, sizeof(double) * 2 * (size_t)count * pl.max_plan, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(pl.plan_count + first, f->hp_plan_cnt + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(pl.front_last + (size_t)first * 2, f->hp_front + (size_t)first * 2, sizeof(double) * 2 * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(pl.align_on + first, f->hp_align + first, sizeof(int32_t) * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(pl.bfs_reach + first, f->hp_reach + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
+  if (first == 0 && count == f->desc.n_instances) {  // the whole fleet: one copy of the block
+    HIP_TRY(hipMemcpyAsync(f->pl_stage_dev, f->pl_stage_host, f->pl_stage_bytes, hipMemcpyHostToDevice, f->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(pl.state + first, f->hp_state + first, sizeof(navgpu_robot_state) * count, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(pl.plan + (size_t)first * pl.max_plan * 2, f->hp_plan + (size_t)first * pl.max_plan * 2, sizeof(double) * 2 * (size_t)count * pl.max_plan, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(pl.plan_count + first, f->hp_plan_cnt + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(pl.front_last + (size_t)first * 2, f->hp_front + (size_t)first * 2, sizeof(double) * 2 * count, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(pl.align_on + first, f->hp_align + first, sizeof(int32_t) * count, hipMemcpyHostToDevice, f->stream));
+    HIP_TRY(hipMemcpyAsync(pl.bfs_reach + first, f->hp_reach + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
+  }
   f->planner_staged = true;
   f->hp_dma_pending = true;
   return NAVGPU_OK;

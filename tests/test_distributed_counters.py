@@ -91,3 +91,48 @@ def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr and r.stdout.strip() == ""
+
+
+@pytest.mark.timeout(300)
+def test_bench_two_ranks_stub_fleet_json_line():
+    """bench.py's N > 1 code path end to end on the CPU box: two ranks under torch.distributed.run (gloo), a host-only stand-in
+    for the fleet (--stub-fleet: computes nothing), the counter all-reduce, ranks_seen, per-rank step times, and the ONE JSON
+    line rank 0 prints."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-fleet", "--steps", "6", "--warmup", "1", "--instances", "16",
+                        "--groups", "2", "--no-cpu-baseline", "--no-single"], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["config"]["groups_per_gpu"] == 2
+    assert [x["rank"] for x in d["ranks_seen"]] == [0, 1] and "rehearsal" in d
+    assert d["trajectories_per_step"] == 2 * 16 * 17000            # both ranks' robots, every cycle's own count
+    assert abs(d["value"] - d["trajectories_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    pr = d["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - d["ms_per_step"]) < 1e-6  # MAX over ranks is the job's time
+    assert d["roofline"]["kernel"] and "alone" in d["roofline"]
+
+
+def test_bench_refuses_ranks_that_share_a_device(monkeypatch):
+    """Two ranks on one device are a rehearsal: without --rehearse-on-one-gpu (or the stand-in) bench.py must stop, not report."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+
+    class P:
+        pci_bus_id, pci_domain_id, pci_device_id = 0x43, 0, 0
+
+    class T:
+        class cuda:
+            @staticmethod
+            def get_device_properties(i):
+                return P()
+    assert bench.device_identity(T, 0, False) == bench.device_identity(T, 1, False) == "0000:43:00"
+    assert bench.device_identity(T, 1, True) == "stub:1"

@@ -1,17 +1,23 @@
 #!/bin/bash
 # Collect the per-round rocprofv3 evidence on the GPU box:  bash tools/collect_profiles.sh round3_a [extra bench.py flags]
 # Every pass is its own run (kernel-trace/stats, FETCH_SIZE, WRITE_SIZE, three SQ counter groups); the VALU issue time
-# is measured on the SAME box by tools/microbench/valu_rate.  Outputs: gpurun_out/profiles_<tag>/<tag>_*.{csv,json,txt};
-# copy the summaries (not the raw per-dispatch PMC rows) into profiles/.
+# is measured on the SAME box by tools/microbench/valu_rate.  The per-kernel passes run the fleet on ONE stream
+# (--groups 1: one full-fleet launch per kernel and step, nothing overlapping - per-kernel times and counters mean what
+# they say); one more kernel-trace pass runs the default stream groups and records how far their kernels overlap.
+# Outputs: gpurun_out/profiles_<tag>/<tag>_*.{csv,json,txt}; copy the summaries (not the raw per-dispatch PMC rows) into profiles/.
 set -e
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 tag=$1; shift || true
 extra="$@"
 out=gpurun_out/profiles_$tag; mkdir -p $out
-BENCH="python3 bench.py --no-cpu-baseline --no-single $extra"
+BENCH="python3 bench.py --no-cpu-baseline --no-single --groups 1 $extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o r -- $BENCH --steps 10 --warmup 2 > $out/${tag}_bench_under_rocprof.json 2> $out/stats.err
 cp $out/stats/r_kernel_stats.csv $out/${tag}_kernel_stats.csv
 python3 tools/timeline_gaps.py $out/stats/r_kernel_trace.csv > $out/${tag}_timeline_gaps.txt 2>&1 || true
+# the default schedule (stream groups): which kernels run side by side, and each kernel's duration in that company
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/groups -o r -- python3 bench.py --no-cpu-baseline --no-single $extra --steps 20 --warmup 2 > $out/${tag}_bench_groups_under_rocprof.json 2> $out/groups.err
+cp $out/groups/r_kernel_stats.csv $out/${tag}_kernel_stats_groups.csv
+python3 tools/overlap_trace.py $out/groups/r_kernel_trace.csv > $out/${tag}_overlap_groups.txt 2>&1 || true
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o r -- $BENCH --steps 3 --warmup 1 > $out/$c.json 2> $out/$c.err
   lc=$(echo $c | tr A-Z a-z)

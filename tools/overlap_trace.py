@@ -14,8 +14,11 @@ for r in rows:
     ev.append((e, -1, k))
     dur[k].append(e - s)
 ev.sort()
-# steady state: the last 60 % of the trace
-t_lo = ev[0][0] + 0.4 * (ev[-1][0] - ev[0][0])
+# steady state: from the first k_select on (set-up launches before it), over the span in which k_select keeps recurring
+sel = sorted(t for t, d, k in ev if d == 1 and k.startswith("k_select"))
+t_lo = sel[len(sel) // 5] if sel else ev[0][0]
+t_hi = sel[-1] if sel else ev[-1][0]
+ev = [e for e in ev if e[0] <= t_hi]
 active, last, share = 0, None, collections.Counter()
 pair = collections.Counter()
 running = collections.Counter()
