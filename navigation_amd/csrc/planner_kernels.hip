@@ -1349,7 +1349,13 @@ __device__ __forceinline__ void bfsRowsGrid(const PlannerDev& pl, const uint32_t
     by1 = __builtin_amdgcn_readfirstlane(bb.w);
     care_ok = __builtin_amdgcn_readfirstlane(pl.bfs_box[8 * inst + 4]);
   }
-  if (!(bx1 >= bx0 && by1 >= by0)) return;  // (uniform over the workgroup) a whole-grid search: the plane variant's item
+  if (!(bx1 >= bx0 && by1 >= by0)) {  // (uniform over the workgroup) a whole-grid search: the region is the map, nothing is ever "settled"
+    bx0 = 0;
+    by0 = 0;
+    bx1 = (int)pl.nx - 1;
+    by1 = (int)pl.ny - 1;
+    care_ok = 0;
+  }
   extern __shared__ __align__(16) uint32_t sm[];
   __shared__ uint32_t s_wave[16];
   __shared__ uint32_t s_flag[3];  // rotating by exchange: something new was reached since the last one
@@ -2327,11 +2333,13 @@ void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_
     if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<R, LEG, P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); \
     if (!free_ready) hipLaunchKernelGGL(k_free_bits, dim3((pl.ny * ((pl.nx + 31) / 32) + 255) / 256, count), dim3(256), 0, s, pl, first); \
     if (!free_ready) hipMemsetAsync(pl.bfs_next_item, 0, 2 * sizeof(uint32_t), s);  /* (k_samples zeroes them too) */         \
+    if constexpr (!LEG) {                                                                                                     \
+      if (launch_bfs_rows(pl, first, count, s, order)) return;  /* bounded and whole-grid searches alike */                    \
+    }                                                                                                                         \
     const bool direct = !LEG && pl.bfs_bounded && n_whole >= 0 && (uint32_t)n_whole < count;                                  \
     if (!direct || n_whole > 0)                                                                                               \
       hipLaunchKernelGGL((k_bfs_wave<R, LEG, P>), dim3(std::min(count * pl.bfs_grids, bfs_cu_count())), dim3(1024), lds_w, s, pl, first, count, pl.bfs_next_item, order, direct ? 1 : 0); \
     if constexpr (!LEG) {                                                                                                     \
-      if (direct && launch_bfs_rows(pl, first, count, s, order)) return;                                                       \
       if (direct) {                                                                                                           \
         if (lds_w > 48 * 1024) hipFuncSetAttribute((const void*)k_bfs_wave<R, false, P, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w); \
         hipLaunchKernelGGL((k_bfs_wave<R, false, P, true>), dim3(std::min(count * pl.bfs_grids, std::min(bfs_direct_wgs_per_cu(), 2 * lds_w <= 156u * 1024u ? 2u : 1u) * bfs_cu_count())), dim3(1024), lds_w, s, pl, first, count, pl.bfs_next_item + 1, order, 0); \
