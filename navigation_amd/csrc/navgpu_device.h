@@ -21,7 +21,7 @@ constexpr int kCareRows = 128, kCareWords = 4;  // bounded wavefronts: extent of
 #define NAVGPU_SCORE_TAB_THREADS 256  // samples per k_score_tab workgroup (512 with a 52 KB image: 0.523 ms; 256 with 26 KB: 0.516 ms, configs[4] 2.17 -> 1.82 ms)
 #endif
 #ifndef NAVGPU_SCORE_TAB_LDS_KB
-#define NAVGPU_SCORE_TAB_LDS_KB 26    // first LDS budget tried for a k_score_tab workgroup's image (window + screens + table rows)
+#define NAVGPU_SCORE_TAB_LDS_KB 14    // first LDS budget tried for a k_score_tab workgroup's image (window + screens + table rows): 3 v_theta rows at configs[2] (26 KB = 9 rows: k_score 0.526 -> 0.506 ms)
 #endif
 #ifndef NAVGPU_SCORE_TAB_WAVES
 #define NAVGPU_SCORE_TAB_WAVES 6      // waves per SIMD k_score_tab is compiled for (6: 80 registers)

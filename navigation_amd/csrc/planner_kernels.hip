@@ -2441,6 +2441,11 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
 #ifdef NAVGPU_SCORE_TIMING
   const unsigned long long ts0 = wall_clock64();
 #endif
+  // A scoring workgroup's prologue (a few dependent loads, the image copy, barriers) is a handful of instructions, but its
+  // waves are the YOUNGEST on their SIMDs and lose every issue arbitration against the five older workgroups in their
+  // rollout loops: measured 40 % of a workgroup's residence before its first trajectory point.  Raised priority until the
+  // image is in place gets it out of the way.
+  if (PREP == 2) __builtin_amdgcn_s_setprio(3);
   const navgpu_dwa_config& c = pl.cfg;
   const Geom g = geomOf(pl, inst);
   const navgpu_robot_state st = pl.state[inst];
@@ -2454,11 +2459,28 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   const int win = (int)pl.win;
 
   // ---- stage: footprint, per-axis samples, costmap window around the robot
-  if (tid < 2 * nfp) s_fp[tid] = pl.fp_spec[(size_t)inst * kMaxFootprint * 2 + tid];
-  if (!EXPLICIT) {
-    for (uint32_t i = tid; i < 3 * kMaxAxis; i += blockDim.x) {
-      uint32_t a = i / kMaxAxis, k = i - a * kMaxAxis;
-      s_axis[a][k] = k < pl.max_axis ? pl.axis_samples[((size_t)inst * 3 + a) * pl.max_axis + k] : 0.f;
+  // A scoring workgroup (PREP 2) keeps what it loads here in registers and writes it to LDS together with its image
+  // further down: ONE batch of loads in flight and one barrier instead of five dependent round trips and three barriers
+  // (a load takes several microseconds while 24 waves per CU gather from the distance grids; measured 40 % of a
+  // workgroup's residence was spent before its first trajectory point).
+  constexpr int kAxisChunks = (3 * kMaxAxis + THREADS - 1) / THREADS;
+  double pre_fp = 0.0;
+  float pre_axis[kAxisChunks];
+  if (PREP == 2) {
+    pre_fp = pl.fp_spec[(size_t)inst * kMaxFootprint * 2 + (tid < 2 * nfp ? tid : 0)];
+#pragma unroll
+    for (int u = 0; u < kAxisChunks; ++u) {
+      const uint32_t i = min(tid + (uint32_t)u * THREADS, 3u * kMaxAxis - 1), a = i / kMaxAxis, k = i - a * kMaxAxis;
+      pre_axis[u] = pl.axis_samples[((size_t)inst * 3 + a) * pl.max_axis + min(k, pl.max_axis - 1)];
+      if (k >= pl.max_axis) pre_axis[u] = 0.f;
+    }
+  } else {
+    if (tid < 2 * nfp) s_fp[tid] = pl.fp_spec[(size_t)inst * kMaxFootprint * 2 + tid];
+    if (!EXPLICIT) {
+      for (uint32_t i = tid; i < 3 * kMaxAxis; i += blockDim.x) {
+        uint32_t a = i / kMaxAxis, k = i - a * kMaxAxis;
+        s_axis[a][k] = k < pl.max_axis ? pl.axis_samples[((size_t)inst * 3 + a) * pl.max_axis + k] : 0.f;
+      }
     }
   }
   if (tid == 0) s_cnt[0] = s_cnt[1] = 0;
@@ -2508,7 +2530,10 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   uint32_t* s_bb = s_ba + 2 * win * nw;
   const int rc = (int)pl.fp_rcells;
   const uint8_t fail_span_w = (pl.cfg.allow_unknown != 0) ? 0 : 1;
-  __syncthreads();
+  if (PREP != 2) __syncthreads();
+#ifdef NAVGPU_SCORE_TIMING
+  const unsigned long long ts0a = wall_clock64();
+#endif
   if (PREP != 2) {
   for (int it = tid; it < win * nw; it += blockDim.x) {
     const int y = it / nw, j = it - y * nw;
@@ -2666,7 +2691,10 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       }
     }
   }
-  __syncthreads();
+  if (PREP != 2) __syncthreads();
+#ifdef NAVGPU_SCORE_TIMING
+  const unsigned long long ts0b = wall_clock64();
+#endif
   if (PREP != 0) {  // the LDS image as 16-byte words: [0, prep_bytes)
     uint4* img = reinterpret_cast<uint4*>(pl.prep + (size_t)inst * pl.prep_stride);
     uint4* lds = reinterpret_cast<uint4*>(s_dyn);
@@ -2677,6 +2705,14 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     }
     if (!TABLES) {
       for (uint32_t i = tid; i < n16; i += blockDim.x) lds[i] = img[i];
+      if (PREP == 2) {
+        if (tid < 2 * nfp) s_fp[tid] = pre_fp;
+#pragma unroll
+        for (int u = 0; u < kAxisChunks; ++u) {
+          const uint32_t i = tid + (uint32_t)u * THREADS;
+          if (i < 3u * kMaxAxis) s_axis[i / kMaxAxis][i % kMaxAxis] = pre_axis[u];
+        }
+      }
     } else {
       // window + screens, and of the tables only the v_theta rows this workgroup's samples use (lanes are
       // v_theta-major: 512 lanes of a 33 x 33 (vx, vy) grid span two of the 17 rows), at their usual place
@@ -2689,17 +2725,33 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       const int n_trig = ncopy * K * 2, n_rot = ncopy * K * tnfp;  // 32 B per entry, 16 B per vertex
       const int l_trig = n16w + r0 * K * 2, g_trig = n16w + (t_row_base + r0) * K * 2;
       const int l_rot = n16w + lrows * K * 2 + r0 * K * tnfp, g_rot = n16w + (int)pl.tab_nth * K * 2 + (t_row_base + r0) * K * tnfp;
-      for (int i = tid; i < n16w + n_trig + n_rot; i += blockDim.x) {
-        if (i < n16w) lds[i] = img[i];
-        else if (i < n16w + n_trig) lds[l_trig + (i - n16w)] = img[g_trig + (i - n16w)];
-        else lds[l_rot + (i - n16w - n_trig)] = img[g_rot + (i - n16w - n_trig)];
-      }
+      const int n16t = n16w + n_trig + n_rot;
       const float* g_th = reinterpret_cast<const float*>(img + n16w + (size_t)pl.tab_nth * K * (2 + tnfp)) + t_row_base * K;
-      for (int i = r0 * K + (int)tid; i < (r0 + ncopy) * K; i += blockDim.x) s_th[i] = g_th[i];
+      auto srcOf = [&](int i) { return i < n16w ? i : (i < n16w + n_trig ? g_trig + (i - n16w) : g_rot + (i - n16w - n_trig)); };
+      auto dstOf = [&](int i) { return i < n16w ? i : (i < n16w + n_trig ? l_trig + (i - n16w) : l_rot + (i - n16w - n_trig)); };
+      constexpr int kBatch = 4;  // 16-byte loads a lane has in flight (4 x 256 lanes x 16 B = 16 KB: a configs[2] image whole)
+      uint4 v[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) v[u] = img[srcOf(min((int)tid + u * THREADS, n16t - 1))];
+      const int th_i = r0 * K + (int)tid, th_n = (r0 + ncopy) * K;
+      const float th_v = g_th[min(th_i, max(th_n - 1, 0))];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u)
+        if ((int)tid + u * THREADS < n16t) lds[dstOf((int)tid + u * THREADS)] = v[u];
+      if (th_i < th_n) s_th[th_i] = th_v;
+      if (tid < 2 * nfp) s_fp[tid] = pre_fp;
+#pragma unroll
+      for (int u = 0; u < kAxisChunks; ++u) {
+        const uint32_t i = tid + (uint32_t)u * THREADS;
+        if (i < 3u * kMaxAxis) s_axis[i / kMaxAxis][i % kMaxAxis] = pre_axis[u];
+      }
+      for (int i = (int)tid + kBatch * THREADS; i < n16t; i += blockDim.x) lds[dstOf(i)] = img[srcOf(i)];  // larger images: the rest
+      for (int i = th_i + (int)blockDim.x; i < th_n; i += blockDim.x) s_th[i] = g_th[i];
     }
     __syncthreads();
   }
 
+  if (PREP == 2) __builtin_amdgcn_s_setprio(0);
 #ifdef NAVGPU_SCORE_TIMING
   const unsigned long long ts1 = wall_clock64();
 #endif
@@ -2870,6 +2922,10 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       // which of the four screens count: obstacle (dilated "not free" with sum_scores, else dilated "can fail"), path, goal
       const bool scr_sum = c.sum_scores != 0;  // the obstacle screen: dilated "not free" with sum_scores, else dilated "can fail"
       const bool screen_on = !AGG && fwd_screen && (nfp >= 3 || !en_obs);
+      // the forward-margin test is only needed when the LDS window reaches into the margin band of the map (wave-uniform)
+      const bool need_margin = !((uint32_t)wx0 - fwd_lo < fwd_nx && (uint32_t)(wx0 + win - 1) - fwd_lo < fwd_nx && (uint32_t)wy0 - fwd_lo < fwd_ny &&
+                                 (uint32_t)(wy0 + win - 1) - fwd_lo < fwd_ny);
+      uint32_t scr_z = 0xFFFFFFFFu, scr_w = 0xFFFFFFFFu;  // the path / goal screens count while their critics are live
       if (osc_fail) {
         total = -5.0;
       } else {
@@ -2890,22 +2946,41 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           // ---- screen: on every point but the last a critic can only FAIL (its value is overwritten: aggregation
           // Last; with sum_scores the obstacle critic adds the point's cost, which is 0 when everything in reach is
           // free).  One 16-byte LDS read says whether any critic could fail here; if none can, the point is done.
-          bool screened = false;
-          if (screen_on && step != num_steps - 1 && ok_c && inWin((int)cx, (int)cy)) {
-            const int lxw = (int)cx - wx0;
-            const uint4 fb = s_fb4[((int)cy - wy0) * nw + (lxw >> 5)];
-            // (a critic that has already failed, or that follows one that has, cannot change the outcome any more)
-            const uint32_t any = (scr_sum ? fb.x : fb.y) | (first_fail > 4 ? fb.z : 0u) | (first_fail > 5 ? fb.w : 0u);
-            screened = !((any >> (lxw & 31)) & 1u) && (cx - fwd_lo < fwd_nx) && (cy - fwd_lo < fwd_ny);
-#ifdef NAVGPU_SCORE_STATS
-            SCORE_STAT(8, (fb.y >> (lxw & 31)) & 1u);
-            SCORE_STAT(9, (fb.z >> (lxw & 31)) & 1u);
-            SCORE_STAT(10, (fb.w >> (lxw & 31)) & 1u);
-            SCORE_STAT(11, !((cx - fwd_lo < fwd_nx) && (cy - fwd_lo < fwd_ny)));
-#endif
+          // Branch-free up to the decision: the screen word is read whatever the point is (clamped address) and the NEXT
+          // pose is computed while that read is in flight - the step's LDS round trips used to be waited for one by one,
+          // each behind its own exec-mask branch (38 % of the kernel's wave cycles were spent parked, profiles/round3_b).
+          const bool in_w = ok_c && inWin((int)cx, (int)cy);
+          const int lxw = in_w ? (int)cx - wx0 : 0;
+          const uint4 fbw = s_fb4[(in_w ? (int)cy - wy0 : 0) * nw + (lxw >> 5)];
+          // ---- advance (computeNewPositions :253-260): fp64 on fp32 state, rounded back to fp32
+          if (continued) {
+            float t1[3];
+            newVel(lv, t1);
+            lv[0] = t1[0];
+            lv[1] = t1[1];
+            lv[2] = t1[2];
           }
+          double sn2 = 0.0, cs2 = 0.0;
+          if (TABLES) {
+            cs2 = s_trig[4 * te + 2];
+            sn2 = s_trig[4 * te + 3];
+          } else if (lv[1] != 0.0f) {
+            sincos(M_PI_2 + th, &sn2, &cs2);
+          }
+          const float nxp = (float)(px + (lv[0] * cs + lv[1] * cs2) * dt);
+          const float nyp = (float)(py + (lv[0] * sn + lv[1] * sn2) * dt);
+          const float ntp = (float)(pth + lv[2] * dt);
+          // (a critic that has already failed, or that follows one that has, cannot change the outcome any more: scr_z / scr_w)
+          const uint32_t any = (scr_sum ? fbw.x : fbw.y) | (fbw.z & scr_z) | (fbw.w & scr_w);
+          const bool margin_ok = !need_margin || ((cx - fwd_lo < fwd_nx) && (cy - fwd_lo < fwd_ny));
+          const bool screened = screen_on && step != num_steps - 1 && in_w && !((any >> (lxw & 31)) & 1u) && margin_ok;
 #ifdef NAVGPU_SCORE_STATS
-          else if (step != num_steps - 1) {
+          if (screen_on && step != num_steps - 1 && in_w) {
+            SCORE_STAT(8, (fbw.y >> (lxw & 31)) & 1u);
+            SCORE_STAT(9, (fbw.z >> (lxw & 31)) & 1u);
+            SCORE_STAT(10, (fbw.w >> (lxw & 31)) & 1u);
+            SCORE_STAT(11, !((cx - fwd_lo < fwd_nx) && (cy - fwd_lo < fwd_ny)));
+          } else if (step != num_steps - 1) {
             SCORE_STAT(12, !ok_c);
             SCORE_STAT(13, ok_c && !inWin((int)cx, (int)cy));
             SCORE_STAT(14, !screen_on);
@@ -2930,10 +3005,8 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           // Without sum_scores only the LAST point's footprint cost survives (obstacle_cost_function.cpp:
           // cost = f_cost), the earlier points only have to be legal: no failing cell in reach is enough.
           bool all_free = false;
-          if (live_obs && ok_c && nfp >= 3 && inWin((int)cx, (int)cy)) {
-            const int lxw = (int)cx - wx0;
-            const uint2 fb = reinterpret_cast<const uint2*>(s_fb)[2 * (((int)cy - wy0) * nw + (lxw >> 5))];
-            const bool not_free = (fb.x >> (lxw & 31)) & 1u, can_fail = (fb.y >> (lxw & 31)) & 1u;
+          if (live_obs && nfp >= 3 && in_w) {  // (the same screen word as above)
+            const bool not_free = (fbw.x >> (lxw & 31)) & 1u, can_fail = (fbw.y >> (lxw & 31)) & 1u;
             all_free = !not_free || (!c.sum_scores && step != num_steps - 1 && !can_fail);
           }
           if (live_obs && all_free) {
@@ -3171,25 +3244,9 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
             }
           }
           }  // !AGG
+          scr_z = first_fail > 4 ? 0xFFFFFFFFu : 0u;  // (first_fail only changes in here)
+          scr_w = first_fail > 5 ? 0xFFFFFFFFu : 0u;
           }  // !screened
-          // ---- advance (computeNewPositions :253-260): fp64 on fp32 state, rounded back to fp32
-          if (continued) {
-            float t1[3];
-            newVel(lv, t1);
-            lv[0] = t1[0];
-            lv[1] = t1[1];
-            lv[2] = t1[2];
-          }
-          double sn2 = 0.0, cs2 = 0.0;
-          if (TABLES) {
-            cs2 = s_trig[4 * te + 2];
-            sn2 = s_trig[4 * te + 3];
-          } else if (lv[1] != 0.0f) {
-            sincos(M_PI_2 + th, &sn2, &cs2);
-          }
-          const float nxp = (float)(px + (lv[0] * cs + lv[1] * cs2) * dt);
-          const float nyp = (float)(py + (lv[0] * sn + lv[1] * sn2) * dt);
-          const float ntp = (float)(pth + lv[2] * dt);
           px = nxp;
           py = nyp;
           pth = ntp;
@@ -3248,6 +3305,8 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   if (PREP == 2 && (tid & 63) == 0) {
     const unsigned long long ts3 = wall_clock64();
     atomicAdd(&g_score_stats[16], ts1 - ts0);  // image load, per wave
+    atomicAdd(&g_score_stats[22], ts0a - ts0);  // ... of which: staging of footprint / axis samples up to the first barrier
+    atomicAdd(&g_score_stats[23], ts0b - ts0a); // ... lane mapping up to the second barrier
     atomicAdd(&g_score_stats[17], ts2 - ts1);  // sample setup + rollout, per wave
     atomicAdd(&g_score_stats[18], ts3 - ts2);  // reduction + wait for the slowest wave of the workgroup
     atomicAdd(&g_score_stats[19], 1ull);

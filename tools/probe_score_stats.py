@@ -48,3 +48,4 @@ print("non-last lanes with: can-fail bit %.3e  path bit %.3e  goal bit %.3e  fwd
 w, g = max(v[19], 1), max(v[21], 1)
 print("per wave (10 ns ticks -> us): image load %.2f  setup+rollout %.2f  reduce+wait %.2f | per workgroup residence %.2f us, %d workgroups, %d waves" %
       (v[16] / w / 100, v[17] / w / 100, v[18] / w / 100, v[20] / g / 100, g, w))
+print("image load split: staging + barrier 1 %.2f us, lane mapping + barrier 2 %.2f us, copy + barrier 3 %.2f us" % (v[22] / w / 100, v[23] / w / 100, (v[16] - v[22] - v[23]) / w / 100))
