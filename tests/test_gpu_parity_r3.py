@@ -195,3 +195,59 @@ def test_global_planner_border_cells_stay_in_bounds(nav, orc):
             if res[k].found:
                 assert np.array_equal(nf.path(k).view(np.uint32), path.view(np.uint32))
     nf.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# bench.py runs the fleet as stream groups (4 fleets of 64 robots on 4 HIP streams, their cycles interleaved and their
+# kernels overlapping).  Robots are independent, so the partition and the interleaving must not show in any result: the
+# same 12 robots as ONE fleet and as 3 groups of 4 whose cycles are queued round-robin without waiting for one another
+# give the same winners, costs, counters and master grids - and both equal the oracle.
+# ----------------------------------------------------------------------------------------------
+def test_stream_groups_equal_one_fleet(nav, orc):
+    import bench
+    from navigation_amd import synth
+    n, n_rob, G = 400, 12, 3
+    one, insts, cfg = bench.build_fleet(nav, n_rob, n, seed0=500)
+    g_one = bench.Group(nav, one, insts, seed=9)
+    groups = []
+    for gi in range(G):
+        fl, gi_insts, _ = bench.build_fleet(nav, n_rob // G, n, seed0=500 + gi * (n_rob // G))
+        groups.append(bench.Group(nav, fl, gi_insts, seed=9))
+    # the same pose schedule for a robot whichever fleet it is in
+    for gi, g in enumerate(groups):
+        lo = gi * g.n
+        g.sched.pos = [p[lo:lo + g.n].copy() for p in g_one.sched.pos]
+        for c, st in enumerate(g.states):
+            for i in range(g.n):
+                st[i].pos[:] = list(g_one.states[c][lo + i].pos)
+    res_one, res_grp = [], []
+    m_first = None
+    for k in range(4):
+        g_one.cycle(k)
+        g_one.collect()
+        res_one.append([(r.best_index, r.cost, tuple(r.drive), r.n_valid, r.n_scored) for r in g_one.rbuf])
+        if k == 0:
+            m_first = one.master()
+    for k in range(4):  # queued round-robin, results read one cycle later (the bench's loop)
+        for g in groups:
+            g.cycle(k)
+        cyc = []
+        for g in groups:
+            g.collect()
+            cyc += [(r.best_index, r.cost, tuple(r.drive), r.n_valid, r.n_scored) for r in g.rbuf]
+        res_grp.append(cyc)
+    assert res_one == res_grp
+    m_one = one.master()
+    m_grp = np.concatenate([g.fl.master() for g in groups])
+    assert np.array_equal(m_one, m_grp)
+    # ... and the first cycle (fresh oscillation flags) against the oracle on that cycle's costmap
+    ocfg = orc.DwaConfig(**cfg.as_dict())
+    for i in (0, 5, 11):
+        p = orc.DwaPlanner(m_first[i], synth.RES, 0.0, 0.0, ocfg)
+        p.set_plan()
+        st = g_one.states[0][i]
+        o, _, _, _, _ = p.cycle(np.array(list(st.pos), np.float32), np.array(list(st.vel), np.float32), insts[i]["plan"], synth.FOOTPRINT)
+        assert (res_one[0][i][0], res_one[0][i][3], res_one[0][i][4]) == (o.best_index, o.n_valid, o.n_scored) and abs(res_one[0][i][1] - o.cost) <= 1e-5
+    one.close()
+    for g in groups:
+        g.fl.close()
