@@ -90,15 +90,12 @@ class PoseSchedule:
         self.vel = np.ascontiguousarray(vel, np.float32)
 
 
-_SCANS = {}
-
-
 def cached_scan(synth, ins, cycle):
-    """synth.laser_scan(ins, cycle) as float32, kept per (robot, cycle): the one-stream leg re-uses the groups' clouds."""
-    key = (ins["cells"].ctypes.data, cycle)
-    if key not in _SCANS:
-        _SCANS[key] = np.ascontiguousarray(synth.laser_scan(ins, cycle), np.float32)
-    return _SCANS[key]
+    """synth.laser_scan(ins, cycle) as float32, kept with the robot's own record (the one-stream pre-pass re-uses the groups' clouds)."""
+    scans = ins.setdefault("_scans", {})
+    if cycle not in scans:
+        scans[cycle] = np.ascontiguousarray(synth.laser_scan(ins, cycle), np.float32)
+    return scans[cycle]
 
 
 class Group:

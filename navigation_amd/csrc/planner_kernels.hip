@@ -2426,6 +2426,18 @@ __host__ __device__ inline size_t score_scratch_bytes(int win) { return score_bi
 // AGG: the MapGridCostFunction options DWAPlanner itself never sets - aggregation Sum / Product and a sideways shift
 // (map_grid_cost_function.cpp:75-129) - as navgpu_planner_set_map_grid_options configures them: every live critic looks
 // its own cell up at every point (no screen, no shared cell); the product kernels are compiled without it.
+// n / d for 0 <= n < 2^22, 1 <= d < 2^22: float quotient + one correction step either way (the generic 32-bit division is
+// ~40 vector instructions, and every lane of a scoring workgroup makes two of them)
+__device__ __forceinline__ int divSmall(int n, int d) {
+  int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
+  int r = n - q * d;
+  if (r < 0) {
+    --q;
+    r += d;
+  }
+  if (r >= d) ++q;
+  return q;
+}
 template <bool EXPLICIT, bool TABLES, int THREADS, int PREP = 0, int CHUNK = 12, bool AGG = false>
 __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first, const float* explicit_sample) {
   extern __shared__ __align__(16) uint8_t s_dyn[];
@@ -2798,7 +2810,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   if (TABLES) {
     const int nxy = max(cnt[0] * cnt[1], 1);
     const int li = t_li0 + (int)tid;
-    t_row = li / nxy;            // row within the group = row of the tables in LDS
+    t_row = divSmall(li, nxy);   // row within the group = row of the tables in LDS
     t_r = li - t_row * nxy;      // index of the (vx, vy) pair, x-outer
     t_ith = t_row_base + t_row;
     in_range = n_samples > 0 && t_row < t_rows;
@@ -2817,7 +2829,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       const int nth = cnt[2], nyv = cnt[1];
       int ix, iy, ith;
       if (TABLES) {  // sidx = (ix * nyv + iy) * nth + ith with ith = t_ith: one division instead of two
-        ix = t_r / nyv;
+        ix = divSmall(t_r, nyv);
         iy = t_r - ix * nyv;
         ith = t_ith;
       } else {
