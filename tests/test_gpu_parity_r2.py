@@ -536,11 +536,12 @@ def test_layered_cycles_reference_priority_queue_order(nav, orc):
 
 
 # ----------------------------------------------------------------------------------------------
-# k_bfs_big: the register-resident wavefront for maps beyond k_bfs_wave's reach (up to 1023 x 1024; configs[4]'s
-# 1000 x 1000).  Sizes pick its corner cases: 32 words per row with a ragged last word (no separator lane between the
-# two strips of a wave), 31 words (an idle lane separates them), 24 and 32 rows per lane, a partial last strip.
+# k_bfs_rows2: the register-resident row sweep, two rows per lane, for maps beyond k_bfs_rows' reach (up to 1024 x 1344;
+# configs[4]'s 1000 x 1000).  Sizes pick its corner cases: 32 words per row with a ragged last word and with a full one,
+# fewer words (a scalar row load instead of the 16-byte one), an odd row count (a lane whose second row does not exist),
+# a partial last wave, 12 waves; (1000, 1400) is beyond it (k_bfs_global).
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("nx,ny", [(1000, 1000), (1023, 1024), (992, 800), (700, 650), (993, 641)])
+@pytest.mark.parametrize("nx,ny", [(1000, 1000), (1023, 1024), (992, 800), (700, 650), (993, 641), (1024, 1121), (801, 1344), (1000, 1400), (840, 1009)])
 def test_big_map_wavefronts_match_oracle(nav, orc, nx, ny):
     from navigation_amd import synth
     from test_gpu_parity import _mapgrid_case
