@@ -554,6 +554,11 @@ int navgpu_profile_reset(navgpu_fleet* fleet);
 int navgpu_profile_read(navgpu_fleet* fleet, int32_t kernel, double* total_ms, uint64_t* launches);
 const char* navgpu_kernel_name(int32_t kernel);
 
+/* The floating-point contract, checkable: sin / cos of `n` headings exactly as the scoring kernels evaluate them on `device`
+ * (double `sincos`, the reference's `cos(theta)` / `sin(theta)` of simple_trajectory_generator.cpp:253-258 on the host's
+ * libm).  Host pointers.  tests/ compare the result with the host's libm bit for bit and bound the difference. */
+int navgpu_device_sincos(int32_t device, const double* theta, uint32_t n, double* sin_out, double* cos_out);
+
 /* ------------------------------------------------------------------------------------------ */
 /* navfn::NavFn - global-planner potential expansion and path extraction       */
 /* ------------------------------------------------------------------------------------------ */

@@ -267,6 +267,7 @@ SYMBOLS = [
     ("navgpu_profile_reset", C.c_int, [vp]),
     ("navgpu_profile_read", C.c_int, [vp, i32, C.POINTER(dbl), C.POINTER(C.c_uint64)]),
     ("navgpu_kernel_name", C.c_char_p, [i32]),
+    ("navgpu_device_sincos", C.c_int, [i32, vp, u32, vp, vp]),
 ]
 
 

@@ -226,6 +226,7 @@ struct PoseChunk {
 };
 static_assert(sizeof(PoseChunk) <= 4096, "kernel arguments are limited to 4 KB");
 void launch_stage_poses(const PoseChunk& c, hipStream_t s);
+void launch_sincos(const double* th, uint32_t n, double* sn, double* cs, hipStream_t s);
 size_t bfs_lds_bytes(uint32_t nx, uint32_t ny);
 bool bfs_bounded_applies(const PlannerDev& pl);  // the wavefront kernel launch_bfs picks for this map can stop at the robot's box
 size_t score_table_bytes(const PlannerDev& pl);

@@ -464,6 +464,25 @@ int navgpu_footprint_from_radius(double radius, double* xy16) {  // footprint.cp
   return NAVGPU_OK;
 }
 
+/* the device's sincos over host arrays (the floating-point contract, checkable against the host's libm) */
+int navgpu_device_sincos(int32_t device, const double* theta, uint32_t n, double* sin_out, double* cos_out) {
+  if (!theta || !sin_out || !cos_out) return NAVGPU_ERR_INVALID;
+  if (n == 0) return NAVGPU_OK;
+  HIP_TRY(hipSetDevice(device));
+  double* d = nullptr;
+  HIP_TRY(hipMalloc(&d, (size_t)3 * n * sizeof(double)));
+  int rc = NAVGPU_OK;
+  if (hipMemcpy(d, theta, (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = NAVGPU_ERR_HIP;
+  if (rc == NAVGPU_OK) {
+    launch_sincos(d, n, d + n, d + 2 * (size_t)n, nullptr);
+    if (hipMemcpy(sin_out, d + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(cos_out, d + 2 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = NAVGPU_ERR_HIP;
+  }
+  hipFree(d);
+  return rc;
+}
+
 /* Costmap2DPublisher view of a window of the master grid */
 int navgpu_costmap_export(navgpu_fleet* f, uint32_t instance, uint32_t x0, uint32_t y0, uint32_t xn, uint32_t yn, int8_t* out) {
   if (!f || !out || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;

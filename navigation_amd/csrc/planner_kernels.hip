@@ -3994,6 +3994,15 @@ __global__ __launch_bounds__(64) void k_stage_poses(PoseChunk c) {
 }
 void launch_stage_poses(const PoseChunk& c, hipStream_t s) { hipLaunchKernelGGL(k_stage_poses, dim3(1), dim3(64), 0, s, c); }
 
+// sin / cos of the headings as score_body evaluates them (navgpu_device_sincos: the floating-point contract, checkable)
+__global__ void k_sincos(const double* th, uint32_t n, double* sn, double* cs) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sincos(th[i], &sn[i], &cs[i]);
+}
+void launch_sincos(const double* th, uint32_t n, double* sn, double* cs, hipStream_t s) {
+  hipLaunchKernelGGL(k_sincos, dim3((n + 255) / 256), dim3(256), 0, s, th, n, sn, cs);
+}
+
 #ifdef NAVGPU_BFS_STATS
 extern "C" int navgpu_debug_bfs_stats(unsigned long long* out16, int reset) {
   if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bfs_stats), sizeof(unsigned long long) * 16);

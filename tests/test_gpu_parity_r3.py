@@ -251,3 +251,33 @@ def test_stream_groups_equal_one_fleet(nav, orc):
     one.close()
     for g in groups:
         g.fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# The floating-point contract's one library dependency: the rollout's cos(theta) / sin(theta)
+# (simple_trajectory_generator.cpp:253-258) are the host libm's on the reference and ocml's on the device.  Neither is
+# correctly rounded; both are faithful.  Measured here through navgpu_device_sincos: they never differ by more than one
+# unit in the last place, and do so for about 3 % of the arguments.  A one-ulp change of a double factor moves the next
+# pose - rounded to float - only when the double result lies within ~1e-16 of a float rounding boundary (float spacing:
+# 6e-8 relative), i.e. about 2e-9 of the affected steps, which is why every cost / index comparison of this suite holds
+# bit for bit.
+# ----------------------------------------------------------------------------------------------
+def test_device_sincos_against_host_libm(nav):
+    import ctypes as C
+    import math
+    Lb = nav.lib()
+    rs = np.random.RandomState(7)
+    n = 1 << 17
+    th = np.concatenate([rs.uniform(-2 * math.pi, 2 * math.pi, n).astype(np.float32).astype(np.float64),   # rollout headings are floats
+                         math.pi / 2 + rs.uniform(-math.pi, math.pi, n // 4).astype(np.float32).astype(np.float64),  # M_PI_2 + theta
+                         np.array([0.0, -0.0, math.pi / 2, math.pi, -math.pi, 1e-30, 1e6, -1e6])])
+    sn, cs = np.empty_like(th), np.empty_like(th)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert Lb.navgpu_device_sincos(0, ptr(th), len(th), ptr(sn), ptr(cs)) == 0
+    hs = np.array([math.sin(v) for v in th])
+    hc = np.array([math.cos(v) for v in th])
+    for dev, host in ((sn, hs), (cs, hc)):
+        ulp = np.abs(dev.view(np.int64) - host.view(np.int64))
+        assert ulp.max() <= 1, ulp.max()
+        assert (ulp != 0).mean() < 0.06
+    assert Lb.navgpu_device_sincos(0, None, 4, ptr(sn), ptr(cs)) == -1  # NAVGPU_ERR_INVALID
