@@ -767,7 +767,6 @@ __device__ __forceinline__ void bfsWaveGrid(const PlannerDev& pl, const uint32_t
   const uint32_t* freew = pl.bfs_free + (size_t)inst * ny * W;  // traversable-cell bitmap of the robot's costmap (k_free_bits)
   uint32_t* dist = (which == 0 ? pl.path : (which == 1 ? pl.goal : pl.goal_front)) + (size_t)inst * pl.cells;
   const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
-  const uint32_t unknown_is_obstacle = pl.cfg.allow_unknown != 0 ? 0u : 1u;
   const uint32_t last_mask = (nx & 31) ? ((1u << (nx & 31)) - 1u) : 0xFFFFFFFFu;
   const uint32_t col_mask = (wi + 1 == W) ? last_mask : 0xFFFFFFFFu;
   const bool aligned4 = (nx & 3) == 0;
@@ -2257,7 +2256,6 @@ __global__ __launch_bounds__(1024) void k_bfs_global(PlannerDev pl, uint32_t fir
   const uint8_t* master = pl.master + (size_t)inst * pl.cells_padded;
   uint32_t* dist = (which == 0 ? pl.path : (which == 1 ? pl.goal : pl.goal_front)) + (size_t)inst * pl.cells;
   const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
-  const uint32_t unknown_is_obstacle = pl.cfg.allow_unknown != 0 ? 0u : 1u;
   const uint32_t last_mask = (nx & 31) ? ((1u << (nx & 31)) - 1u) : 0xFFFFFFFFu;
   const uint32_t* freew = pl.bfs_free + (size_t)inst * words;  // k_free_bits (or the extra blocks of k_samples)
   for (uint32_t w = tid; w < words; w += blockDim.x) {
@@ -3240,8 +3238,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           }
 #endif
           if (!screened) {
-          const bool live_obs = en_obs && 1 < first_fail, live_gf = en_gf && 2 < first_fail, live_al = en_al && 3 < first_fail,
-                     live_path = en_path && 4 < first_fail, live_goal = en_goal && 5 < first_fail;
+          const bool live_obs = en_obs && 1 < first_fail;
           // all_free: every cell the footprint can touch is FREE_SPACE -> the step costs exactly 0.
           // Without sum_scores only the LAST point's footprint cost survives (obstacle_cost_function.cpp:
           // cost = f_cost), the earlier points only have to be legal: no failing cell in reach is enough.
@@ -3748,7 +3745,6 @@ __global__ __launch_bounds__(64) void k_select(PlannerDev pl, uint32_t first, ui
   __shared__ float s_lv[kSelectSteps][3];
   __shared__ float s_pth[kSelectSteps];
   __shared__ double s_sc[kSelectSteps][4];
-  __shared__ int s_steps;
   const navgpu_robot_state st = pl.state[inst];
   const int32_t* cnt = pl.axis_count + 4 * inst;
   float sel_vs[3] = {0.f, 0.f, 0.f}, sel_lv0[3] = {0.f, 0.f, 0.f};
