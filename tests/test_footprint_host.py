@@ -61,3 +61,25 @@ def test_footprint_pad_and_circle(L):
         assert out[i, 0] == math.cos(angle) * 0.46 and out[i, 1] == math.sin(angle) * 0.46
     mn, mx = _radii(L, out)
     assert abs(mx - 0.46) < 1e-12 and 0.45 < mn < 0.46
+
+
+def test_reference_footprint_test_expectations(L):
+    """costmap_2d/test/footprint_tests.cpp: what the reference's own tests expect of padFootprint and
+    makeFootprintFromRadius (the parameter-server parsing around them is ROS plumbing, out of scope)."""
+    # padded_footprint_from_string_param (:64-81): footprint [[1, 1], [-1, 1], [-1, -1]], footprint_padding 0.5
+    fp = np.array([[1.0, 1.0], [-1.0, 1.0], [-1.0, -1.0]], np.float64)
+    assert L.navgpu_footprint_pad(fp.ctypes.data, len(fp), 0.5) == 0
+    assert fp.astype(np.float32).tolist() == [[1.5, 1.5], [-1.5, 1.5], [-1.5, -1.5]]
+    # unpadded_footprint_from_string_param (:45-62): padding 0 leaves it alone
+    fp0 = np.array([[1.0, 1.0], [-1.0, 1.0], [-1.0, -1.0]], np.float64)
+    assert L.navgpu_footprint_pad(fp0.ctypes.data, len(fp0), 0.0) == 0
+    assert fp0.tolist() == [[1.0, 1.0], [-1.0, 1.0], [-1.0, -1.0]]
+    # radius_param (:83-99): robot_radius 10 -> 16 points, the first (10, 0), the fifth a quarter turn on: (~0, 10)
+    out = np.zeros((16, 2))
+    assert L.navgpu_footprint_from_radius(10.0, out.ctypes.data) == 0
+    assert np.float32(out[0, 0]) == np.float32(10.0) and np.float32(out[0, 1]) == np.float32(0.0)
+    assert abs(out[4, 0]) < 1e-4 and abs(out[4, 1] - 10.0) < 1e-4
+    # footprint_from_xmlrpc_param (:101-122): [[0.1, 0.1], [-0.1, 0.1], [-0.1, -0.1], [0.1, -0.1]] comes back as given
+    fpx = np.array([[0.1, 0.1], [-0.1, 0.1], [-0.1, -0.1], [0.1, -0.1]], np.float64)
+    assert L.navgpu_footprint_pad(fpx.ctypes.data, len(fpx), 0.0) == 0
+    assert fpx.astype(np.float32).tolist() == np.array([[0.1, 0.1], [-0.1, 0.1], [-0.1, -0.1], [0.1, -0.1]], np.float32).tolist()

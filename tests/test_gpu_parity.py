@@ -197,6 +197,7 @@ def test_reference_inflation_scenarios(nav, orc, ten_by_ten):  # costmap_2d/test
     g.add_observation([[0, 0, MAX_Z]])
     m = g.update()
     assert m[0, 0] == LETHAL and m[0, 1] == INSCRIBED and m[0, 2] == INSCRIBED and m[0, 3] < INSCRIBED and m[1, 1] == INSCRIBED
+    assert count(m, NOINFO) == 0  # testInflationShouldNotCreateUnknowns (inflation_tests.cpp:156-175)
 
 
 def test_costmap_cycles_synthetic_fleet(nav, orc):
