@@ -70,6 +70,7 @@ void launch_stage_poses(const PoseChunk& c, hipStream_t) {
   memcpy(c.state + c.first, c.st, sizeof(navgpu_robot_state) * c.count);
   memcpy(c.bfs_reach + c.first, c.reach, sizeof(uint32_t) * c.count);
 }
+void launch_sincos(const double*, uint32_t, double*, double*, hipStream_t) {}
 size_t bfs_lds_bytes(uint32_t, uint32_t) { return 0; }
 bool bfs_bounded_applies(const PlannerDev&) { return true; }
 size_t score_table_bytes(const PlannerDev&) { return 1024; }
