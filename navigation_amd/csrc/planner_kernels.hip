@@ -3436,7 +3436,14 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
               }
             } else {
               const uint32_t cell = cy * g.nx + cx;
-              if (en_path && 4 < first_fail) {
+              // A point of the window whose path / goal screen bit is clear cannot fail that critic (the bit IS the failure
+              // test, taken from this cycle's grid by the prep launch), and of the distances only the LAST point's survives
+              // (aggregation Last): no look-up.  Points that leave the screened path because an obstacle is near - most of
+              // them - used to wait for two L2 round trips here.
+              const bool last_pt = step == num_steps - 1;
+              const bool look_p = last_pt || !in_w || ((fbw.z >> (lxw & 31)) & 1u);
+              const bool look_g = last_pt || !in_w || ((fbw.w >> (lxw & 31)) & 1u);
+              if (en_path && 4 < first_fail && look_p) {
                 const uint32_t d = dpath[cell];
                 if (d == N_obst) {
                   fail_code = -3.0;
@@ -3447,7 +3454,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
                 } else
                   v_path = d;
               }
-              if (en_goal && 5 < first_fail) {
+              if (en_goal && 5 < first_fail && look_g) {
                 const uint32_t d = dgoal[cell];
                 if (d == N_obst) {
                   fail_code = -3.0;
