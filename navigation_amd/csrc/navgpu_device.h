@@ -23,6 +23,9 @@ constexpr int kCareRows = 128, kCareWords = 4;  // bounded wavefronts: extent of
 #ifndef NAVGPU_SCORE_TAB_LDS_KB
 #define NAVGPU_SCORE_TAB_LDS_KB 14    // first LDS budget tried for a k_score_tab workgroup's image (window + screens + table rows): 3 v_theta rows at configs[2] (26 KB = 9 rows: k_score 0.526 -> 0.506 ms)
 #endif
+#ifndef NAVGPU_SCORE_PREP_THREADS
+#define NAVGPU_SCORE_PREP_THREADS 256  // threads of the workgroup that builds a robot's image (k_score_prep_*): alone 512 is 3 us faster, but beside the other stream groups' kernels its 8 waves and 53 KB wait longer for a CU (0.872 -> 0.862 ms per step)
+#endif
 #ifndef NAVGPU_SCORE_TAB_WAVES
 #define NAVGPU_SCORE_TAB_WAVES 6      // waves per SIMD k_score_tab is compiled for (6: 80 registers)
 #endif

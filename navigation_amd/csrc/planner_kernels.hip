@@ -3575,7 +3575,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
 // three entry points over the same body: the table variant is compiled for 6 waves/SIMD (80 VGPRs) in 256-thread
 // workgroups whose image (window + screens + the v_theta rows of their row group) stays below 26 KB: 6 per CU = 24 waves
 constexpr int kScoreThreadsTab = NAVGPU_SCORE_TAB_THREADS;
-constexpr int kScorePrepThreads = 512;  // the workgroup that builds a robot's image
+constexpr int kScorePrepThreads = NAVGPU_SCORE_PREP_THREADS;  // the workgroup that builds a robot's image
 template <int CHUNK>
 __global__ __launch_bounds__(kScoreThreadsTab, NAVGPU_SCORE_TAB_WAVES) void k_score_tab(PlannerDev pl, uint32_t first, const float* explicit_sample) {
   score_body<false, true, kScoreThreadsTab, 2, CHUNK>(pl, first, explicit_sample);
