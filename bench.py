@@ -135,6 +135,7 @@ class Group:
         self.rview = np.frombuffer(self.rbuf, dtype=np.dtype(PlanResult))
         self.scored = 0      # trajectories scored by the cycles whose results have been read
         self.pending = False  # a cycle is queued whose results have not been read yet
+        self.depth = 1       # cycles in flight on the stream (set_depth)
         self.h2d_bytes = self.poses_h.nbytes + self.scans[0][1].nbytes + self.plans_pk.nbytes + self.n * (56 + 32)
 
     def collect(self):
@@ -144,9 +145,17 @@ class Group:
             self.scored += int(self.rview["n_scored"].sum())
             self.pending = False
 
+    def set_depth(self, depth):
+        """Cycles in flight on the group's stream (navgpu_planner_set_cycles_in_flight): with 2, cycle k is handed over and
+        queued BEFORE the results of cycle k - 1 are read, so the stream goes straight from one cycle into the next."""
+        self.collect()
+        self.fl.set_cycles_in_flight(depth)
+        self.depth = depth
+
     def cycle(self, k, restage=True):
         """One control cycle: results of the previous one, hand over cycle k's inputs, queue updateMap + findBestPath."""
-        self.collect()
+        if self.depth < 2:
+            self.collect()
         if restage:
             arr, pts = self.scans[k % SCAN_CYCLES]
             self.fl.stage_observations_raw(self.poses_h, arr, self.n, pts)
@@ -155,6 +164,9 @@ class Group:
             self.fl.stage_poses(self.sched.pos[k % len(self.sched.pos)], self.sched.vel)
         self.fl.update_map()
         self.fl.planner_cycle()
+        if self.depth >= 2 and self.pending:  # cycle k - 1's results, while cycle k runs
+            self.fl.results_previous_into(self.rbuf)
+            self.scored += int(self.rview["n_scored"].sum())
         self.pending = True
 
 
@@ -454,6 +466,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--instances", type=int, default=256, help="robot instances per GPU")
     ap.add_argument("--groups", type=int, default=4, help="independent groups (= HIP streams) the rank's fleet runs as; 1 = one stream, serial")
+    ap.add_argument("--cycles-in-flight", type=int, default=1, choices=[1, 2],
+                    help="2: a group's cycle k + 1 is handed over and queued while its cycle k runs (results of k read after that); "
+                         "1: results of cycle k are read before cycle k + 1 is handed over (the stream idles meanwhile)")
     ap.add_argument("--total-instances", type=int, default=0,
                     help="strong scaling (SURVEY 8e: 2048 robots over the node): this many robots in all, split over the ranks by "
                          "navigation_amd.sharding.shard_range; 0 = --instances per GPU (weak scaling, the contract workload)")
@@ -517,6 +532,11 @@ def main():
             fl, gi_insts, cfg = build_fleet(nav, gn, n_cells, seed0=seed0 + g0, device=local_rank, vs=vs, footprint=args.footprint)
         groups.append(Group(nav, fl, gi_insts, seed=4242 + rank * 64 + gi, stub=stub))
         insts += gi_insts
+
+    depth = 1 if stub else args.cycles_in_flight
+    if depth > 1:
+        for g in groups:
+            g.set_depth(depth)
 
     def sync_all():
         for g in groups:
@@ -682,9 +702,9 @@ def main():
                                    f"velocity samples, 20 sim steps, a NEW LaserScan (720 beams, 3 moving discs) every cycle; "
                                    + (f"{args.total_instances} instances in all, split over the ranks (strong scaling)" if args.total_instances
                                       else f"N GPUs = N x {n_inst} instances (N=8 is configs[3])"),
-                       "instances_per_gpu": n_inst, "groups_per_gpu": G, "costmap": f"{n_cells}x{n_cells}@0.05", "vsamples": "x".join(str(v) for v in vs),
+                       "instances_per_gpu": n_inst, "groups_per_gpu": G, "cycles_in_flight_per_group": depth, "costmap": f"{n_cells}x{n_cells}@0.05", "vsamples": "x".join(str(v) for v in vs),
                        "sim_steps": T_STEPS, "critics": "oscillation+obstacle+goal_front+alignment+path+goal",
-                       "parallelism": f"fleet-shard x{world}, {G} stream groups per GPU"},
+                       "parallelism": f"fleet-shard x{world}, {G} stream groups per GPU x {depth} cycle(s) in flight each"},
             "value_is": "SURVEY 8(d)'s protocol: every timed cycle hands over its own new scan cloud, pose / velocity and plan from host memory "
                         f"(H2D, {sum(g.h2d_bytes for g in groups)} B per step) and reads its results back (D2H); costmaps resident.  The transfers of one "
                         "group hide behind the other groups' kernels; resident_inputs is the same loop without them",

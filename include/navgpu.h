@@ -355,6 +355,17 @@ int navgpu_planner_wavefront_levels(navgpu_fleet* fleet, uint32_t first, uint32_
  * (boxes = count x 4); the whole map for an instance whose grids were searched whole */
 int navgpu_planner_wavefront_boxes(navgpu_fleet* fleet, uint32_t first, uint32_t count, int32_t* boxes);
 int navgpu_planner_results(navgpu_fleet* fleet, uint32_t first, uint32_t count, navgpu_plan_result* results);
+/* Two control cycles in flight on the fleet's stream (no counterpart in the reference, whose cycle is a blocking call:
+ * move_base.cpp:947 runs computeVelocityCommands to completion; an option of this library for callers that drive many
+ * robots).  cycles = 2: navgpu_costmap_stage / navgpu_planner_stage of cycle k + 1 wait only until the copies out of
+ * their pinned mirrors have run (a marker behind them), not for the stream, so cycle k + 1 can be handed over and queued
+ * while cycle k runs; navgpu_planner_cycle then writes its results into the slot the cycle before it did not use, and
+ * navgpu_planner_results_previous returns the results of the cycle BEFORE the latest queued one as soon as that cycle
+ * has finished (NAVGPU_ERR_STATE when there is none).  navgpu_planner_results keeps its meaning: the latest queued cycle,
+ * after the stream has drained.  With cycles = 2 a cycle covers the whole fleet (NAVGPU_ERR_STATE for a sub-range: the
+ * result slot alternates per call).  cycles = 1 (default): every call as before.  The call itself drains the stream. */
+int navgpu_planner_set_cycles_in_flight(navgpu_fleet* fleet, int32_t cycles);
+int navgpu_planner_results_previous(navgpu_fleet* fleet, uint32_t first, uint32_t count, navgpu_plan_result* results);
 /* winning trajectory of one instance: xyth = n_points x {x,y,theta}; returns n_points or <0 */
 int navgpu_planner_trajectory(navgpu_fleet* fleet, uint32_t instance, double* xyth, uint32_t capacity_points);
 /* every sample slot of one instance (needs keep_sample_costs): total cost with all critics summed

@@ -229,6 +229,8 @@ SYMBOLS = [
     ("navgpu_planner_wavefront_levels", C.c_int, [vp, u32, u32, vp]),
     ("navgpu_planner_wavefront_boxes", C.c_int, [vp, u32, u32, vp]),
     ("navgpu_planner_results", C.c_int, [vp, u32, u32, vp]),
+    ("navgpu_planner_set_cycles_in_flight", C.c_int, [vp, C.c_int32]),
+    ("navgpu_planner_results_previous", C.c_int, [vp, u32, u32, vp]),
     ("navgpu_planner_trajectory", C.c_int, [vp, u32, vp, u32]),
     ("navgpu_planner_samples", C.c_int, [vp, u32, vp, vp, vp, u32]),
     ("navgpu_planner_check_trajectory", C.c_int, [vp, u32, vp, C.POINTER(i32)]),

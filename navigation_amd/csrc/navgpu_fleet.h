@@ -84,8 +84,22 @@ struct navgpu_fleet {
     for (uint32_t i = first; i < first + count && i < inputs_gen.size(); ++i) ++inputs_gen[i];
   }
   navgpu_robot_state* hp_state = nullptr;
-  navgpu_plan_result* hp_result = nullptr;
+  navgpu_plan_result* hp_result = nullptr;      // [2][n]: the slot a cycle writes alternates while two cycles are in flight
   bool hp_dma_pending = false;  // a full stage's copies out of hp_state / hp_front / hp_align / hp_reach may still be queued
+  // Two control cycles in flight on the stream (navgpu_planner_set_cycles_in_flight(f, 2)): cycle k + 1 is handed over and
+  // queued while cycle k still runs, so the stream never idles between the end of a cycle and the host's next hand-over.
+  // What has to be known for that is finer than "the stream has drained": that the copies out of the pinned mirrors have
+  // run (ev_cm_h2d / ev_pl_h2d, recorded behind them) and that ONE cycle's results are in place (ev_cycle[slot], recorded
+  // behind its k_select).
+  int cycles_in_flight = 1;
+  int res_slot = 0;                             // slot of hp_result the latest queued cycle writes
+  hipEvent_t ev_cycle[2] = {nullptr, nullptr}, ev_cm_h2d = nullptr, ev_pl_h2d = nullptr;
+  bool ev_cycle_set[2] = {false, false}, ev_cm_set = false, ev_pl_set = false;
+  // the pinned mirrors are free again: the whole stream with one cycle in flight, the marker behind their copies with two
+  hipError_t waitMirrors(hipEvent_t ev, bool set) {
+    if (cycles_in_flight < 2) return navgpu::waitStream(stream);
+    return set ? hipEventSynchronize(ev) : hipSuccess;
+  }
   // DWAPlannerROS mirror (navgpu_local_planner_*): per-instance controller state, host only
   struct LocalPlannerState {
     std::vector<double> plan;      // stored global plan, (x, y, yaw) triples in the plan's frame (prunePlan shrinks it)

@@ -153,7 +153,7 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   }
   AP(f->hp_used, n);
   AP(f->hp_shift, (size_t)n * 2);
-  AP(f->hp_result, n);
+  AP(f->hp_result, (size_t)n * 2);  // two slots: navgpu_planner_set_cycles_in_flight
   f->pl.result = f->hp_result;  // k_select writes results straight into pinned host memory (72 B per robot)
 #undef AP
   A(f->d_bounds_tmp, (size_t)n * 4);
@@ -267,6 +267,8 @@ int navgpu_fleet_destroy(navgpu_fleet* f) {
     hipEventDestroy(e.a);
     hipEventDestroy(e.b);
   }
+  for (hipEvent_t e : {f->ev_cycle[0], f->ev_cycle[1], f->ev_cm_h2d, f->ev_pl_h2d})
+    if (e) hipEventDestroy(e);
   for (void* p : f->allocs) hipFree(p);
   for (void* p : f->pinned) hipHostFree(p);
   if (f->stream) hipStreamDestroy(f->stream);
@@ -800,7 +802,7 @@ int navgpu_costmap_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
   CostmapDev& cm = f->cm;
   if (f->desc.rolling_window && f->shift_pending) return NAVGPU_ERR_STATE;  // previous stage not consumed by an update yet
   if (f->desc.rolling_window) f->touchInputs(first, count);  // the origins move now
-  HIP_TRY(waitStream(f->stream));  // the pinned mirrors may still feed an earlier copy
+  HIP_TRY(f->waitMirrors(f->ev_cm_h2d, f->ev_cm_set));  // the pinned mirrors may still feed an earlier copy
   for (uint32_t li = 0; li < count; ++li) f->hp_cnt[first + li] = f->hp_used[first + li] = 0;
   for (uint32_t k = 0; k < n_obs; ++k) {
     const navgpu_observation& o = obs[k];
@@ -866,6 +868,10 @@ int navgpu_costmap_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
     HIP_TRY(hipMemcpyAsync(cm.points + (size_t)first * cm.max_points * 3, f->hp_pts + (size_t)first * cm.max_points * 3, sizeof(float) * 3 * (size_t)count * cm.max_points, hipMemcpyHostToDevice, f->stream));
     HIP_TRY(hipMemcpyAsync(cm.fp_world + (size_t)first * kMaxFootprint * 2, f->hp_fpw + (size_t)first * kMaxFootprint * 2, sizeof(double) * 2 * kMaxFootprint * (size_t)count, hipMemcpyHostToDevice, f->stream));
     HIP_TRY(hipMemcpyAsync(cm.fp_n + first, f->hp_fpn + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
+  }
+  if (f->cycles_in_flight > 1) {
+    HIP_TRY(hipEventRecord(f->ev_cm_h2d, f->stream));
+    f->ev_cm_set = true;
   }
   return NAVGPU_OK;  // copies stay in flight on the fleet's stream; the kernels are ordered behind them
 }
@@ -1171,7 +1177,7 @@ int navgpu_planner_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
     if (s.plan_count > pl.max_plan) return NAVGPU_ERR_CAPACITY;
     if ((uint64_t)s.plan_first + s.plan_count > n_plan_total) return NAVGPU_ERR_INVALID;
   }
-  HIP_TRY(waitStream(f->stream));  // the pinned mirrors may still feed an earlier copy
+  HIP_TRY(f->waitMirrors(f->ev_pl_h2d, f->ev_pl_set));  // the pinned mirrors may still feed an earlier copy
   for (uint32_t li = 0; li < count; ++li) {
     const uint32_t i = first + li;
     const navgpu_robot_state& s = states[li];
@@ -1198,6 +1204,10 @@ int navgpu_planner_stage(navgpu_fleet* f, uint32_t first, uint32_t count, const 
     HIP_TRY(hipMemcpyAsync(pl.align_on + first, f->hp_align + first, sizeof(int32_t) * count, hipMemcpyHostToDevice, f->stream));
     HIP_TRY(hipMemcpyAsync(pl.bfs_reach + first, f->hp_reach + first, sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
   }
+  if (f->cycles_in_flight > 1) {
+    HIP_TRY(hipEventRecord(f->ev_pl_h2d, f->stream));
+    f->ev_pl_set = true;
+  }
   f->planner_staged = true;
   f->hp_dma_pending = true;
   return NAVGPU_OK;
@@ -1219,7 +1229,7 @@ int navgpu_planner_stage_poses(navgpu_fleet* f, uint32_t first, uint32_t count, 
       return NAVGPU_ERR_STATE;
     }
   if (f->hp_dma_pending) {  // the host mirrors written below may still feed a full stage's copies
-    HIP_TRY(waitStream(f->stream));
+    HIP_TRY(f->waitMirrors(f->ev_pl_h2d, f->ev_pl_set));
     f->hp_dma_pending = false;
   }
   for (uint32_t li = 0; li < count; ++li) {
@@ -1291,6 +1301,11 @@ int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
   FleetGuard guard_(f);
   if (!f->planner_configured || !f->planner_staged) return NAVGPU_ERR_STATE;
   PlannerDev& pl = f->pl;
+  if (f->cycles_in_flight > 1) {  // the cycle before this one may still run: its results stay where they are
+    if (first != 0 || count != f->desc.n_instances) return NAVGPU_ERR_STATE;
+    f->res_slot ^= 1;
+    pl.result = f->hp_result + (size_t)f->res_slot * f->desc.n_instances;
+  }
   pl.bfs_bounded = 1;  // per robot: bfs_reach (0 = whole grid)
   int n_whole = 0;  // robots that search their whole grids this cycle (near the end of their plan, off the map, bounding off)
   for (uint32_t i = first; i < first + count; ++i) {
@@ -1313,7 +1328,38 @@ int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
   uint32_t n_blocks = 0;
   PROFILED(f, NAVGPU_K_SCORE, n_blocks = launch_score(pl, first, count, nullptr, f->stream));
   PROFILED(f, NAVGPU_K_SELECT, launch_select(pl, first, count, n_blocks, f->stream));
+  if (f->cycles_in_flight > 1) {
+    HIP_TRY(hipEventRecord(f->ev_cycle[f->res_slot], f->stream));
+    f->ev_cycle_set[f->res_slot] = true;
+  }
   return checkLaunch();
+}
+
+int navgpu_planner_set_cycles_in_flight(navgpu_fleet* f, int32_t cycles) {
+  if (!f || cycles < 1 || cycles > 2) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
+  HIP_TRY(waitStream(f->stream));  // nothing in flight across the switch
+  if (cycles > 1)
+    for (hipEvent_t* e : {&f->ev_cycle[0], &f->ev_cycle[1], &f->ev_cm_h2d, &f->ev_pl_h2d})
+      if (!*e) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  if (cycles == 1 && f->res_slot) {  // back to slot 0, the latest results with it
+    memcpy(f->hp_result, f->hp_result + f->desc.n_instances, sizeof(navgpu_plan_result) * f->desc.n_instances);
+    f->res_slot = 0;
+    f->pl.result = f->hp_result;
+  }
+  f->ev_cycle_set[0] = f->ev_cycle_set[1] = f->ev_cm_set = f->ev_pl_set = false;
+  f->cycles_in_flight = cycles;
+  return NAVGPU_OK;
+}
+
+int navgpu_planner_results_previous(navgpu_fleet* f, uint32_t first, uint32_t count, navgpu_plan_result* results) {
+  if (!f || !results || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
+  const int slot = f->res_slot ^ 1;
+  if (f->cycles_in_flight < 2 || !f->ev_cycle_set[slot]) return NAVGPU_ERR_STATE;  // no cycle before the latest one
+  HIP_TRY(hipEventSynchronize(f->ev_cycle[slot]));
+  memcpy(results, f->hp_result + (size_t)slot * f->desc.n_instances + first, sizeof(navgpu_plan_result) * count);
+  return NAVGPU_OK;
 }
 
 int navgpu_planner_results(navgpu_fleet* f, uint32_t first, uint32_t count, navgpu_plan_result* results) {
@@ -1326,7 +1372,7 @@ int navgpu_planner_results(navgpu_fleet* f, uint32_t first, uint32_t count, navg
   if (dbg) clock_gettime(CLOCK_MONOTONIC, &t0);
   HIP_TRY(waitStream(f->stream));
   if (dbg) clock_gettime(CLOCK_MONOTONIC, &t1);
-  memcpy(results, f->hp_result + first, sizeof(navgpu_plan_result) * count);
+  memcpy(results, f->hp_result + (size_t)f->res_slot * f->desc.n_instances + first, sizeof(navgpu_plan_result) * count);
   if (dbg) {
     clock_gettime(CLOCK_MONOTONIC, &t2);
     fprintf(stderr, "results: wait %.3f ms, memcpy %.3f ms\n", (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6,
@@ -1339,7 +1385,7 @@ int navgpu_planner_trajectory(navgpu_fleet* f, uint32_t instance, double* xyth, 
   if (!f || !xyth || instance >= f->desc.n_instances) return NAVGPU_ERR_INVALID;
   FleetGuard guard_(f);
   HIP_TRY(waitStream(f->stream));
-  const navgpu_plan_result r = f->hp_result[instance];
+  const navgpu_plan_result r = f->hp_result[(size_t)f->res_slot * f->desc.n_instances + instance];
   uint32_t n = std::min<uint32_t>(r.n_points > 0 ? r.n_points : 0, cap);
   if (n) {
     HIP_TRY(hipMemcpyAsync(xyth, f->pl.traj + (size_t)instance * f->pl.max_sim_steps * 3, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, f->stream));

@@ -295,6 +295,15 @@ class Fleet:
         check(self.L.navgpu_planner_results(self.h, first, len(buf), C.cast(buf, C.c_void_p)), "planner_results")
         return buf
 
+    def set_cycles_in_flight(self, cycles):
+        """navgpu_planner_set_cycles_in_flight: 2 = cycle k + 1 is handed over and queued while cycle k runs."""
+        check(self.L.navgpu_planner_set_cycles_in_flight(self.h, int(cycles)), "set_cycles_in_flight")
+
+    def results_previous_into(self, buf, first=0):
+        """Results of the cycle before the latest queued one (two cycles in flight), into a (PlanResult * count) array."""
+        check(self.L.navgpu_planner_results_previous(self.h, first, len(buf), C.cast(buf, C.c_void_p)), "planner_results_previous")
+        return buf
+
     def find_best_path(self, pos, vel, plans, first=0):
         pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
         self.stage_planner(pos, vel, plans, first)

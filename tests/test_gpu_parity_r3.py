@@ -254,6 +254,65 @@ def test_stream_groups_equal_one_fleet(nav, orc):
 
 
 # ----------------------------------------------------------------------------------------------
+# Two cycles in flight on a stream (navgpu_planner_set_cycles_in_flight): cycle k + 1 is handed over (new scan, pose, plan)
+# and queued while cycle k runs, cycle k's results are read afterwards.  Every cycle must return exactly what the same
+# cycle returns when it is run to completion before the next hand-over; the first cycle is checked against the oracle.
+# ----------------------------------------------------------------------------------------------
+def test_two_cycles_in_flight_equal_one(nav, orc):
+    import bench
+    from navigation_amd import synth
+    from navigation_amd._lib import NavgpuError as NavGpuError
+    n, n_rob, n_cyc = 400, 8, 7
+    key = lambda rbuf: [(r.best_index, r.cost, tuple(r.drive), r.n_valid, r.n_scored) for r in rbuf]
+    a, insts, cfg = bench.build_fleet(nav, n_rob, n, seed0=640)
+    ga = bench.Group(nav, a, insts, seed=3)
+    res_a, m_first = [], None
+    for k in range(n_cyc):
+        ga.cycle(k)
+        ga.collect()
+        res_a.append(key(ga.rbuf))
+        if k == 0:
+            m_first = a.master()
+    b, insts_b, _ = bench.build_fleet(nav, n_rob, n, seed0=640)
+    gb = bench.Group(nav, b, insts_b, seed=3)
+    with pytest.raises(NavGpuError):  # one cycle in flight: there is no "previous" slot
+        b.results_previous_into(gb.rbuf)
+    gb.set_depth(2)
+    with pytest.raises(NavGpuError):  # no cycle queued yet
+        b.results_previous_into(gb.rbuf)
+    res_b = []
+    for k in range(n_cyc):
+        gb.pending_before = gb.pending
+        gb.cycle(k)            # queues cycle k, then reads cycle k - 1 into rbuf
+        if gb.pending_before:
+            res_b.append(key(gb.rbuf))
+    with pytest.raises(NavGpuError):  # a sub-range cycle cannot alternate the result slot
+        b.planner_cycle(0, 1)
+    gb.collect()               # the last cycle: navgpu_planner_results = the latest queued cycle
+    res_b.append(key(gb.rbuf))
+    assert res_a == res_b
+    assert ga.scored == gb.scored
+    assert np.array_equal(a.master(), b.master())
+    # back to one cycle in flight: the latest results stay readable, the next cycle behaves as before
+    gb.set_depth(1)
+    assert key(b.results_into(gb.rbuf)) == res_a[-1]
+    ga.cycle(n_cyc)
+    ga.collect()
+    gb.cycle(n_cyc)
+    gb.collect()
+    assert key(ga.rbuf) == key(gb.rbuf)
+    ocfg = orc.DwaConfig(**cfg.as_dict())
+    for i in (0, 3, 7):
+        p = orc.DwaPlanner(m_first[i], synth.RES, 0.0, 0.0, ocfg)
+        p.set_plan()
+        st = ga.states[0][i]
+        o, _, _, _, _ = p.cycle(np.array(list(st.pos), np.float32), np.array(list(st.vel), np.float32), insts[i]["plan"], synth.FOOTPRINT)
+        assert (res_b[0][i][0], res_b[0][i][3], res_b[0][i][4]) == (o.best_index, o.n_valid, o.n_scored) and abs(res_b[0][i][1] - o.cost) <= 1e-5
+    a.close()
+    b.close()
+
+
+# ----------------------------------------------------------------------------------------------
 # The floating-point contract's one library dependency: the rollout's cos(theta) / sin(theta)
 # (simple_trajectory_generator.cpp:253-258) are the host libm's on the reference and ocml's on the device.  Neither is
 # correctly rounded; both are faithful.  Measured here through navgpu_device_sincos: they never differ by more than one
