@@ -601,6 +601,17 @@ int navgpu_navfn_set_costmap_from_fleet(navgpu_navfn* nav, uint32_t first, uint3
  * navfn_ros.cpp:270-281: the potential is grown from the robot.) */
 int navgpu_navfn_plan(navgpu_navfn* nav, uint32_t first, uint32_t count, const int32_t* goals_xy, const int32_t* starts_xy, int32_t astar,
                       int32_t at_start, navgpu_navfn_result* results);
+/* The same call as a device algorithm (no counterpart in the reference): NavFn::updateCell's update rule (navfn.cpp:466-535,
+ * same float / double arithmetic) relaxed to its fixed point by 32 x 32 tiles in LDS, round by round, instead of walked
+ * through the three priority buffers on one lane; at_start stops once the start cell and everything below its potential
+ * is final (the counterpart of :692-694).  The potentials are those the reference's process converges to where it is
+ * allowed to finish: <= the reference's everywhere (its 10 000-entry buffers drop cells, its push tests skip updates, its
+ * early stop leaves the last block half done), equal along most of the path; calcPath (the same code) then gives a path
+ * within a fraction of a cell of the reference's (tests/test_navfn.py: Hausdorff distance <= 1 cell on the reference's
+ * willow_costmap searches).  Results do not depend on scheduling (rounds are Jacobi across tiles, tiles are swept
+ * red / black).  results[k].cycles = rounds run.  Dijkstra only.  The bit-exact mode stays navgpu_navfn_plan. */
+int navgpu_navfn_plan_wavefront(navgpu_navfn* nav, uint32_t first, uint32_t count, const int32_t* goals_xy, const int32_t* starts_xy,
+                                int32_t at_start, navgpu_navfn_result* results);
 /* replaces: NavFn::getPathX / getPathY / getPathLen: xy = up to capacity_points x {x, y}; returns the path length */
 int navgpu_navfn_path(navgpu_navfn* nav, uint32_t plan, float* xy, uint32_t capacity_points);
 /* NavFn::potarr of one plan (ny x nx floats, POT_HIGH = 1e10 where unassigned) */

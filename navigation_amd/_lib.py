@@ -257,6 +257,7 @@ SYMBOLS = [
     ("navgpu_navfn_set_costmap", C.c_int, [vp, u32, u32, vp, i32, i32, i32]),
     ("navgpu_navfn_set_costmap_from_fleet", C.c_int, [vp, u32, u32, vp, u32, i32]),
     ("navgpu_navfn_plan", C.c_int, [vp, u32, u32, vp, vp, i32, i32, vp]),
+    ("navgpu_navfn_plan_wavefront", C.c_int, [vp, u32, u32, vp, vp, i32, vp]),
     ("navgpu_global_planner_plan", C.c_int, [vp, u32, u32, C.POINTER(GlobalPlannerParams), vp, vp, vp, vp]),
     ("navgpu_navfn_path", C.c_int, [vp, u32, vp, u32]),
     ("navgpu_navfn_potential", C.c_int, [vp, u32, vp]),

@@ -56,6 +56,110 @@ __global__ __launch_bounds__(256) void k_navfn_costmap(NavfnDev nv, uint32_t fir
   nv.costarr[(size_t)plan * nv.ns_padded + n] = out;
 }
 
+// NavFn::calcPath / gradCell (:811-1056) over one plan's potential array, one lane: the interpolated gradient descent from the
+// start cell, its result record included.  Shared by the two expansions (reference order: k_navfn_plan; tiled wavefront:
+// k_navfn_wf_path).
+__device__ void navfnCalcPath(const NavfnDev& nv, uint32_t plan, const float* potarr, int goal0, int goal1, int start0, int start1, int n_max,
+                              int cycle) {
+  const int nx = nv.nx, ny = nv.ny, ns = nv.ns;
+  float* gradx = nv.gradx + (size_t)plan * nv.ns_padded;
+  float* grady = nv.grady + (size_t)plan * nv.ns_padded;
+  float* pathx = nv.path + (size_t)plan * 2 * nv.path_cap;
+  float* pathy = pathx + nv.path_cap;
+  const int startCell = start1 * nx + start0;
+  // ---- gradCell (:1001-1056)
+  auto gradCell = [&](int n) {
+    if (gradx[n] + grady[n] > 0.0) return;
+    if (n < nx || n > ns - nx) return;
+    const float cv = potarr[n];
+    float dx = 0.0f, dy = 0.0f;
+    if (cv >= kPotHigh) {
+      if (potarr[n - 1] < kPotHigh)
+        dx = -kCostObs;
+      else if (potarr[n + 1] < kPotHigh)
+        dx = kCostObs;
+      if (potarr[n - nx] < kPotHigh)
+        dy = -kCostObs;
+      else if (potarr[nx + 1] < kPotHigh)  // as written in the reference (:1020)
+        dy = kCostObs;
+    } else {
+      if (potarr[n - 1] < kPotHigh) dx += potarr[n - 1] - cv;
+      if (potarr[n + 1] < kPotHigh) dx += cv - potarr[n + 1];
+      if (potarr[n - nx] < kPotHigh) dy += potarr[n - nx] - cv;
+      if (potarr[n + nx] < kPotHigh) dy += cv - potarr[n + nx];
+    }
+    float norm = (float)hypot((double)dx, (double)dy);
+    if (norm > 0) {
+      norm = (float)(1.0 / norm);
+      gradx[n] = norm * dx;
+      grady[n] = norm * dy;
+    }
+  };
+  // ---- calcPath (:811-985)
+  const float pathStep = 0.5f;
+  int stc = startCell, npath = 0, found = 0;
+  float dx = 0, dy = 0;
+  for (int i = 0; i < n_max && i < (int)nv.path_cap; i++) {
+    const int nearest_point = max(0, min(nx * ny - 1, stc + (int)round((double)dx) + (int)(nx * round((double)dy))));
+    if (potarr[nearest_point] < (float)kCostNeutral) {
+      pathx[npath] = (float)goal0;
+      pathy[npath] = (float)goal1;
+      ++npath;
+      found = 1;
+      break;
+    }
+    if (stc < nx || stc > ns - nx) break;  // would be out of bounds
+    pathx[npath] = (float)(stc % nx) + dx;
+    pathy[npath] = (float)(stc / nx) + dy;
+    npath++;
+    bool oscillation_detected = false;
+    if (npath > 2 && pathx[npath - 1] == pathx[npath - 3] && pathy[npath - 1] == pathy[npath - 3]) oscillation_detected = true;
+    const int stcnx = stc + nx, stcpx = stc - nx;
+    if (potarr[stc] >= kPotHigh || potarr[stc + 1] >= kPotHigh || potarr[stc - 1] >= kPotHigh || potarr[stcnx] >= kPotHigh ||
+        potarr[stcnx + 1] >= kPotHigh || potarr[stcnx - 1] >= kPotHigh || potarr[stcpx] >= kPotHigh || potarr[stcpx + 1] >= kPotHigh ||
+        potarr[stcpx - 1] >= kPotHigh || oscillation_detected) {
+      // potential-function boundary: follow the grid to the lowest of the eight neighbours (:893-925; minp is an int there)
+      int minc = stc;
+      int minp = truncX86(potarr[stc]);
+      const int nb[8] = {stcpx - 1, stcpx, stcpx + 1, stc - 1, stc + 1, stcnx - 1, stcnx, stcnx + 1};
+      for (int q = 0; q < 8; ++q)
+        if (potarr[nb[q]] < (float)minp) {
+          minp = (int)potarr[nb[q]];
+          minc = nb[q];
+        }
+      stc = minc;
+      dx = 0;
+      dy = 0;
+      if (potarr[stc] >= kPotHigh) break;
+    } else {
+      gradCell(stc);
+      gradCell(stc + 1);
+      gradCell(stcnx);
+      gradCell(stcnx + 1);
+      const float x1 = (float)((1.0 - dx) * gradx[stc] + dx * gradx[stc + 1]);
+      const float x2 = (float)((1.0 - dx) * gradx[stcnx] + dx * gradx[stcnx + 1]);
+      const float x = (float)((1.0 - dy) * x1 + dy * x2);
+      const float y1 = (float)((1.0 - dx) * grady[stc] + dx * grady[stc + 1]);
+      const float y2 = (float)((1.0 - dx) * grady[stcnx] + dx * grady[stcnx + 1]);
+      const float y = (float)((1.0 - dy) * y1 + dy * y2);
+      if (x == 0.0 && y == 0.0) break;  // zero gradient
+      const float ss = (float)(pathStep / hypot((double)x, (double)y));
+      dx += x * ss;
+      dy += y * ss;
+      if (dx > 1.0) { stc++; dx = (float)(dx - 1.0); }
+      if (dx < -1.0) { stc--; dx = (float)(dx + 1.0); }
+      if (dy > 1.0) { stc += nx; dy = (float)(dy - 1.0); }
+      if (dy < -1.0) { stc -= nx; dy = (float)(dy + 1.0); }
+    }
+  }
+  navgpu_navfn_result r;
+  r.found = found;
+  r.path_length = found ? npath : 0;
+  r.cycles = cycle;
+  r.start_potential = potarr[startCell];
+  nv.results[plan] = r;
+}
+
 __global__ __launch_bounds__(256) void k_navfn_plan(NavfnDev nv, uint32_t first, const int32_t* goals, const int32_t* starts, int astar,
                                                     int at_start) {
   const uint32_t plan = first + blockIdx.x;
@@ -65,8 +169,6 @@ __global__ __launch_bounds__(256) void k_navfn_plan(NavfnDev nv, uint32_t first,
   float* potarr = nv.potarr + (size_t)plan * nv.ns_padded;
   float* gradx = nv.gradx + (size_t)plan * nv.ns_padded;
   float* grady = nv.grady + (size_t)plan * nv.ns_padded;
-  float* pathx = nv.path + (size_t)plan * 2 * nv.path_cap;
-  float* pathy = pathx + nv.path_cap;
   const int goal0 = goals[2 * blockIdx.x], goal1 = goals[2 * blockIdx.x + 1];
   const int start0 = starts[2 * blockIdx.x], start1 = starts[2 * blockIdx.x + 1];
   // ---- setupNavFn(keepit = true) (:379-440), all lanes
@@ -188,81 +290,323 @@ __global__ __launch_bounds__(256) void k_navfn_plan(NavfnDev nv, uint32_t first,
     if (astar || at_start)
       if (potarr[startCell] < kPotHigh) break;
   }
-  // ---- gradCell (:1001-1056)
-  auto gradCell = [&](int n) {
-    if (gradx[n] + grady[n] > 0.0) return;
-    if (n < nx || n > ns - nx) return;
-    const float cv = potarr[n];
-    float dx = 0.0f, dy = 0.0f;
-    if (cv >= kPotHigh) {
-      if (potarr[n - 1] < kPotHigh)
-        dx = -kCostObs;
-      else if (potarr[n + 1] < kPotHigh)
-        dx = kCostObs;
-      if (potarr[n - nx] < kPotHigh)
-        dy = -kCostObs;
-      else if (potarr[nx + 1] < kPotHigh)  // as written in the reference (:1020)
-        dy = kCostObs;
-    } else {
-      if (potarr[n - 1] < kPotHigh) dx += potarr[n - 1] - cv;
-      if (potarr[n + 1] < kPotHigh) dx += cv - potarr[n + 1];
-      if (potarr[n - nx] < kPotHigh) dy += potarr[n - nx] - cv;
-      if (potarr[n + nx] < kPotHigh) dy += cv - potarr[n + nx];
+  navfnCalcPath(nv, plan, potarr, goal0, goal1, start0, start1, astar ? nx * 4 : nx * ny / 2, cycle);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The expansion as a device algorithm (navgpu_navfn_plan_wavefront): the same update rule - NavFn::updateCell's
+// two-neighbour interpolation (navfn.cpp:466-535), float / double arithmetic as written there - relaxed to its FIXED POINT by
+// 32 x 32 tiles instead of walked through three priority buffers on one lane.
+//   * A tile in LDS (34 x 34 potentials with its halo, 32 x 32 costs) is swept red / black - the four-neighbour stencil is
+//     bipartite, so a half-sweep reads only cells of the other colour: race-free, and the same result whatever the waves'
+//     timing - until nothing in it changes; then its interior goes back to HBM and the tiles across every edge whose border
+//     row changed are marked for the next round.  One launch per round; a launch's workgroups look their tile's mark up and
+//     leave if there is none.
+//   * Rounds are Jacobi across tiles: round r reads the array round r - 1 wrote (P[(r - 1) & 1]) and writes P[r & 1]; a tile
+//     that changed in round r - 1 and is not marked in round r copies itself across, so both arrays stay complete.  Nothing a
+//     round reads is written in that round: results do not depend on how the workgroups are scheduled.
+//   * Early stop, the counterpart of `if (atStart) if (potarr[startCell] < POT_HIGH) break` (:692-694): an update writes a
+//     value above every value it was computed from, so once a round's smallest new value is >= the start cell's potential
+//     no later round can write below it - the start cell and everything below its potential are final.  Each round
+//     records its number of changed tiles and its smallest new value; the next one reads them before anything else.
+// The array this leaves is the update rule's fixed point wherever the potential is below the start cell's, which the
+// reference only approaches (its buffers drop entries beyond 10 000, its push tests skip some updates, its early stop leaves
+// the last block half done): potentials here are <= the reference's, and the path differs from the reference's by a
+// fraction of a cell (tests/test_navfn.py).  The reference-order mode stays the bit-exact one.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWfTile = 32, kWfThreads = 256, kWfMaxSweeps = 160;
+constexpr uint32_t kWfCopy = 1u, kWfCompute = 2u;
+
+__global__ __launch_bounds__(256) void k_navfn_wf_init(NavfnDev nv, uint32_t first, const int32_t* goals) {
+  const uint32_t plan = first + blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= nv.ns) return;
+  const int nx = nv.nx, ny = nv.ny;
+  const size_t base = (size_t)plan * nv.ns_padded;
+  const int goal = goals[2 * blockIdx.y] + goals[2 * blockIdx.y + 1] * nx;
+  const float p0 = n == goal ? 0.0f : kPotHigh;  // setupNavFn + initCost(goal, 0) (:379-453)
+  nv.potarr[base + n] = p0;
+  nv.potalt[base + n] = p0;
+  nv.gradx[base + n] = 0.0f;
+  nv.grady[base + n] = 0.0f;
+  const int y = n / nx, x = n - y * nx;
+  if (y == 0 || y == ny - 1 || x == 0 || x == nx - 1) nv.costarr[base + n] = (uint8_t)kCostObs;  // outer bounds of the cost array
+  if (n == goal) {
+    const int tiles = nv.wf_tiles_x * nv.wf_tiles_y;
+    nv.wf_act[((size_t)plan * 2 + 0) * tiles + (y / kWfTile) * nv.wf_tiles_x + x / kWfTile] = kWfCompute;
+  }
+}
+
+__global__ __launch_bounds__(kWfThreads) void k_navfn_wf_round(NavfnDev nv, uint32_t first, const int32_t* starts, int at_start, int round) {
+  __shared__ float sP[kWfTile + 2][kWfTile + 4];
+  __shared__ float sH[kWfTile][kWfTile];
+  __shared__ uint32_t s_sides, s_min;
+  const uint32_t plan = first + blockIdx.y;
+  const int nx = nv.nx, ny = nv.ny;
+  const int tiles = nv.wf_tiles_x * nv.wf_tiles_y;
+  const int tile = blockIdx.x, ty = tile / nv.wf_tiles_x, tx = tile - ty * nv.wf_tiles_x;
+  const int tid = threadIdx.x;
+  NavfnWfStatus* st = nv.wf_status + plan;
+  if (st->done) return;
+  const size_t base = (size_t)plan * nv.ns_padded;
+  const float* Pin = ((round & 1) ? nv.potarr : nv.potalt) + base;  // what round - 1 wrote
+  float* Pout = ((round & 1) ? nv.potalt : nv.potarr) + base;
+  uint32_t* nchg = nv.wf_nchg + (size_t)plan * nv.wf_max_rounds;
+  uint32_t* minv = nv.wf_min + (size_t)plan * nv.wf_max_rounds;
+  if (round > 0) {
+    const uint32_t changed_tiles = nchg[round - 1];
+    const float low = __uint_as_float(minv[round - 1]);  // (0xFFFFFFFF = a NaN when nothing changed: not read then)
+    const float ps = Pin[starts[2 * blockIdx.y + 1] * nx + starts[2 * blockIdx.y]];
+    if (changed_tiles == 0 || (at_start && ps < kPotHigh && low >= ps)) {
+      if (tile == 0 && tid == 0) {
+        st->final_array = (round & 1) ^ 1;  // 0: potarr, 1: potalt
+        st->rounds = round;
+        st->done = 1;
+      }
+      return;
     }
-    float norm = (float)hypot((double)dx, (double)dy);
-    if (norm > 0) {
-      norm = (float)(1.0 / norm);
-      gradx[n] = norm * dx;
-      grady[n] = norm * dy;
+  }
+  uint32_t* act_cur = nv.wf_act + ((size_t)plan * 2 + (round & 1)) * tiles;
+  uint32_t* act_nxt = nv.wf_act + ((size_t)plan * 2 + ((round & 1) ^ 1)) * tiles;
+  const uint32_t a = act_cur[tile];
+  if (a == 0) return;
+  if (tid == 0) {
+    s_sides = 0;
+    s_min = 0xFFFFFFFFu;
+  }
+  const int x0 = tx * kWfTile, y0 = ty * kWfTile;
+  // ---- load: interior (4 cells per thread, rows of 32 floats), then the halo ring; off the map = an unreached obstacle
+  const uint8_t* cost = nv.costarr + base;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = tid + kWfThreads * k, row = i >> 5, col = i & 31;
+    const int gx = x0 + col, gy = y0 + row;
+    const bool in = gx < nx && gy < ny;
+    sP[row + 1][col + 1] = in ? Pin[gy * nx + gx] : kPotHigh;
+    const uint8_t c = in ? cost[gy * nx + gx] : (uint8_t)kCostObs;
+    sH[row][col] = c < kCostObs ? (float)c : 0.0f;  // 0 = not updated ("don't propagate into obstacles", :483)
+  }
+  if (tid < 128) {
+    const int side = tid >> 5, j = tid & 31;  // 0: row above, 1: row below, 2: column left, 3: column right
+    const int gx = side == 0 || side == 1 ? x0 + j : (side == 2 ? x0 - 1 : x0 + kWfTile);
+    const int gy = side == 0 ? y0 - 1 : (side == 1 ? y0 + kWfTile : y0 + j);
+    const bool in = gx >= 0 && gy >= 0 && gx < nx && gy < ny;
+    const float v = in ? Pin[gy * nx + gx] : kPotHigh;
+    if (side == 0) sP[0][j + 1] = v;
+    else if (side == 1) sP[kWfTile + 1][j + 1] = v;
+    else if (side == 2) sP[j + 1][0] = v;
+    else sP[j + 1][kWfTile + 1] = v;
+  }
+  __syncthreads();
+  bool any_change = false, capped = false;
+  if (a & kWfCompute) {
+    uint32_t sides = 0;
+    float low = kPotHigh * 4.0f;
+    int sweeps = 0;
+    for (;;) {
+      int changed = 0;
+#pragma unroll
+      for (int colour = 0; colour < 2; ++colour) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int i = tid + kWfThreads * k, row = i >> 4, col = 2 * (i & 15) + ((row + colour) & 1);
+          const float hf = sH[row][col];
+          const float l = sP[row + 1][col], r = sP[row + 1][col + 2], u = sP[row][col + 1], d = sP[row + 2][col + 1];
+          float ta, tc;
+          if (l < r) tc = l; else tc = r;
+          if (u < d) ta = u; else ta = d;
+          float dc = tc - ta;
+          if (dc < 0) {
+            dc = -dc;
+            ta = tc;
+          }
+          float pot;
+          if (dc >= hf)
+            pot = ta + hf;
+          else {  // (hf > 0 here: dc >= 0)
+            const float dd = dc / hf;
+            const float v = (float)(-0.2301 * dd * dd + 0.5307 * dd + 0.7040);
+            pot = ta + hf * v;
+          }
+          if (hf > 0.0f && pot < sP[row + 1][col + 1]) {
+            sP[row + 1][col + 1] = pot;
+            changed = 1;
+            low = fminf(low, pot);
+            sides |= (row == 0 ? 1u : 0u) | (row == kWfTile - 1 ? 2u : 0u) | (col == 0 ? 4u : 0u) | (col == kWfTile - 1 ? 8u : 0u);
+          }
+        }
+        if (colour == 0) __syncthreads();
+      }
+      const int any = __syncthreads_or(changed);
+      if (!any) break;
+      any_change = true;
+      if (++sweeps >= kWfMaxSweeps) {  // a maze inside the tile: go on next round
+        capped = true;
+        break;
+      }
     }
-  };
-  // ---- calcPath (:811-985)
-  const int n_max = astar ? nx * 4 : nx * ny / 2;
+    if (any_change) {
+      // (positive floats order like their bit patterns)
+      for (int off = 32; off > 0; off >>= 1) {
+        low = fminf(low, __shfl_down(low, off));
+        sides |= __shfl_down(sides, off);
+      }
+      if ((tid & 63) == 0) {
+        atomicMin(&s_min, __float_as_uint(low));
+        atomicOr(&s_sides, sides);
+      }
+      __syncthreads();
+    }
+  }
+  if (any_change || (a & kWfCopy)) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = tid + kWfThreads * k, row = i >> 5, col = i & 31;
+      const int gx = x0 + col, gy = y0 + row;
+      if (gx < nx && gy < ny) Pout[gy * nx + gx] = sP[row + 1][col + 1];
+    }
+  }
+  if (tid == 0) {
+    act_cur[tile] = 0;  // (read again two rounds on; set only by round + 1)
+    if (any_change) {
+      const uint32_t sd = s_sides;
+      atomicOr(&act_nxt[tile], kWfCopy | (capped ? kWfCompute : 0u));
+      if ((sd & 1u) && ty > 0) atomicOr(&act_nxt[tile - nv.wf_tiles_x], kWfCompute);
+      if ((sd & 2u) && ty + 1 < nv.wf_tiles_y) atomicOr(&act_nxt[tile + nv.wf_tiles_x], kWfCompute);
+      if ((sd & 4u) && tx > 0) atomicOr(&act_nxt[tile - 1], kWfCompute);
+      if ((sd & 8u) && tx + 1 < nv.wf_tiles_x) atomicOr(&act_nxt[tile + 1], kWfCompute);
+      atomicAdd(&nchg[round], 1u);
+      atomicMin(&minv[round], s_min);
+    }
+  }
+}
+
+// NavFn::calcPath / gradCell (:811-1056) by one WAVE: the walk itself is sequential (a step needs the cell and offset the step
+// before it left), but a step alone on one lane costs ~3 us of dependent L2 round trips (the 3 x 3 neighbourhood, then four
+// gradCell calls of five reads each, memoised through two more arrays).  Here a 64 x 64 window of the potential array around
+// the walker sits in LDS (reloaded when the walker comes within two cells of its rim; addressed by FLAT index, so a read that
+// runs off a row's end sees what the reference's flat array holds there), the nine neighbourhood reads are nine lanes and a
+// ballot, the four gradCell calls four lanes, and every lane carries the walker's state.  gradCell is a pure function of the
+// potential array (its gradx / grady memo only saves recomputation), so the arithmetic per value is that of navfnCalcPath,
+// expression for expression.
+constexpr int kPathWin = 64;
+__global__ __launch_bounds__(64) void k_navfn_wf_path(NavfnDev nv, uint32_t first, const int32_t* goals, const int32_t* starts) {
+  __shared__ float sW[kPathWin * kPathWin];
+  const uint32_t plan = first + blockIdx.x;
+  const int lane = threadIdx.x;
+  const NavfnWfStatus st = nv.wf_status[plan];
+  const float* potarr = (st.final_array ? nv.potalt : nv.potarr) + (size_t)plan * nv.ns_padded;
+  const int nx = nv.nx, ny = nv.ny, ns = nv.ns;
+  float* pathx = nv.path + (size_t)plan * 2 * nv.path_cap;
+  float* pathy = pathx + nv.path_cap;
+  const int goal0 = goals[2 * blockIdx.x], goal1 = goals[2 * blockIdx.x + 1];
+  const int startCell = starts[2 * blockIdx.x + 1] * nx + starts[2 * blockIdx.x];
+  const int n_max = nx * ny / 2;
+  const float pot_nx1 = potarr[nx + 1];  // gradCell's `potarr[nx + 1]` (:1020, as written in the reference)
+  int wx0 = 0, wy0 = 0;
+  bool have_win = false;
   const float pathStep = 0.5f;
   int stc = startCell, npath = 0, found = 0;
   float dx = 0, dy = 0;
+  float px1 = 0, py1 = 0, px2 = 0, py2 = 0;  // the two points before the last one (oscillation test)
   for (int i = 0; i < n_max && i < (int)nv.path_cap; i++) {
-    const int nearest_point = max(0, min(nx * ny - 1, stc + (int)round((double)dx) + (int)(nx * round((double)dy))));
-    if (potarr[nearest_point] < (float)kCostNeutral) {
-      pathx[npath] = (float)goal0;
-      pathy[npath] = (float)goal1;
-      ++npath;
-      found = 1;
-      break;
+    const int sy = stc / nx, sx = stc - sy * nx;
+    if (!have_win || sx - wx0 < 2 || sx - wx0 > kPathWin - 4 || sy - wy0 < 2 || sy - wy0 > kPathWin - 4) {
+      __syncthreads();
+      wx0 = sx - kPathWin / 2;
+      wy0 = sy - kPathWin / 2;
+      for (int k = lane; k < kPathWin * kPathWin; k += 64) {
+        const int j = k / kPathWin, c = k - j * kPathWin;
+        const long n = (long)(wy0 + j) * nx + (wx0 + c);
+        sW[k] = (n >= 0 && n < ns) ? potarr[n] : kPotHigh;
+      }
+      have_win = true;
+      __syncthreads();
+    }
+    auto P = [&](int ox, int oy) -> float { return sW[(sy - wy0 + oy) * kPathWin + (sx - wx0 + ox)]; };  // potarr[stc + ox + oy * nx]
+    {
+      const int want = stc + (int)round((double)dx) + (int)(nx * round((double)dy));
+      const int nearest_point = max(0, min(nx * ny - 1, want));
+      const float pn = nearest_point == want ? P((int)round((double)dx), (int)round((double)dy)) : potarr[nearest_point];
+      if (pn < (float)kCostNeutral) {
+        if (lane == 0) {
+          pathx[npath] = (float)goal0;
+          pathy[npath] = (float)goal1;
+        }
+        ++npath;
+        found = 1;
+        break;
+      }
     }
     if (stc < nx || stc > ns - nx) break;  // would be out of bounds
-    pathx[npath] = (float)(stc % nx) + dx;
-    pathy[npath] = (float)(stc / nx) + dy;
+    const float cx = (float)(stc % nx) + dx, cy = (float)(stc / nx) + dy;
+    if (lane == 0) {
+      pathx[npath] = cx;
+      pathy[npath] = cy;
+    }
     npath++;
-    bool oscillation_detected = false;
-    if (npath > 2 && pathx[npath - 1] == pathx[npath - 3] && pathy[npath - 1] == pathy[npath - 3]) oscillation_detected = true;
-    const int stcnx = stc + nx, stcpx = stc - nx;
-    if (potarr[stc] >= kPotHigh || potarr[stc + 1] >= kPotHigh || potarr[stc - 1] >= kPotHigh || potarr[stcnx] >= kPotHigh ||
-        potarr[stcnx + 1] >= kPotHigh || potarr[stcnx - 1] >= kPotHigh || potarr[stcpx] >= kPotHigh || potarr[stcpx + 1] >= kPotHigh ||
-        potarr[stcpx - 1] >= kPotHigh || oscillation_detected) {
+    const bool oscillation_detected = npath > 2 && cx == px2 && cy == py2;
+    px2 = px1;
+    py2 = py1;
+    px1 = cx;
+    py1 = cy;
+    const int l9 = lane < 9 ? lane : 0;
+    const bool high9 = lane < 9 && P(l9 % 3 - 1, l9 / 3 - 1) >= kPotHigh;
+    if (__ballot(high9) != 0ull || oscillation_detected) {
       // potential-function boundary: follow the grid to the lowest of the eight neighbours (:893-925; minp is an int there)
-      int minc = stc;
-      int minp = truncX86(potarr[stc]);
-      const int nb[8] = {stcpx - 1, stcpx, stcpx + 1, stc - 1, stc + 1, stcnx - 1, stcnx, stcnx + 1};
-      for (int q = 0; q < 8; ++q)
-        if (potarr[nb[q]] < (float)minp) {
-          minp = (int)potarr[nb[q]];
-          minc = nb[q];
+      int mox = 0, moy = 0;
+      int minp = truncX86(P(0, 0));
+      const int ox[8] = {-1, 0, 1, -1, 1, -1, 0, 1}, oy[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+      for (int q = 0; q < 8; ++q) {
+        const float v = P(ox[q], oy[q]);
+        if (v < (float)minp) {
+          minp = (int)v;
+          mox = ox[q];
+          moy = oy[q];
         }
-      stc = minc;
+      }
+      const float pm = P(mox, moy);
+      stc += mox + moy * nx;
       dx = 0;
       dy = 0;
-      if (potarr[stc] >= kPotHigh) break;
+      if (pm >= kPotHigh) break;
     } else {
-      gradCell(stc);
-      gradCell(stc + 1);
-      gradCell(stcnx);
-      gradCell(stcnx + 1);
-      const float x1 = (float)((1.0 - dx) * gradx[stc] + dx * gradx[stc + 1]);
-      const float x2 = (float)((1.0 - dx) * gradx[stcnx] + dx * gradx[stcnx + 1]);
+      // gradCell (:1001-1056) of stc, stc + 1, stc + nx, stc + nx + 1 on lanes 0..3
+      const int q = lane & 3, qx = q & 1, qy = q >> 1;
+      const int n = stc + qx + qy * nx;
+      float gx = 0.0f, gy = 0.0f;
+      if (!(n < nx || n > ns - nx)) {
+        const float cv = P(qx, qy);
+        float ddx = 0.0f, ddy = 0.0f;
+        if (cv >= kPotHigh) {
+          if (P(qx - 1, qy) < kPotHigh)
+            ddx = -kCostObs;
+          else if (P(qx + 1, qy) < kPotHigh)
+            ddx = kCostObs;
+          if (P(qx, qy - 1) < kPotHigh)
+            ddy = -kCostObs;
+          else if (pot_nx1 < kPotHigh)
+            ddy = kCostObs;
+        } else {
+          if (P(qx - 1, qy) < kPotHigh) ddx += P(qx - 1, qy) - cv;
+          if (P(qx + 1, qy) < kPotHigh) ddx += cv - P(qx + 1, qy);
+          if (P(qx, qy - 1) < kPotHigh) ddy += P(qx, qy - 1) - cv;
+          if (P(qx, qy + 1) < kPotHigh) ddy += cv - P(qx, qy + 1);
+        }
+        float norm = (float)hypot((double)ddx, (double)ddy);
+        if (norm > 0) {
+          norm = (float)(1.0 / norm);
+          gx = norm * ddx;
+          gy = norm * ddy;
+        }
+      }
+      const float gx0 = __shfl(gx, 0), gx1 = __shfl(gx, 1), gx2 = __shfl(gx, 2), gx3 = __shfl(gx, 3);
+      const float gy0 = __shfl(gy, 0), gy1 = __shfl(gy, 1), gy2 = __shfl(gy, 2), gy3 = __shfl(gy, 3);
+      const float x1 = (float)((1.0 - dx) * gx0 + dx * gx1);
+      const float x2 = (float)((1.0 - dx) * gx2 + dx * gx3);
       const float x = (float)((1.0 - dy) * x1 + dy * x2);
-      const float y1 = (float)((1.0 - dx) * grady[stc] + dx * grady[stc + 1]);
-      const float y2 = (float)((1.0 - dx) * grady[stcnx] + dx * grady[stcnx + 1]);
+      const float y1 = (float)((1.0 - dx) * gy0 + dx * gy1);
+      const float y2 = (float)((1.0 - dx) * gy2 + dx * gy3);
       const float y = (float)((1.0 - dy) * y1 + dy * y2);
       if (x == 0.0 && y == 0.0) break;  // zero gradient
       const float ss = (float)(pathStep / hypot((double)x, (double)y));
@@ -274,12 +618,14 @@ __global__ __launch_bounds__(256) void k_navfn_plan(NavfnDev nv, uint32_t first,
       if (dy < -1.0) { stc -= nx; dy = (float)(dy + 1.0); }
     }
   }
-  navgpu_navfn_result r;
-  r.found = found;
-  r.path_length = found ? npath : 0;
-  r.cycles = cycle;
-  r.start_potential = potarr[startCell];
-  nv.results[plan] = r;
+  if (lane == 0) {
+    navgpu_navfn_result r;
+    r.found = found;
+    r.path_length = found ? npath : 0;
+    r.cycles = st.rounds;
+    r.start_potential = potarr[startCell];
+    nv.results[plan] = r;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -666,6 +1012,16 @@ void launch_navfn_costmap(const NavfnDev& nv, uint32_t first, uint32_t count, co
 void launch_navfn_plan(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* goals, const int32_t* starts, int astar, int at_start,
                        hipStream_t s) {
   hipLaunchKernelGGL(k_navfn_plan, dim3(count), dim3(256), 0, s, nv, first, goals, starts, astar, at_start);
+}
+
+void launch_navfn_wf_init(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* goals, hipStream_t s) {
+  hipLaunchKernelGGL(k_navfn_wf_init, dim3((nv.ns + 255) / 256, count), dim3(256), 0, s, nv, first, goals);
+}
+void launch_navfn_wf_round(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* starts, int at_start, int round, hipStream_t s) {
+  hipLaunchKernelGGL(k_navfn_wf_round, dim3(nv.wf_tiles_x * nv.wf_tiles_y, count), dim3(kWfThreads), 0, s, nv, first, starts, at_start, round);
+}
+void launch_navfn_wf_path(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* goals, const int32_t* starts, hipStream_t s) {
+  hipLaunchKernelGGL(k_navfn_wf_path, dim3(count), dim3(64), 0, s, nv, first, goals, starts);
 }
 
 void launch_gp_plan(const NavfnDev& nv, uint32_t first, uint32_t count, const navgpu_global_planner_params& gp, const double* starts,

@@ -278,7 +278,19 @@ struct NavfnDev {
   int* pb;                      // [n][3][PRIORITYBUFSIZE]
   float* path;                  // [n][2][path_cap]: pathx, pathy
   navgpu_navfn_result* results; // [n]
+  // tiled wavefront expansion (navgpu_navfn_plan_wavefront), allocated on first use
+  float* potalt;                // [n][ns_padded] the second potential array (rounds alternate)
+  uint32_t* wf_act;             // [n][2][tiles] marks of this / the next round: 1 copy across, 2 relax
+  uint32_t *wf_nchg, *wf_min;   // [n][wf_max_rounds] tiles that changed in a round / smallest value it wrote (float bits)
+  struct NavfnWfStatus* wf_status;  // [n]
+  int wf_tiles_x, wf_tiles_y, wf_max_rounds;
 };
+struct NavfnWfStatus {
+  int32_t done, final_array, rounds, pad;
+};
+void launch_navfn_wf_init(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* goals, hipStream_t s);
+void launch_navfn_wf_round(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* starts, int at_start, int round, hipStream_t s);
+void launch_navfn_wf_path(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* goals, const int32_t* starts, hipStream_t s);
 void launch_navfn_costmap(const NavfnDev& nv, uint32_t first, uint32_t count, const uint8_t* cmap, size_t stride, int cost_mode, int allow_unknown,
                           hipStream_t s);
 void launch_gp_plan(const NavfnDev& nv, uint32_t first, uint32_t count, const navgpu_global_planner_params& gp, const double* starts,

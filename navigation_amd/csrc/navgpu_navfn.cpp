@@ -14,6 +14,8 @@ struct navgpu_navfn {
   navgpu_navfn_result* h_results = nullptr;  // pinned
   double* d_xy = nullptr;      // [n][2][2] start / goal map coordinates (global_planner)
   void* d_heap = nullptr;      // [n][ns_padded] AStarExpansion's queue_, allocated when A* is first asked for
+  NavfnWfStatus* h_wf_status = nullptr;  // pinned; the tiled wavefront's per-plan state as the host last read it
+  std::vector<uint8_t> final_array;      // [n] which potential array holds a plan's result (1: potalt, wavefront mode only)
   template <class T>
   int alloc(T** p, size_t count) {
     void* q = nullptr;
@@ -49,6 +51,7 @@ int navgpu_navfn_create(uint32_t nx, uint32_t ny, uint32_t n_plans, int32_t devi
   navgpu_navfn* h = new navgpu_navfn();
   h->n = n_plans;
   h->device = device;
+  h->final_array.assign(n_plans, 0);
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     g_last_error = "hipStreamCreate failed";
@@ -92,6 +95,7 @@ int navgpu_navfn_destroy(navgpu_navfn* h) {
   if (h->stream) waitStream(h->stream);
   for (void* p : h->allocs) hipFree(p);
   if (h->h_results) hipHostFree(h->h_results);
+  if (h->h_wf_status) hipHostFree(h->h_wf_status);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return NAVGPU_OK;
@@ -139,6 +143,64 @@ int navgpu_navfn_plan(navgpu_navfn* h, uint32_t first, uint32_t count, const int
   HIP_TRY(hipMemcpyAsync(h->d_goal, goals, sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_start, starts, sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, h->stream));
   launch_navfn_plan(nv, first, count, h->d_goal, h->d_start, astar ? 1 : 0, at_start ? 1 : 0, h->stream);
+  std::fill(h->final_array.begin() + first, h->final_array.begin() + first + count, (uint8_t)0);
+  HIP_TRY(hipMemcpyAsync(h->h_results + first, nv.results + first, sizeof(navgpu_navfn_result) * count, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(waitStream(h->stream));
+  if (results) memcpy(results, h->h_results + first, sizeof(navgpu_navfn_result) * count);
+  return checkLaunch();
+}
+
+// The expansion as a tiled wavefront (navfn_kernels.hip: k_navfn_wf_*): rounds are queued a batch at a time, the per-plan
+// status (done / which array / rounds) is read between batches; a round launched after its plan has finished leaves at once.
+int navgpu_navfn_plan_wavefront(navgpu_navfn* h, uint32_t first, uint32_t count, const int32_t* goals, const int32_t* starts, int32_t at_start,
+                                navgpu_navfn_result* results) {
+  if (!h || !goals || !starts || !navfnRange(h, first, count)) return NAVGPU_ERR_INVALID;
+  NavfnGuard guard_(h);
+  NavfnDev& nv = h->nv;
+  for (uint32_t k = 0; k < count; ++k) {
+    const int32_t* g = goals + 2 * k;
+    const int32_t* s = starts + 2 * k;
+    if (g[0] < 1 || g[1] < 1 || g[0] > nv.nx - 2 || g[1] > nv.ny - 2 || s[0] < 0 || s[1] < 0 || s[0] >= nv.nx || s[1] >= nv.ny) {
+      g_last_error = "navgpu_navfn_plan_wavefront: goal / start cell outside the map";
+      return NAVGPU_ERR_INVALID;
+    }
+  }
+  constexpr int kTile = 32, kMaxRounds = 8192, kBatch = 16;
+  if (!nv.potalt) {
+    nv.wf_tiles_x = (nv.nx + kTile - 1) / kTile;
+    nv.wf_tiles_y = (nv.ny + kTile - 1) / kTile;
+    nv.wf_max_rounds = kMaxRounds;
+    int rc = 0;
+    if (!rc) rc = h->alloc(&nv.wf_act, (size_t)h->n * 2 * nv.wf_tiles_x * nv.wf_tiles_y);
+    if (!rc) rc = h->alloc(&nv.wf_nchg, (size_t)h->n * kMaxRounds);
+    if (!rc) rc = h->alloc(&nv.wf_min, (size_t)h->n * kMaxRounds);
+    if (!rc) rc = h->alloc(&nv.wf_status, h->n);
+    if (!rc && hipHostMalloc((void**)&h->h_wf_status, sizeof(NavfnWfStatus) * h->n, hipHostMallocDefault) != hipSuccess) rc = NAVGPU_ERR_HIP;
+    if (!rc) rc = h->alloc(&nv.potalt, (size_t)h->n * nv.ns_padded);  // last: its presence says the others exist
+    if (rc) return rc;
+  }
+  const size_t tiles = (size_t)nv.wf_tiles_x * nv.wf_tiles_y;
+  HIP_TRY(hipMemcpyAsync(h->d_goal, goals, sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_start, starts, sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemsetAsync(nv.wf_act + (size_t)first * 2 * tiles, 0, sizeof(uint32_t) * 2 * tiles * count, h->stream));
+  HIP_TRY(hipMemsetAsync(nv.wf_nchg + (size_t)first * kMaxRounds, 0, sizeof(uint32_t) * kMaxRounds * (size_t)count, h->stream));
+  HIP_TRY(hipMemsetAsync(nv.wf_min + (size_t)first * kMaxRounds, 0xFF, sizeof(uint32_t) * kMaxRounds * (size_t)count, h->stream));
+  HIP_TRY(hipMemsetAsync(nv.wf_status + first, 0, sizeof(NavfnWfStatus) * count, h->stream));
+  launch_navfn_wf_init(nv, first, count, h->d_goal, h->stream);
+  bool all_done = false;
+  for (int round = 0; round < kMaxRounds && !all_done;) {
+    for (int b = 0; b < kBatch && round < kMaxRounds; ++b, ++round) launch_navfn_wf_round(nv, first, count, h->d_start, at_start ? 1 : 0, round, h->stream);
+    HIP_TRY(hipMemcpyAsync(h->h_wf_status + first, nv.wf_status + first, sizeof(NavfnWfStatus) * count, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(waitStream(h->stream));
+    all_done = true;
+    for (uint32_t k = 0; k < count; ++k) all_done = all_done && h->h_wf_status[first + k].done;
+  }
+  if (!all_done) {
+    g_last_error = "navgpu_navfn_plan_wavefront: not settled within 8192 rounds";
+    return NAVGPU_ERR_CAPACITY;
+  }
+  for (uint32_t k = 0; k < count; ++k) h->final_array[first + k] = (uint8_t)h->h_wf_status[first + k].final_array;
+  launch_navfn_wf_path(nv, first, count, h->d_goal, h->d_start, h->stream);
   HIP_TRY(hipMemcpyAsync(h->h_results + first, nv.results + first, sizeof(navgpu_navfn_result) * count, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(waitStream(h->stream));
   if (results) memcpy(results, h->h_results + first, sizeof(navgpu_navfn_result) * count);
@@ -170,6 +232,7 @@ int navgpu_global_planner_plan(navgpu_navfn* h, uint32_t first, uint32_t count, 
   HIP_TRY(hipMemcpyAsync(h->d_xy + (size_t)2 * h->n, goals, sizeof(double) * 2 * count, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->d_goal, goal_cells, sizeof(int32_t) * 2 * count, hipMemcpyHostToDevice, h->stream));
   launch_gp_plan(nv, first, count, *gp, h->d_xy, h->d_xy + (size_t)2 * h->n, h->d_goal, h->d_heap, h->stream);
+  std::fill(h->final_array.begin() + first, h->final_array.begin() + first + count, (uint8_t)0);
   HIP_TRY(hipMemcpyAsync(h->h_results + first, nv.results + first, sizeof(navgpu_navfn_result) * count, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(waitStream(h->stream));
   if (results) memcpy(results, h->h_results + first, sizeof(navgpu_navfn_result) * count);
@@ -198,7 +261,7 @@ int navgpu_navfn_path(navgpu_navfn* h, uint32_t plan, float* xy, uint32_t cap) {
 int navgpu_navfn_potential(navgpu_navfn* h, uint32_t plan, float* potarr) {
   if (!h || plan >= h->n || !potarr) return NAVGPU_ERR_INVALID;
   NavfnGuard guard_(h);
-  HIP_TRY(hipMemcpyAsync(potarr, h->nv.potarr + (size_t)plan * h->nv.ns_padded, sizeof(float) * (size_t)h->nv.ns, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(potarr, (h->final_array[plan] ? h->nv.potalt : h->nv.potarr) + (size_t)plan * h->nv.ns_padded, sizeof(float) * (size_t)h->nv.ns, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(waitStream(h->stream));
   return NAVGPU_OK;
 }

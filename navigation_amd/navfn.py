@@ -57,6 +57,16 @@ class NavFn:
                                        C.cast(res, C.c_void_p)), "navfn_plan")
         return list(res)
 
+    def plan_wavefront(self, goals, starts, first=0, at_start=True):
+        """navgpu_navfn_plan_wavefront: the expansion as a tiled wavefront (the update rule's fixed point; Dijkstra only)."""
+        g = np.ascontiguousarray(goals, np.int32).reshape(-1, 2)
+        s = np.ascontiguousarray(starts, np.int32).reshape(-1, 2)
+        assert len(g) == len(s)
+        res = (NavfnResult * len(g))()
+        check(self.L.navgpu_navfn_plan_wavefront(self.h, first, len(g), g.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), int(at_start),
+                                                 C.cast(res, C.c_void_p)), "navfn_plan_wavefront")
+        return list(res)
+
     def global_planner_plan(self, starts_xy, goals_xy, goal_cells, first=0, **params):
         """GlobalPlanner::makePlan's expansion + traceback (map coordinates; costs set with cost_mode=0)."""
         st = np.ascontiguousarray(starts_xy, np.float64).reshape(-1, 2)

@@ -195,6 +195,60 @@ struct NavFnOracle {
     }
     return cycle < cycles;
   }
+  // The fixed point of updateCell's rule (:466-535): the same float / double arithmetic, relaxed from a FIFO work list until
+  // no cell changes - no 10 000-entry buffers that drop cells, no push tests (`if (l > pot + le)`) that skip updates, no
+  // early stop.  It is what the reference's process approaches from above (a relaxation only lowers a potential, and never
+  // below the fixed point), and the checker for the tiled wavefront mode of the HIP path (navgpu_navfn_plan_wavefront),
+  // whose potentials must agree with it up to the rule's order dependence (the polynomial jumps from 1.0046 to 1 at
+  // dc = hf, so two relaxation orders can settle a few cells ~1e-4 apart) below the start cell's potential.
+  float relaxValue(int n) const {
+    const float l = potarr[n - 1], r = potarr[n + 1], u = potarr[n - nx], d = potarr[n + nx];
+    float ta, tc;
+    if (l < r) tc = l; else tc = r;
+    if (u < d) ta = u; else ta = d;
+    const float hf = (float)costarr[n];
+    float dc = tc - ta;
+    if (dc < 0) {
+      dc = -dc;
+      ta = tc;
+    }
+    if (dc >= hf) return ta + hf;
+    const float dd = dc / hf;
+    const float v = -0.2301 * dd * dd + 0.5307 * dd + 0.7040;
+    return ta + hf * v;
+  }
+  void propagateFixedPoint() {
+    std::vector<int> fifo;
+    std::vector<uint8_t> queued(ns, 0);
+    size_t head = 0;
+    auto push = [&](int n) {
+      if (n >= nx && n < ns - nx && !queued[n] && costarr[n] < kCostObs) {
+        queued[n] = 1;
+        fifo.push_back(n);
+      }
+    };
+    const int k = goal[0] + goal[1] * nx;
+    push(k + 1);
+    push(k - 1);
+    push(k - nx);
+    push(k + nx);
+    while (head < fifo.size()) {
+      const int n = fifo[head++];
+      queued[n] = 0;
+      const float pot = relaxValue(n);
+      if (pot < potarr[n]) {
+        potarr[n] = pot;
+        push(n - 1);
+        push(n + 1);
+        push(n - nx);
+        push(n + nx);
+      }
+      if (head > (1u << 22)) {  // keep the list short
+        fifo.erase(fifo.begin(), fifo.begin() + head);
+        head = 0;
+      }
+    }
+  }
   // gradCell (:1001-1056)
   float gradCell(int n) {
     if (gradx[n] + grady[n] > 0.0) return 1.0;

@@ -764,6 +764,29 @@ int orc_navfn_plan(const uint8_t* cmap, int nx, int ny, int cost_mode, int allow
   }
   return len;
 }
+// The fixed point of NavFn::updateCell's rule (NavFnOracle::propagateFixedPoint) + calcPath on it: the checker of the HIP
+// path's tiled wavefront mode.  Same arguments as orc_navfn_plan (Dijkstra only).
+int orc_navfn_fixed_point(const uint8_t* cmap, int nx, int ny, int cost_mode, int allow_unknown, const int* goal, const int* start,
+                          float* potarr_out, float* path_xy, int path_cap) {
+  NavFnOracle nav(nx, ny);
+  if (cost_mode == 0)
+    memcpy(nav.costarr.data(), cmap, (size_t)nx * ny);
+  else
+    nav.setCostmap(cmap, cost_mode == 1, allow_unknown != 0);
+  nav.goal[0] = goal[0];
+  nav.goal[1] = goal[1];
+  nav.start[0] = start[0];
+  nav.start[1] = start[1];
+  nav.setupNavFn();
+  nav.propagateFixedPoint();
+  const int len = nav.calcPath(nx * ny / 2);
+  if (potarr_out) memcpy(potarr_out, nav.potarr.data(), sizeof(float) * (size_t)nx * ny);
+  for (int i = 0; i < len && i < path_cap && path_xy; ++i) {
+    path_xy[2 * i] = nav.pathx[i];
+    path_xy[2 * i + 1] = nav.pathy[i];
+  }
+  return len;
+}
 // ------------------------------------------------------------------ global_planner (second half)
 // params = {use_dijkstra, use_quadratic, use_grid_path, old_navfn_behavior, allow_unknown, lethal_cost, neutral_cost, outline_map}
 int orc_global_planner_plan(const uint8_t* cmap, int nx, int ny, const int* params, float cost_factor, const double* start_xy, const double* goal_xy,

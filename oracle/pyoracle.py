@@ -163,6 +163,7 @@ def lib():
     sig("orc_gp_grid_path", i, f32p, i, i, C.c_double, C.c_double, C.c_double, C.c_double, f32p, i)
     sig("orc_global_planner_plan", i, u8p, i, i, i32p, C.c_float, f64p, f64p, i32p, C.c_void_p, C.c_void_p, i, C.POINTER(i), C.POINTER(i))
     sig("orc_navfn_plan", i, u8p, i, i, i, i, i32p, i32p, i, i, C.c_void_p, C.c_void_p, i, C.POINTER(i))
+    sig("orc_navfn_fixed_point", i, u8p, i, i, i, i, i32p, i32p, C.c_void_p, C.c_void_p, i)
     sig("orc_bench_dwa", d, u, u, d, u8p, u, C.POINTER(DwaConfig), f32p, f32p, f64p, u, f64p, f64p, u, u, u,
         C.POINTER(C.c_uint64))
     sig("orc_bench_inflate", d, u8p, u, u, u, d, d, d, d, u, u)
@@ -577,6 +578,19 @@ def navfn_plan(cmap, goal, start, cost_mode=1, allow_unknown=True, astar=False, 
     n = lib().orc_navfn_plan(g, nx, ny, cost_mode, int(allow_unknown), np.ascontiguousarray(goal, np.int32), np.ascontiguousarray(start, np.int32),
                              int(astar), int(at_start), pot.ctypes.data if want_potential else None, path.ctypes.data, cap, C.byref(cyc))
     return path[:n].copy(), pot, cyc.value
+
+
+def navfn_fixed_point(cmap, goal, start, cost_mode=1, allow_unknown=True):
+    """The fixed point of NavFn::updateCell's rule over the whole map and calcPath on it (navfn_oracle.hpp propagateFixedPoint):
+    returns (path (n, 2) float32, potarr (ny, nx) float32)."""
+    g = np.ascontiguousarray(cmap, np.uint8)
+    ny, nx = g.shape
+    pot = np.zeros((ny, nx), np.float32)
+    cap = nx * ny // 2 + 4
+    path = np.zeros((cap, 2), np.float32)
+    n = lib().orc_navfn_fixed_point(g, nx, ny, cost_mode, int(allow_unknown), np.ascontiguousarray(goal, np.int32), np.ascontiguousarray(start, np.int32),
+                                    pot.ctypes.data, path.ctypes.data, cap)
+    return path[:n].copy(), pot
 
 
 GP_DEFAULTS = dict(use_dijkstra=1, use_quadratic=1, use_grid_path=0, old_navfn_behavior=0, allow_unknown=1, lethal_cost=253, neutral_cost=50,

@@ -135,6 +135,184 @@ def test_navfn_costmap_from_fleet(orc):
     fl.close()
 
 
+# ------------------------------------------------------------------------------------------------ tiled wavefront mode
+# navgpu_navfn_plan_wavefront relaxes NavFn::updateCell's rule to its fixed point instead of replaying the reference's
+# priority buffers.  The contract (include/navgpu.h), stated on the oracle alone first (CPU) and then checked on
+# the HIP path (GPU):
+#   (1) the fixed point never lies above the reference's array (a relaxation only lowers a potential, never below the
+#       fixed point; the reference stops early, drops buffer entries beyond 10 000 and skips some pushes);
+#   (2) where the reference has had time to settle - well below the start cell's potential - the two agree closely;
+#   (3) calcPath over the fixed point stays within a cell of calcPath over the reference's array, same end points.
+def _hausdorff(a, b):
+    d = np.hypot(a[:, None, 0] - b[None, :, 0], a[:, None, 1] - b[None, :, 1])
+    return max(d.min(axis=1).max(), d.min(axis=0).max())
+
+
+def _costarr(cm, cost_mode, allow_unknown=True):
+    """NavFn::setCostmap (navfn.cpp:222-283) for cost_mode 1 (isROS), the bytes themselves for 0."""
+    if cost_mode == 0:
+        return cm.astype(np.int32)
+    v = cm.astype(np.int32)
+    out = np.full(cm.shape, 254, np.int32)
+    lo = v < 253
+    out[lo] = np.minimum((50 + 0.8 * v[lo]).astype(np.int32), 253)
+    if allow_unknown:
+        out[v == 255] = 253
+    return out
+
+
+def _path_cost(path, costarr):
+    """Cell cost integrated along a path: what the expansion minimises, whichever cells the path picks."""
+    seg = np.hypot(*np.diff(path, axis=0).T)
+    mid = (path[1:] + path[:-1]) / 2
+    return float((costarr[np.round(mid[:, 1]).astype(int), np.round(mid[:, 0]).astype(int)] * seg).sum())
+
+
+def _maze_costmap(rs, n):
+    """Rooms and doorways with inflated walls: the path has to wind, the wavefront meets tiles more than once."""
+    cm = np.zeros((n, n), np.uint8)
+    for k in range(24, n - 8, 24):
+        cm[k, 4:n - 4] = 254
+        cm[4:n - 4, k] = 254
+        for _ in range(3):
+            a = rs.randint(8, n - 12)
+            cm[k, a:a + 4] = 0
+            b = rs.randint(8, n - 12)
+            cm[b:b + 4, k] = 0
+    soft = (rs.random_sample((n, n)) < 0.2) & (cm == 0)
+    cm[soft] = rs.randint(1, 200, soft.sum())
+    return cm
+
+
+@pytest.mark.parametrize("start,goal", WILLOW_CASES)
+def test_oracle_fixed_point_against_reference_order(orc, willow, start, goal):
+    path, pot, _ = orc.navfn_plan(willow, goal, start, cost_mode=0)
+    fpath, fpot = orc.navfn_fixed_point(willow, goal, start, cost_mode=0)
+    assert not (fpot > pot * (1 + 5e-4)).any()                                # (1)
+    ps = pot[start[1], start[0]]
+    assert fpot[start[1], start[0]] <= ps and ps - fpot[start[1], start[0]] < 100.0   # one priority block (2 x COST_NEUTRAL)
+    iy, ix = np.clip(np.round(path[:, 1]).astype(int), 0, pot.shape[0] - 1), np.clip(np.round(path[:, 0]).astype(int), 0, pot.shape[1] - 1)
+    assert np.abs(pot[iy, ix] - fpot[iy, ix]).max() < 100.0                   # (2) along the path: within one block
+    assert len(fpath) > 0 and tuple(fpath[0]) == tuple(path[0]) and tuple(fpath[-1]) == tuple(path[-1])
+    assert _hausdorff(path, fpath) <= 1.0                                     # (3) on the reference's own two searches
+    assert _path_cost(fpath, _costarr(willow, 0)) <= 1.01 * _path_cost(path, _costarr(willow, 0))
+
+
+def test_oracle_fixed_point_random_and_maze_maps(orc):
+    """Away from the reference's own vectors: the rule is not monotone at dc = hf (its polynomial steps from 1.0046 down to 1), so
+    which value a cell keeps depends on the order of the relaxations at the 1e-4 level, and where two routes round an obstacle
+    at nearly the same cost the two arrays may choose differently - the paths then differ by cells, not their cost."""
+    rs = np.random.RandomState(5)
+    n_paths = 0
+    for it in range(10):
+        n = 140
+        cm = _maze_costmap(rs, n) if it % 2 else _random_costmap(rs, n, 0.05)
+        goal, start = rs.randint(8, n - 8, 2), rs.randint(8, n - 8, 2)
+        cm[goal[1], goal[0]] = 0
+        cm[start[1], start[0]] = 0
+        path, pot, _ = orc.navfn_plan(cm, goal, start, cost_mode=1)
+        fpath, fpot = orc.navfn_fixed_point(cm, goal, start, cost_mode=1)
+        assert not (fpot > pot * (1 + 5e-4)).any()
+        assert fpot[start[1], start[0]] <= pot[start[1], start[0]]
+        assert (len(fpath) > 0) == (len(path) > 0)
+        if len(path):
+            assert tuple(fpath[0]) == tuple(path[0]) and tuple(fpath[-1]) == tuple(path[-1])
+            assert _path_cost(fpath, _costarr(cm, 1)) <= 1.05 * _path_cost(path, _costarr(cm, 1))
+            n_paths += 1
+    assert n_paths >= 5
+
+
+def _check_wavefront_plan(orc, nf, k, res, cm, goal, start, cost_mode, at_start=True, allow_unknown=True):
+    """One plan of the HIP wavefront mode against the oracle: fixed point (potentials, path) and reference order (contract)."""
+    fpath, fpot = orc.navfn_fixed_point(cm, goal, start, cost_mode=cost_mode, allow_unknown=allow_unknown)
+    path, pot, _ = orc.navfn_plan(cm, goal, start, cost_mode=cost_mode, allow_unknown=allow_unknown, at_start=at_start)
+    g = nf.potential(k)
+    ps = g[start[1], start[0]]
+    reached = ps < 1e9
+    assert reached == (fpot[start[1], start[0]] < 1e9)
+    # settled region: everything below the start cell's potential (the whole map when the start was never reached or at_start
+    # is off).  There the HIP array is the rule's fixed point - equal to the oracle's FIFO relaxation up to the rule's order
+    # dependence (a percent or two of the cells, <= 1e-3 relative); beyond it a cell holds POT_HIGH or a value on its way down.
+    settled = (fpot < ps) if (reached and at_start) else np.ones_like(fpot, bool)
+    a, b = g[settled], fpot[settled]
+    assert ((a >= 1e9) == (b >= 1e9)).all()
+    fin = b < 1e9
+    rel = np.abs(a[fin] - b[fin]) / np.maximum(b[fin], 1.0)
+    assert rel.max() <= 1e-3 if fin.any() else True, rel.max()  # (willow: 5.2e-4 at worst, 1.4 % of the cells differ at all)
+    assert not (g[~settled] < fpot[~settled] * (1 - 1e-3)).any()  # never below the fixed point
+    assert not (g[pot < 1e9] > pot[pot < 1e9] * (1 + 1e-3)).any() if at_start else True  # (1): never above the reference's array
+    gpath = nf.path(k)
+    assert bool(res.found) == (len(gpath) > 0) == (len(fpath) > 0)
+    assert res.path_length == len(gpath)
+    if len(gpath):
+        assert tuple(gpath[0]) == tuple(float(v) for v in start) and tuple(gpath[-1]) == tuple(float(v) for v in goal)
+        ca = _costarr(cm, cost_mode, allow_unknown)
+        assert _path_cost(gpath, ca) <= 1.02 * _path_cost(fpath, ca)
+        if len(path):
+            assert _path_cost(gpath, ca) <= 1.05 * _path_cost(path, ca)          # (3) against the reference order
+    return len(gpath) > 0
+
+
+@pytest.mark.gpu
+def test_navfn_wavefront_willow_cases(orc, willow):
+    """The reference's two searches of path_calc_test.cpp in the tiled wavefront mode, both at once; run twice: identical bits."""
+    import navigation_amd as nav
+    ny, nx = willow.shape
+    nf = nav.NavFn(nx, ny, 2)
+    nf.set_costmap(willow, cost_mode=0)
+    goals, starts = [g for _, g in WILLOW_CASES], [s for s, _ in WILLOW_CASES]
+    res = nf.plan_wavefront(goals, starts)
+    first = [(nf.potential(k).copy(), nf.path(k).copy(), res[k].cycles) for k in range(2)]
+    for k, (start, goal) in enumerate(WILLOW_CASES):
+        assert _check_wavefront_plan(orc, nf, k, res[k], willow, goal, start, 0)
+        path, _, _ = orc.navfn_plan(willow, goal, start, cost_mode=0)
+        assert _hausdorff(nf.path(k), path) <= 1.0
+    res = nf.plan_wavefront(goals, starts)
+    for k in range(2):
+        assert res[k].cycles == first[k][2]
+        assert np.array_equal(nf.potential(k).view(np.uint32), first[k][0].view(np.uint32))
+        assert np.array_equal(nf.path(k).view(np.uint32), first[k][1].view(np.uint32))
+    # the reference-order mode on the same handle afterwards: still bit-exact (the two modes share the arrays)
+    res = nf.plan(goals, starts)
+    for k, (start, goal) in enumerate(WILLOW_CASES):
+        path, pot, cyc = orc.navfn_plan(willow, goal, start, cost_mode=0)
+        assert res[k].cycles == cyc and np.array_equal(nf.potential(k).view(np.uint32), pot.view(np.uint32))
+        assert np.array_equal(nf.path(k).view(np.uint32), path.view(np.uint32))
+    nf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("at_start", [True, False])
+def test_navfn_wavefront_batch_random_and_maze(orc, at_start):
+    import navigation_amd as nav
+    rs = np.random.RandomState(17)
+    n, nI = 150, 8   # 150 = 4 tiles of 32 + a ragged fifth
+    maps = np.stack([_maze_costmap(rs, n) if k % 2 else _random_costmap(rs, n, 0.05) for k in range(nI)])
+    goals = rs.randint(8, n - 8, (nI, 2))
+    starts = rs.randint(8, n - 8, (nI, 2))
+    for k in range(nI):
+        maps[k][goals[k][1], goals[k][0]] = 0
+        maps[k][starts[k][1], starts[k][0]] = 0
+    maps[nI - 1][starts[nI - 1][1] - 2:starts[nI - 1][1] + 3, starts[nI - 1][0] - 2:starts[nI - 1][0] + 3] = 254  # walled in: no plan
+    maps[nI - 1][starts[nI - 1][1], starts[nI - 1][0]] = 0
+    nf = nav.NavFn(n, n, nI)
+    n_found = 0
+    for allow_unknown in (True, False):
+        nf.set_costmap(maps, cost_mode=1, allow_unknown=allow_unknown)
+        res = nf.plan_wavefront(goals, starts, at_start=at_start)
+        for k in range(nI):
+            n_found += _check_wavefront_plan(orc, nf, k, res[k], maps[k], goals[k], starts[k], 1, at_start=at_start, allow_unknown=allow_unknown)
+        assert not res[nI - 1].found
+    assert n_found >= 8
+    # a sub-range of the batch leaves the other plans' results alone
+    keep = nf.potential(0).copy()
+    nf.plan_wavefront(goals[3:5], starts[3:5], first=3, at_start=at_start)
+    assert np.array_equal(nf.potential(0).view(np.uint32), keep.view(np.uint32))
+    with pytest.raises(nav.NavgpuError):
+        nf.plan_wavefront([[0, 5]], [[5, 5]])
+    nf.close()
+
+
 # ------------------------------------------------------------------------------------------------ global_planner
 GP_VARIANTS = [dict(), dict(use_quadratic=0), dict(use_grid_path=1), dict(old_navfn_behavior=1), dict(use_dijkstra=0),
                dict(use_dijkstra=0, use_quadratic=0, use_grid_path=1), dict(allow_unknown=0, cost_factor=0.55, neutral_cost=66)]
