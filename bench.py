@@ -287,6 +287,32 @@ def configs4_leg(nav, device, n_robots=64, n_cells=1000, steps=10):
             "kernel_ms": {k: round(v[0] / v[1], 4) for k, v in pr.items() if v[1]}}
 
 
+def navfn_leg(nav, fleet, n_robots, device):
+    """SURVEY 8 row f-4 (navfn::NavFn, once per replan): one global plan per robot across its own master grid, handed over on
+    the device - the tiled wavefront mode (navgpu_navfn_plan_wavefront) and the reference-order mode (navgpu_navfn_plan, bit-exact,
+    one lane per plan) on the same plans."""
+    n = int(fleet.nx)
+    nf = nav.NavFn(n, n, n_robots, device=device)
+    nf.set_costmap_from_fleet(fleet, count=n_robots)
+    goals = np.tile(np.array([[n // 2, n // 2]], np.int32), (n_robots, 1))
+    starts = np.array([[12 + (7 * i) % 24, n - 13 - (11 * i) % 24] if i % 2 else [n - 13 - (5 * i) % 24, 12 + (3 * i) % 24] for i in range(n_robots)], np.int32)
+    out = {}
+    for name, fn in (("wavefront", lambda: nf.plan_wavefront(goals, starts)), ("reference_order", lambda: nf.plan(goals, starts))):
+        fn()
+        t = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = fn()
+            t.append((time.perf_counter() - t0) * 1e3)
+        out[name] = {"ms_per_batch": min(t), "plans": n_robots, "found": int(sum(r.found for r in res)),
+                     "mean_path_points": float(np.mean([r.path_length for r in res]))}
+    nf.close()
+    out["note"] = (f"{n_robots} plans side by side on {n} x {n} master grids (corner of the map -> its centre), costmaps handed over on the device; "
+                   "wavefront: updateCell's rule relaxed to its fixed point by 32 x 32 LDS tiles, potentials <= the reference's, paths of equal cost "
+                   "(tests/test_navfn.py); reference_order: the reference's priority buffers replayed bit for bit, one lane per plan")
+    return out
+
+
 def inflation_reference_order_leg(nav, insts, n_cells, device):
     """SURVEY a10 in the reference's own order (priority_queue_order = 1: InflationLayer::updateCosts' priority-queue walk,
     byte-identical to the reference) on the contract workload: static + obstacle + inflation layers, a new scan per cycle,
@@ -866,6 +892,7 @@ def main():
         masters = groups[0].fl.master(0, min(groups[0].n, 32))
         if not args.no_single:
             out["inflation_reference_order"] = inflation_reference_order_leg(nav, insts, n_cells, local_rank)
+            out["navfn_global_plans"] = navfn_leg(nav, groups[0].fl, min(groups[0].n, 32), local_rank)
             f1, i1, c1 = build_fleet(nav, 1, n_cells, seed0=0, device=local_rank)
             p1 = PoseSchedule(f1._bench_host_inputs[2], f1._bench_host_inputs[3], 64, seed=7)
             for k in range(3):
