@@ -645,6 +645,12 @@ typedef struct {
  * reports found = 0. */
 int navgpu_global_planner_plan(navgpu_navfn* nav, uint32_t first, uint32_t count, const navgpu_global_planner_params* params,
                                const double* starts_xy, const double* goals_xy, const int32_t* goal_cells_xy, navgpu_navfn_result* results);
+/* The same call with DijkstraExpansion run as a device algorithm (see navgpu_navfn_plan_wavefront: the update rule of
+ * dijkstra.cpp:170-229 - getCost, PotentialCalculator or QuadraticCalculator - relaxed to its fixed point by LDS tiles from the
+ * start cell(s), stopped once the goal cell and everything below its potential is final); clearEndpoint and the traceback are
+ * the same code as in navgpu_global_planner_plan.  use_dijkstra must be 1.  results[k].cycles = rounds run. */
+int navgpu_global_planner_plan_wavefront(navgpu_navfn* nav, uint32_t first, uint32_t count, const navgpu_global_planner_params* params,
+                                         const double* starts_xy, const double* goals_xy, const int32_t* goal_cells_xy, navgpu_navfn_result* results);
 
 #ifdef __cplusplus
 }

@@ -259,6 +259,7 @@ SYMBOLS = [
     ("navgpu_navfn_plan", C.c_int, [vp, u32, u32, vp, vp, i32, i32, vp]),
     ("navgpu_navfn_plan_wavefront", C.c_int, [vp, u32, u32, vp, vp, i32, vp]),
     ("navgpu_global_planner_plan", C.c_int, [vp, u32, u32, C.POINTER(GlobalPlannerParams), vp, vp, vp, vp]),
+    ("navgpu_global_planner_plan_wavefront", C.c_int, [vp, u32, u32, C.POINTER(GlobalPlannerParams), vp, vp, vp, vp]),
     ("navgpu_navfn_path", C.c_int, [vp, u32, vp, u32]),
     ("navgpu_navfn_potential", C.c_int, [vp, u32, vp]),
     ("navgpu_footprint_radii", C.c_int, [vp, u32, C.POINTER(dbl), C.POINTER(dbl)]),

@@ -317,27 +317,50 @@ __global__ __launch_bounds__(256) void k_navfn_plan(NavfnDev nv, uint32_t first,
 constexpr int kWfTile = 32, kWfThreads = 256, kWfMaxSweeps = 160;
 constexpr uint32_t kWfCopy = 1u, kWfCompute = 2u;
 
-__global__ __launch_bounds__(256) void k_navfn_wf_init(NavfnDev nv, uint32_t first, const int32_t* goals) {
+// hf of a cell under a rule: its cost as the update sees it, < 0 = never updated.  navfn: costarr itself, obstacles from COST_OBS
+// (navfn.cpp:483); global_planner: DijkstraExpansion::getCost (dijkstra.h:78-87) narrowed to unsigned char as updateCell passes it
+// (dijkstra.cpp:178-185)
+__device__ __forceinline__ float wfCellCost(const NavfnWfRule& rule, uint8_t cost) {
+  if (!rule.global_planner) return cost < kCostObs ? (float)cost : -1.0f;
+  float c = cost;
+  if (c < rule.lethal_cost - 1 || (rule.allow_unknown && c == 255)) {
+    c = c * rule.cost_factor + rule.neutral_cost;
+    if (c >= rule.lethal_cost) c = rule.lethal_cost - 1;
+    return (float)(uint8_t)c;
+  }
+  return -1.0f;
+}
+
+// the arrays a search starts from: POT_HIGH everywhere but the seeds (navfn: the goal, 0 - setupNavFn + initCost :379-453;
+// global_planner: the start cell, or setPreciseStart's four cells - dijkstra.cpp:88-110), zero gradients, the outline; the
+// tiles that hold a seed or one of its four neighbours are marked for round 0
+__global__ __launch_bounds__(256) void k_navfn_wf_init(NavfnDev nv, uint32_t first, NavfnWfRule rule, const int32_t* seed_cells, const float* seed_vals) {
   const uint32_t plan = first + blockIdx.y;
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= nv.ns) return;
   const int nx = nv.nx, ny = nv.ny;
   const size_t base = (size_t)plan * nv.ns_padded;
-  const int goal = goals[2 * blockIdx.y] + goals[2 * blockIdx.y + 1] * nx;
-  const float p0 = n == goal ? 0.0f : kPotHigh;  // setupNavFn + initCost(goal, 0) (:379-453)
+  float p0 = kPotHigh;
+  bool mark = false;
+  for (int k = 0; k < 4; ++k) {
+    const int c = seed_cells[4 * blockIdx.y + k];
+    if (c < 0) continue;
+    if (n == c) p0 = seed_vals[4 * blockIdx.y + k];
+    mark = mark || n == c || n == c - 1 || n == c + 1 || n == c - nx || n == c + nx;
+  }
   nv.potarr[base + n] = p0;
   nv.potalt[base + n] = p0;
   nv.gradx[base + n] = 0.0f;
   nv.grady[base + n] = 0.0f;
   const int y = n / nx, x = n - y * nx;
-  if (y == 0 || y == ny - 1 || x == 0 || x == nx - 1) nv.costarr[base + n] = (uint8_t)kCostObs;  // outer bounds of the cost array
-  if (n == goal) {
+  if (rule.outline && (y == 0 || y == ny - 1 || x == 0 || x == nx - 1)) nv.costarr[base + n] = (uint8_t)kCostObs;  // outer bounds of the cost array (254 = LETHAL_OBSTACLE too)
+  if (mark) {
     const int tiles = nv.wf_tiles_x * nv.wf_tiles_y;
-    nv.wf_act[((size_t)plan * 2 + 0) * tiles + (y / kWfTile) * nv.wf_tiles_x + x / kWfTile] = kWfCompute;
+    atomicOr(&nv.wf_act[((size_t)plan * 2 + 0) * tiles + (y / kWfTile) * nv.wf_tiles_x + x / kWfTile], kWfCompute);
   }
 }
 
-__global__ __launch_bounds__(kWfThreads) void k_navfn_wf_round(NavfnDev nv, uint32_t first, const int32_t* starts, int at_start, int round) {
+__global__ __launch_bounds__(kWfThreads) void k_navfn_wf_round(NavfnDev nv, uint32_t first, NavfnWfRule rule, const int32_t* stop_cells, int at_start, int round) {
   __shared__ float sP[kWfTile + 2][kWfTile + 4];
   __shared__ float sH[kWfTile][kWfTile];
   __shared__ uint32_t s_sides, s_min;
@@ -356,7 +379,7 @@ __global__ __launch_bounds__(kWfThreads) void k_navfn_wf_round(NavfnDev nv, uint
   if (round > 0) {
     const uint32_t changed_tiles = nchg[round - 1];
     const float low = __uint_as_float(minv[round - 1]);  // (0xFFFFFFFF = a NaN when nothing changed: not read then)
-    const float ps = Pin[starts[2 * blockIdx.y + 1] * nx + starts[2 * blockIdx.y]];
+    const float ps = Pin[stop_cells[blockIdx.y]];
     if (changed_tiles == 0 || (at_start && ps < kPotHigh && low >= ps)) {
       if (tile == 0 && tid == 0) {
         st->final_array = (round & 1) ^ 1;  // 0: potarr, 1: potalt
@@ -384,7 +407,7 @@ __global__ __launch_bounds__(kWfThreads) void k_navfn_wf_round(NavfnDev nv, uint
     const bool in = gx < nx && gy < ny;
     sP[row + 1][col + 1] = in ? Pin[gy * nx + gx] : kPotHigh;
     const uint8_t c = in ? cost[gy * nx + gx] : (uint8_t)kCostObs;
-    sH[row][col] = c < kCostObs ? (float)c : 0.0f;  // 0 = not updated ("don't propagate into obstacles", :483)
+    sH[row][col] = wfCellCost(rule, c);  // < 0 = not updated ("don't propagate into obstacles", :483)
   }
   if (tid < 128) {
     const int side = tid >> 5, j = tid & 31;  // 0: row above, 1: row below, 2: column left, 3: column right
@@ -421,14 +444,16 @@ __global__ __launch_bounds__(kWfThreads) void k_navfn_wf_round(NavfnDev nv, uint
             ta = tc;
           }
           float pot;
-          if (dc >= hf)
+          if (!rule.quadratic)  // PotentialCalculator::calculatePotential (potential_calculator.h:50-59)
+            pot = fminf(fminf(l, r), fminf(u, d)) + hf;
+          else if (dc >= hf)
             pot = ta + hf;
-          else {  // (hf > 0 here: dc >= 0)
+          else {  // (hf > 0 here: 0 <= dc < hf)
             const float dd = dc / hf;
             const float v = (float)(-0.2301 * dd * dd + 0.5307 * dd + 0.7040);
             pot = ta + hf * v;
           }
-          if (hf > 0.0f && pot < sP[row + 1][col + 1]) {
+          if (hf >= 0.0f && pot < sP[row + 1][col + 1]) {
             sP[row + 1][col + 1] = pot;
             changed = 1;
             low = fminf(low, pot);
@@ -643,13 +668,17 @@ struct GpHeapEntry {  // astar.h:47-55 Index
   int i;
   float cost;
 };
-__global__ __launch_bounds__(256) void k_gp_plan(NavfnDev nv, uint32_t first, navgpu_global_planner_params gp, const double* starts, const double* goals,
-                                                 const int32_t* goal_cells, GpHeapEntry* heaps) {
+// WAVEFRONT: the expansion has already run as a tiled wavefront (k_navfn_wf_round with the global_planner rule) and left its
+// potentials in `wf_potential`, its round count in `wf_rounds`; what remains is makePlan's tail - found_legal, clearEndpoint,
+// the traceback - on one lane, the same code as the reference-order kernel's.
+template <bool WAVEFRONT>
+__device__ __forceinline__ void gpPlanBody(const NavfnDev& nv, uint32_t first, const navgpu_global_planner_params& gp, const double* starts,
+                                           const double* goals, const int32_t* goal_cells, GpHeapEntry* heaps, float* wf_potential, int wf_rounds) {
   const uint32_t plan = first + blockIdx.x;
   const int nx = nv.nx, ny = nv.ny, ns = nv.ns;
   uint8_t* costs = nv.costarr + (size_t)plan * nv.ns_padded;
   uint8_t* pending = nv.pending + (size_t)plan * nv.ns_padded;
-  float* potential = nv.potarr + (size_t)plan * nv.ns_padded;
+  float* potential = WAVEFRONT ? wf_potential : nv.potarr + (size_t)plan * nv.ns_padded;
   float* gradx = nv.gradx + (size_t)plan * nv.ns_padded;
   float* grady = nv.grady + (size_t)plan * nv.ns_padded;
   float* pathx = nv.path + (size_t)plan * 2 * nv.path_cap;
@@ -661,15 +690,19 @@ __global__ __launch_bounds__(256) void k_gp_plan(NavfnDev nv, uint32_t first, na
   const bool unknown = gp.allow_unknown != 0, quadratic = gp.use_quadratic != 0;
   constexpr float kHigh = 1.0e10f;
   // all lanes: the arrays every expansion starts from, and GlobalPlanner::outlineMap
-  for (int i = threadIdx.x; i < ns; i += blockDim.x) {
-    potential[i] = kHigh;
-    gradx[i] = 0.0f;
-    grady[i] = 0.0f;
-    pending[i] = 0;
-    const int y = i / nx, x = i - y * nx;
-    if (gp.outline_map && (y == 0 || y == ny - 1 || x == 0 || x == nx - 1)) costs[i] = 254;  // costmap_2d::LETHAL_OBSTACLE
+  if (!WAVEFRONT) {
+    for (int i = threadIdx.x; i < ns; i += blockDim.x) {
+      potential[i] = kHigh;
+      gradx[i] = 0.0f;
+      grady[i] = 0.0f;
+      pending[i] = 0;
+      const int y = i / nx, x = i - y * nx;
+      if (gp.outline_map && (y == 0 || y == ny - 1 || x == 0 || x == nx - 1)) costs[i] = 254;  // costmap_2d::LETHAL_OBSTACLE
+    }
+    __syncthreads();
   }
-  __syncthreads();
+  (void)ny;
+  (void)pending;
   if (threadIdx.x != 0) return;
 
   // A border cell can enter the expansion when nothing outlines the map (gp.outline_map == 0) or when the outline's 254 is
@@ -714,7 +747,10 @@ __global__ __launch_bounds__(256) void k_gp_plan(NavfnDev nv, uint32_t first, na
   int cycle = 0;
   bool found_legal = false;
   const int endCell = (int)goal_x + nx * (int)goal_y;
-  if (gp.use_dijkstra) {
+  if (WAVEFRONT) {
+    cycle = wf_rounds;
+    found_legal = potential[endCell] < kHigh;  // the reference leaves its loop through `break` exactly when the goal cell has a potential
+  } else if (gp.use_dijkstra) {
     int* cur = nv.pb + (size_t)plan * 3 * kPriorityBufSize;
     int* nxt = cur + kPriorityBufSize;
     int* ovr = nxt + kPriorityBufSize;
@@ -1004,6 +1040,16 @@ __global__ __launch_bounds__(256) void k_gp_plan(NavfnDev nv, uint32_t first, na
   r.start_potential = potential[endCell];
   nv.results[plan] = r;
 }
+__global__ __launch_bounds__(256) void k_gp_plan(NavfnDev nv, uint32_t first, navgpu_global_planner_params gp, const double* starts, const double* goals,
+                                                 const int32_t* goal_cells, GpHeapEntry* heaps) {
+  gpPlanBody<false>(nv, first, gp, starts, goals, goal_cells, heaps, nullptr, 0);
+}
+__global__ __launch_bounds__(64) void k_gp_wf_finish(NavfnDev nv, uint32_t first, navgpu_global_planner_params gp, const double* starts, const double* goals,
+                                                     const int32_t* goal_cells) {
+  const uint32_t plan = first + blockIdx.x;
+  const NavfnWfStatus st = nv.wf_status[plan];
+  gpPlanBody<true>(nv, first, gp, starts, goals, goal_cells, nullptr, (st.final_array ? nv.potalt : nv.potarr) + (size_t)plan * nv.ns_padded, st.rounds);
+}
 
 void launch_navfn_costmap(const NavfnDev& nv, uint32_t first, uint32_t count, const uint8_t* cmap, size_t stride, int cost_mode, int allow_unknown,
                           hipStream_t s) {
@@ -1014,11 +1060,17 @@ void launch_navfn_plan(const NavfnDev& nv, uint32_t first, uint32_t count, const
   hipLaunchKernelGGL(k_navfn_plan, dim3(count), dim3(256), 0, s, nv, first, goals, starts, astar, at_start);
 }
 
-void launch_navfn_wf_init(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* goals, hipStream_t s) {
-  hipLaunchKernelGGL(k_navfn_wf_init, dim3((nv.ns + 255) / 256, count), dim3(256), 0, s, nv, first, goals);
+void launch_navfn_wf_init(const NavfnDev& nv, uint32_t first, uint32_t count, const NavfnWfRule& rule, const int32_t* seed_cells, const float* seed_vals,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(k_navfn_wf_init, dim3((nv.ns + 255) / 256, count), dim3(256), 0, s, nv, first, rule, seed_cells, seed_vals);
 }
-void launch_navfn_wf_round(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* starts, int at_start, int round, hipStream_t s) {
-  hipLaunchKernelGGL(k_navfn_wf_round, dim3(nv.wf_tiles_x * nv.wf_tiles_y, count), dim3(kWfThreads), 0, s, nv, first, starts, at_start, round);
+void launch_navfn_wf_round(const NavfnDev& nv, uint32_t first, uint32_t count, const NavfnWfRule& rule, const int32_t* stop_cells, int at_start, int round,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(k_navfn_wf_round, dim3(nv.wf_tiles_x * nv.wf_tiles_y, count), dim3(kWfThreads), 0, s, nv, first, rule, stop_cells, at_start, round);
+}
+void launch_gp_wf_finish(const NavfnDev& nv, uint32_t first, uint32_t count, const navgpu_global_planner_params& gp, const double* starts,
+                         const double* goals, const int32_t* goal_cells, hipStream_t s) {
+  hipLaunchKernelGGL(k_gp_wf_finish, dim3(count), dim3(64), 0, s, nv, first, gp, starts, goals, goal_cells);
 }
 void launch_navfn_wf_path(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* goals, const int32_t* starts, hipStream_t s) {
   hipLaunchKernelGGL(k_navfn_wf_path, dim3(count), dim3(64), 0, s, nv, first, goals, starts);

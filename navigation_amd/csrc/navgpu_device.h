@@ -288,8 +288,19 @@ struct NavfnDev {
 struct NavfnWfStatus {
   int32_t done, final_array, rounds, pad;
 };
-void launch_navfn_wf_init(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* goals, hipStream_t s);
-void launch_navfn_wf_round(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* starts, int at_start, int round, hipStream_t s);
+// which update rule the tiled wavefront relaxes: NavFn::updateCell's (navfn.cpp:466-535) or DijkstraExpansion::updateCell's with
+// its cost translation and either potential calculator (dijkstra.cpp:170-229, dijkstra.h:78-87)
+struct NavfnWfRule {
+  int32_t global_planner, quadratic, outline, allow_unknown;
+  int32_t lethal_cost, neutral_cost;
+  float cost_factor;
+};
+void launch_navfn_wf_init(const NavfnDev& nv, uint32_t first, uint32_t count, const NavfnWfRule& rule, const int32_t* seed_cells, const float* seed_vals,
+                          hipStream_t s);
+void launch_navfn_wf_round(const NavfnDev& nv, uint32_t first, uint32_t count, const NavfnWfRule& rule, const int32_t* stop_cells, int at_start, int round,
+                           hipStream_t s);
+void launch_gp_wf_finish(const NavfnDev& nv, uint32_t first, uint32_t count, const navgpu_global_planner_params& gp, const double* starts,
+                         const double* goals, const int32_t* goal_cells, hipStream_t s);
 void launch_navfn_wf_path(const NavfnDev& nv, uint32_t first, uint32_t count, const int32_t* goals, const int32_t* starts, hipStream_t s);
 void launch_navfn_costmap(const NavfnDev& nv, uint32_t first, uint32_t count, const uint8_t* cmap, size_t stride, int cost_mode, int allow_unknown,
                           hipStream_t s);

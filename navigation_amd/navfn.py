@@ -67,15 +67,17 @@ class NavFn:
                                                  C.cast(res, C.c_void_p)), "navfn_plan_wavefront")
         return list(res)
 
-    def global_planner_plan(self, starts_xy, goals_xy, goal_cells, first=0, **params):
-        """GlobalPlanner::makePlan's expansion + traceback (map coordinates; costs set with cost_mode=0)."""
+    def global_planner_plan(self, starts_xy, goals_xy, goal_cells, first=0, wavefront=False, **params):
+        """GlobalPlanner::makePlan's expansion + traceback (map coordinates; costs set with cost_mode=0).  wavefront: the
+        Dijkstra expansion as the tiled wavefront (navgpu_global_planner_plan_wavefront)."""
         st = np.ascontiguousarray(starts_xy, np.float64).reshape(-1, 2)
         gl = np.ascontiguousarray(goals_xy, np.float64).reshape(-1, 2)
         gc = np.ascontiguousarray(goal_cells, np.int32).reshape(-1, 2)
         gp = GlobalPlannerParams(**params)
         res = (NavfnResult * len(st))()
-        check(self.L.navgpu_global_planner_plan(self.h, first, len(st), C.byref(gp), st.ctypes.data_as(C.c_void_p), gl.ctypes.data_as(C.c_void_p),
-                                                gc.ctypes.data_as(C.c_void_p), C.cast(res, C.c_void_p)), "global_planner_plan")
+        fn = self.L.navgpu_global_planner_plan_wavefront if wavefront else self.L.navgpu_global_planner_plan
+        check(fn(self.h, first, len(st), C.byref(gp), st.ctypes.data_as(C.c_void_p), gl.ctypes.data_as(C.c_void_p),
+                 gc.ctypes.data_as(C.c_void_p), C.cast(res, C.c_void_p)), "global_planner_plan")
         return list(res)
 
     def path(self, plan=0):

@@ -176,6 +176,55 @@ struct GlobalPlannerOracle {
     cycles_used = cycle;
     return cycle < cycles;
   }
+  // The fixed point of DijkstraExpansion::updateCell's rule (dijkstra.cpp:170-229: getCost, then PotentialCalculator or
+  // QuadraticCalculator on the cost narrowed to unsigned char) from the same seeds: a FIFO relaxation until no cell changes -
+  // no 10 000-entry buffers, no push tests, no early stop.  The checker of the HIP path's tiled wavefront mode
+  // (navgpu_global_planner_plan_wavefront); see NavFnOracle::propagateFixedPoint for what "fixed point" means here.
+  bool dijkstraFixedPoint(double start_x, double start_y, double end_x, double end_y, bool precise) {
+    std::fill(potential.begin(), potential.end(), kPotHigh);
+    std::vector<int> fifo;
+    std::vector<uint8_t> queued(ns, 0);
+    size_t head = 0;
+    auto push = [&](int n) {
+      if (n >= nx && n < ns - nx && !queued[n] && getCost(n) < p.lethal_cost) {
+        queued[n] = 1;
+        fifo.push_back(n);
+      }
+    };
+    const int k = (int)start_x + nx * (int)start_y;
+    if (precise) {  // dijkstra.cpp:88-103
+      double dx = start_x - (int)start_x, dy = start_y - (int)start_y;
+      dx = floorf(dx * 100 + 0.5) / 100;
+      dy = floorf(dy * 100 + 0.5) / 100;
+      potential[k] = p.neutral_cost * 2 * dx * dy;
+      potential[k + 1] = p.neutral_cost * 2 * (1 - dx) * dy;
+      potential[k + nx] = p.neutral_cost * 2 * dx * (1 - dy);
+      potential[k + nx + 1] = p.neutral_cost * 2 * (1 - dx) * (1 - dy);
+      for (int c : {k, k + 1, k + nx, k + nx + 1})
+        for (int d : {c, c - 1, c + 1, c - nx, c + nx}) push(d);
+    } else {
+      potential[k] = 0;
+      for (int d : {k - 1, k + 1, k - nx, k + nx}) push(d);
+    }
+    while (head < fifo.size()) {
+      const int n = fifo[head++];
+      queued[n] = 0;
+      const float pot = calculatePotential((uint8_t)getCost(n), n);
+      if (pot < potential[n]) {
+        potential[n] = pot;
+        push(n - 1);
+        push(n + 1);
+        push(n - nx);
+        push(n + nx);
+      }
+      if (head > (1u << 22)) {
+        fifo.erase(fifo.begin(), fifo.begin() + head);
+        head = 0;
+      }
+    }
+    cycles_used = 0;
+    return potential[(int)end_x + nx * (int)end_y] < kPotHigh;
+  }
   // AStarExpansion::calculatePotentials + add (astar.cpp:46-95), std::push_heap / pop_heap with greater1
   struct Index {
     int i;
@@ -351,11 +400,14 @@ struct GlobalPlannerOracle {
   // The part of GlobalPlanner::makePlan between worldToMap and the plan assembly (planner_core.cpp:250-306): start / goal
   // are map coordinates as makePlan computes them (cell index, or (w - origin) / res - 0.5 without old_navfn_behavior).
   // Returns found_legal && getPath; the path is the traceback's own (goal first), before getPlanFromPotential reverses it.
-  bool plan(const uint8_t* cmap, double start_x, double start_y, double goal_x, double goal_y, int goal_x_i, int goal_y_i, bool* found_legal) {
+  bool plan(const uint8_t* cmap, double start_x, double start_y, double goal_x, double goal_y, int goal_x_i, int goal_y_i, bool* found_legal,
+            bool fixed_point = false) {
     memcpy(costs.data(), cmap, (size_t)ns);
     if (p.outline_map) outlineMap(254);  // costmap_2d::LETHAL_OBSTACLE
     bool legal;
-    if (p.use_dijkstra)
+    if (fixed_point)
+      legal = dijkstraFixedPoint(start_x, start_y, goal_x, goal_y, !p.old_navfn_behavior);
+    else if (p.use_dijkstra)
       legal = dijkstra(start_x, start_y, goal_x, goal_y, nx * ny * 2, !p.old_navfn_behavior);  // setPreciseStart(true) unless old behaviour (planner_core.cpp:124-127)
     else
       legal = astar(start_x, start_y, goal_x, goal_y, nx * ny * 2);

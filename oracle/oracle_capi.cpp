@@ -788,7 +788,8 @@ int orc_navfn_fixed_point(const uint8_t* cmap, int nx, int ny, int cost_mode, in
   return len;
 }
 // ------------------------------------------------------------------ global_planner (second half)
-// params = {use_dijkstra, use_quadratic, use_grid_path, old_navfn_behavior, allow_unknown, lethal_cost, neutral_cost, outline_map}
+// params = {use_dijkstra, use_quadratic, use_grid_path, old_navfn_behavior, allow_unknown, lethal_cost, neutral_cost, outline_map,
+//           fixed_point (1: the Dijkstra rule's fixed point instead of the reference-order expansion - the wavefront mode's checker)}
 int orc_global_planner_plan(const uint8_t* cmap, int nx, int ny, const int* params, float cost_factor, const double* start_xy, const double* goal_xy,
                             const int* goal_cell, float* potential_out, float* path_xy, int path_cap, int* found_legal, int* cycles_used) {
   GlobalPlannerParams p;
@@ -803,7 +804,7 @@ int orc_global_planner_plan(const uint8_t* cmap, int nx, int ny, const int* para
   p.cost_factor = cost_factor;
   GlobalPlannerOracle gp(nx, ny, p);
   bool legal = false;
-  const bool ok = gp.plan(cmap, start_xy[0], start_xy[1], goal_xy[0], goal_xy[1], goal_cell[0], goal_cell[1], &legal);
+  const bool ok = gp.plan(cmap, start_xy[0], start_xy[1], goal_xy[0], goal_xy[1], goal_cell[0], goal_cell[1], &legal, /*fixed_point=*/params[8] != 0);
   if (found_legal) *found_legal = legal;
   if (cycles_used) *cycles_used = gp.cycles_used;
   if (potential_out) memcpy(potential_out, gp.potential.data(), sizeof(float) * (size_t)nx * ny);

@@ -597,7 +597,7 @@ GP_DEFAULTS = dict(use_dijkstra=1, use_quadratic=1, use_grid_path=0, old_navfn_b
                    outline_map=1, cost_factor=3.0)
 
 
-def global_planner_plan(cmap, start_xy, goal_xy, goal_cell, **params):
+def global_planner_plan(cmap, start_xy, goal_xy, goal_cell, fixed_point=False, **params):
     """global_planner (global_planner_oracle.hpp): the expansion + traceback of GlobalPlanner::makePlan on map coordinates.
     Returns (path (n, 2) float32 goal first, potential (ny, nx) float32, found_legal, cycles)."""
     pr = dict(GP_DEFAULTS)
@@ -609,7 +609,7 @@ def global_planner_plan(cmap, start_xy, goal_xy, goal_cell, **params):
     path = np.zeros((min(cap, 1 << 22), 2), np.float32)
     legal, cyc = C.c_int(), C.c_int()
     ints = np.array([pr[k] for k in ("use_dijkstra", "use_quadratic", "use_grid_path", "old_navfn_behavior", "allow_unknown", "lethal_cost",
-                                     "neutral_cost", "outline_map")], np.int32)
+                                     "neutral_cost", "outline_map")] + [int(fixed_point)], np.int32)
     n = lib().orc_global_planner_plan(g, nx, ny, ints, float(pr["cost_factor"]), np.ascontiguousarray(start_xy, np.float64),
                                       np.ascontiguousarray(goal_xy, np.float64), np.ascontiguousarray(goal_cell, np.int32), pot.ctypes.data,
                                       path.ctypes.data, len(path), C.byref(legal), C.byref(cyc))

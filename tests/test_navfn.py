@@ -398,6 +398,102 @@ def test_global_planner_on_willow(orc, willow):
     nf.close()
 
 
+# ------------------------------------------------------------------------------------------------ global_planner, tiled wavefront
+GP_WF_VARIANTS = [dict(), dict(use_quadratic=0), dict(use_grid_path=1), dict(old_navfn_behavior=1), dict(allow_unknown=0, cost_factor=0.55, neutral_cost=66)]
+
+
+def _gp_cost(cm, kw):
+    """DijkstraExpansion::getCost (dijkstra.h:78-87) of every cell, lethal where it is not traversable."""
+    pr = dict(lethal_cost=253, neutral_cost=50, cost_factor=3.0, allow_unknown=1)
+    pr.update({k: v for k, v in kw.items() if k in pr})
+    c = cm.astype(np.float32)
+    ok = (c < pr["lethal_cost"] - 1) | ((c == 255) & bool(pr["allow_unknown"]))
+    out = np.full(cm.shape, float(pr["lethal_cost"]), np.float32)
+    out[ok] = np.minimum(c[ok] * np.float32(pr["cost_factor"]) + pr["neutral_cost"], pr["lethal_cost"] - 1)
+    return out
+
+
+def _check_gp_wavefront(orc, nf, k, res, cm, start, goal, kw, against_reference_path=True):
+    cell = [int(goal[0]), int(goal[1])]
+    fpath, fpot, flegal, _ = orc.global_planner_plan(cm, start, goal, cell, fixed_point=True, **kw)
+    path, pot, legal, _ = orc.global_planner_plan(cm, start, goal, cell, **kw)
+    g = nf.potential(k)
+    pg = g[cell[1], cell[0]]
+    assert (pg < 1e9) == flegal == legal
+    # Expander::clearEndpoint fills the 5 x 5 block round the goal with potentials of a cheaper cost (costs + neutral) wherever the
+    # expansion had not reached: what it finds there depends on where the expansion stopped, so that block is left out
+    far = np.ones(cm.shape, bool)
+    far[max(cell[1] - 2, 0):cell[1] + 3, max(cell[0] - 2, 0):cell[0] + 3] = False
+    settled = (fpot < pg) & far if flegal else far
+    a, b = g[settled], fpot[settled]
+    assert ((a >= 1e9) == (b >= 1e9)).all()
+    fin = b < 1e9
+    if fin.any():  # (the rule's order dependence is 0.46 % of a cell's cost per cell, and getCost's costs reach 252: 3e-3 observed)
+        assert (np.abs(a[fin] - b[fin]) / np.maximum(b[fin], 1.0)).max() <= 1e-2
+    m = (pot < 1e9) & far
+    assert not (g[m] > pot[m] * (1 + 1e-2)).any()        # never above the reference-order array
+    gpath = nf.path(k)
+    assert bool(res.found) == (len(gpath) > 0) and res.path_length == len(gpath)
+    assert (len(gpath) > 0) == (len(fpath) > 0)
+    if len(gpath):
+        ca = _gp_cost(cm, kw)
+        assert np.array_equal(gpath[0], fpath[0]) and np.array_equal(gpath[-1], fpath[-1])
+        assert _path_cost(gpath, ca) <= 1.03 * _path_cost(fpath, ca) + 1.0
+        if len(path) and against_reference_path:
+            assert _path_cost(gpath, ca) <= 1.06 * _path_cost(path, ca) + 1.0
+    return len(gpath) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", GP_WF_VARIANTS)
+def test_global_planner_wavefront_batch(orc, kw):
+    """navgpu_global_planner_plan_wavefront: DijkstraExpansion's rule relaxed to its fixed point by LDS tiles, then the reference's
+    own clearEndpoint + traceback; against the oracle's fixed point (potentials, path cost) and its reference-order run (contract)."""
+    import navigation_amd as nav
+    rs = np.random.RandomState(33)
+    n, nI = 110, 6
+    cases = [_gp_case(rs, n) for _ in range(nI)]
+    nf = nav.NavFn(n, n, nI)
+    nf.set_costmap(np.stack([c[0] for c in cases]), cost_mode=0)
+    starts = np.array([c[1] for c in cases])
+    goals = np.array([c[2] for c in cases])
+    if kw.get("old_navfn_behavior"):
+        starts, goals = np.floor(starts), np.floor(goals)
+    cells = goals.astype(np.int32)
+    res = nf.global_planner_plan(starts, goals, cells, wavefront=True, **kw)
+    # GradientPath's half-cell descent zig-zags for dozens of points next to the single-cell cost spikes of these maps - in the
+    # reference-order array and in the fixed point alike, for different numbers of steps - so path against path is compared for
+    # GridPath only here (and for both tracebacks on the reference's willow map below); potentials are compared for every variant
+    n_found = sum(_check_gp_wavefront(orc, nf, k, res[k], cases[k][0], starts[k], goals[k], kw, against_reference_path=bool(kw.get("use_grid_path")))
+                  for k in range(nI))
+    assert n_found >= 2
+    again = nf.global_planner_plan(starts, goals, cells, wavefront=True, **kw)
+    assert [(r.found, r.path_length, r.cycles) for r in again] == [(r.found, r.path_length, r.cycles) for r in res]
+    with pytest.raises(nav.NavgpuError):
+        nf.global_planner_plan(starts, goals, cells, wavefront=True, use_dijkstra=0)
+    # the reference-order call on the same handle afterwards: still bit-exact
+    res = nf.global_planner_plan(starts, goals, cells, **kw)
+    for k in range(nI):
+        path, pot, legal, cyc = orc.global_planner_plan(cases[k][0], starts[k], goals[k], cells[k], **kw)
+        assert res[k].cycles == cyc and np.array_equal(nf.potential(k).view(np.uint32), pot.view(np.uint32))
+        assert np.array_equal(nf.path(k).view(np.uint32), path.view(np.uint32))
+    nf.close()
+
+
+@pytest.mark.gpu
+def test_global_planner_wavefront_on_willow(orc, willow):
+    import navigation_amd as nav
+    ny, nx = willow.shape
+    nf = nav.NavFn(nx, ny, 2)
+    nf.set_costmap(willow, cost_mode=0)
+    starts, goals = np.array([[428.3, 746.6], [350.5, 400.5]]), np.array([[350.4, 450.2], [350.5, 450.5]])
+    for kw in (dict(lethal_cost=255), dict(lethal_cost=255, cost_factor=0.2, use_quadratic=0)):
+        res = nf.global_planner_plan(starts, goals, np.floor(goals).astype(np.int32), wavefront=True, **kw)
+        for k in range(2):
+            assert _check_gp_wavefront(orc, nf, k, res[k], willow, starts[k], goals[k], kw)
+    nf.close()
+
+
 # ------------------------------------------------------------------------------------------------ oracle/_ref: global_planner pieces
 def test_ref_potential_calculators_match_oracle(orc):
     """The reference's own PotentialCalculator / QuadraticCalculator (compiled in place into oracle/_ref/libref_gp.so)
