@@ -84,4 +84,10 @@ uint32_t score_table_rows(const PlannerDev&, uint32_t) { return 4; }
 void launch_navfn_costmap(const NavfnDev&, uint32_t, uint32_t, const uint8_t*, size_t, int, int, hipStream_t) {}
 void launch_gp_plan(const NavfnDev&, uint32_t, uint32_t, const navgpu_global_planner_params&, const double*, const double*, const int32_t*, void*, hipStream_t) {}
 void launch_navfn_plan(const NavfnDev&, uint32_t, uint32_t, const int32_t*, const int32_t*, int, int, hipStream_t) {}
+void launch_navfn_wf_init(const NavfnDev&, uint32_t, uint32_t, const NavfnWfRule&, const int32_t*, const float*, hipStream_t) {}
+void launch_navfn_wf_round(const NavfnDev& nv, uint32_t first, uint32_t count, const NavfnWfRule&, const int32_t*, int, int, hipStream_t) {
+  for (uint32_t i = first; i < first + count; ++i) nv.wf_status[i].done = 1;  // a search that settles at once
+}
+void launch_navfn_wf_path(const NavfnDev&, uint32_t, uint32_t, const int32_t*, const int32_t*, hipStream_t) {}
+void launch_gp_wf_finish(const NavfnDev&, uint32_t, uint32_t, const navgpu_global_planner_params&, const double*, const double*, const int32_t*, hipStream_t) {}
 }  // namespace navgpu
