@@ -398,6 +398,38 @@ def test_global_planner_on_willow(orc, willow):
     nf.close()
 
 
+@pytest.mark.gpu
+def test_navfn_wavefront_tile_edges_and_small_maps(orc):
+    """Seeds on tile borders (the neighbour tile has to start in round 0 even when the seed's own border cells are obstacles),
+    maps smaller than a tile, ragged last tiles, a start next to the goal, a start on an obstacle."""
+    import navigation_amd as nav
+    cases = []
+    cm = np.zeros((70, 70), np.uint8)        # goal in the corner cell of tile (1, 1); its tile-side neighbours are walls
+    cm[33, 32] = cm[32, 33] = cm[33, 33] = 254
+    cases.append((cm, (32, 32), (5, 60)))
+    cm = np.zeros((70, 70), np.uint8)        # goal in the last column of tile (0, 0), walls above and below it
+    cm[9, 31] = cm[11, 31] = cm[10, 30] = 254
+    cases.append((cm, (31, 10), (60, 50)))
+    cm = np.zeros((9, 9), np.uint8)          # one partial tile
+    cases.append((cm, (2, 2), (6, 6)))
+    cm = np.zeros((33, 65), np.uint8)        # 3 x 2 tiles, the last ones one cell wide / high
+    cm[16, 5:60] = 254
+    cases.append((cm, (10, 5), (60, 28)))
+    cm = np.zeros((40, 40), np.uint8)        # start beside the goal
+    cases.append((cm, (20, 20), (21, 20)))
+    cm = np.zeros((40, 40), np.uint8)        # start on an obstacle: never reached
+    cm[30, 30] = 254
+    cases.append((cm, (8, 8), (30, 30)))
+    for cm, goal, start in cases:
+        ny, nx = cm.shape
+        nf = nav.NavFn(nx, ny, 1)
+        nf.set_costmap(cm, cost_mode=1)
+        for at_start in (True, False):
+            res = nf.plan_wavefront([goal], [start], at_start=at_start)
+            _check_wavefront_plan(orc, nf, 0, res[0], cm, goal, start, 1, at_start=at_start)
+        nf.close()
+
+
 # ------------------------------------------------------------------------------------------------ global_planner, tiled wavefront
 GP_WF_VARIANTS = [dict(), dict(use_quadratic=0), dict(use_grid_path=1), dict(old_navfn_behavior=1), dict(allow_unknown=0, cost_factor=0.55, neutral_cost=66)]
 
