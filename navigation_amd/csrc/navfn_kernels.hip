@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_navfn_plan(NavfnDev nv, uint32_t first,
 // the last block half done): potentials here are <= the reference's, and the path differs from the reference's by a
 // fraction of a cell (tests/test_navfn.py).  The reference-order mode stays the bit-exact one.
 // ------------------------------------------------------------------------------------------------
-constexpr int kWfTile = 32, kWfThreads = 256, kWfMaxSweeps = 160;
+constexpr int kWfTile = 32, kWfThreads = 256;
 constexpr uint32_t kWfCopy = 1u, kWfCompute = 2u;
 
 // hf of a cell under a rule: its cost as the update sees it, < 0 = never updated.  navfn: costarr itself, obstacles from COST_OBS
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_navfn_wf_init(NavfnDev nv, uint32_t fir
 __global__ __launch_bounds__(kWfThreads) void k_navfn_wf_round(NavfnDev nv, uint32_t first, NavfnWfRule rule, const int32_t* stop_cells, int at_start, int round) {
   __shared__ float sP[kWfTile + 2][kWfTile + 4];
   __shared__ float sH[kWfTile][kWfTile];
-  __shared__ uint32_t s_sides, s_min;
+  __shared__ uint32_t s_sides, s_min, s_chg[2];
   const uint32_t plan = first + blockIdx.y;
   const int nx = nv.nx, ny = nv.ny;
   const int tiles = nv.wf_tiles_x * nv.wf_tiles_y;
@@ -396,6 +396,7 @@ __global__ __launch_bounds__(kWfThreads) void k_navfn_wf_round(NavfnDev nv, uint
   if (tid == 0) {
     s_sides = 0;
     s_min = 0xFFFFFFFFu;
+    s_chg[0] = s_chg[1] = 0u;
   }
   const int x0 = tx * kWfTile, y0 = ty * kWfTile;
   // ---- load: interior (4 cells per thread, rows of 32 floats), then the halo ring; off the map = an unreached obstacle
@@ -426,18 +427,36 @@ __global__ __launch_bounds__(kWfThreads) void k_navfn_wf_round(NavfnDev nv, uint
     uint32_t sides = 0;
     float low = kPotHigh * 4.0f;
     int sweeps = 0;
+    // a lane's four cells (two per colour): their costs, and the two neighbour minima their last update was computed from - the
+    // update is a function of those and the cost alone, so a cell whose minima have not moved is skipped (most cells, most
+    // sweeps: the front inside a tile is a cell or two wide)
+    float hf4[4], seen_h[4], seen_v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + kWfThreads * (q & 1), row = i >> 4, col = 2 * (i & 15) + ((row + (q >> 1)) & 1);
+      hf4[q] = sH[row][col];
+      seen_h[q] = seen_v[q] = -1.0f;  // (no potential is negative)
+    }
+    // "did anything change this sweep" through two alternating LDS flags (any lane that lowers a cell sets this sweep's flag; the
+    // other flag is cleared between the two barriers of the sweep, when nobody reads or sets it): two barriers per sweep, where
+    // __syncthreads_or costs three of its own
     for (;;) {
       int changed = 0;
+      volatile uint32_t* flag = &s_chg[sweeps & 1];
 #pragma unroll
       for (int colour = 0; colour < 2; ++colour) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int i = tid + kWfThreads * k, row = i >> 4, col = 2 * (i & 15) + ((row + colour) & 1);
-          const float hf = sH[row][col];
+          const int q = 2 * colour + k;
+          const float hf = hf4[q];
           const float l = sP[row + 1][col], r = sP[row + 1][col + 2], u = sP[row][col + 1], d = sP[row + 2][col + 1];
           float ta, tc;
           if (l < r) tc = l; else tc = r;
           if (u < d) ta = u; else ta = d;
+          if (tc == seen_h[q] && ta == seen_v[q]) continue;
+          seen_h[q] = tc;
+          seen_v[q] = ta;
           float dc = tc - ta;
           if (dc < 0) {
             dc = -dc;
@@ -460,12 +479,19 @@ __global__ __launch_bounds__(kWfThreads) void k_navfn_wf_round(NavfnDev nv, uint
             sides |= (row == 0 ? 1u : 0u) | (row == kWfTile - 1 ? 2u : 0u) | (col == 0 ? 4u : 0u) | (col == kWfTile - 1 ? 8u : 0u);
           }
         }
-        if (colour == 0) __syncthreads();
+        if (colour == 0) {
+          if (changed) *flag = 1u;
+          changed = 0;
+          __syncthreads();
+          if (tid == 0) s_chg[(sweeps + 1) & 1] = 0u;
+        }
       }
-      const int any = __syncthreads_or(changed);
+      if (changed) *flag = 1u;
+      __syncthreads();
+      const uint32_t any = *flag;
       if (!any) break;
       any_change = true;
-      if (++sweeps >= kWfMaxSweeps) {  // a maze inside the tile: go on next round
+      if (++sweeps >= rule.max_sweeps) {  // go on next round, with the neighbours' news
         capped = true;
         break;
       }

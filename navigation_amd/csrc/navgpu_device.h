@@ -294,6 +294,7 @@ struct NavfnWfRule {
   int32_t global_planner, quadratic, outline, allow_unknown;
   int32_t lethal_cost, neutral_cost;
   float cost_factor;
+  int32_t max_sweeps;  // red / black sweeps of a tile per round
 };
 void launch_navfn_wf_init(const NavfnDev& nv, uint32_t first, uint32_t count, const NavfnWfRule& rule, const int32_t* seed_cells, const float* seed_vals,
                           hipStream_t s);

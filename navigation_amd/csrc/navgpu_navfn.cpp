@@ -155,10 +155,12 @@ int navgpu_navfn_plan(navgpu_navfn* h, uint32_t first, uint32_t count, const int
 // The expansion as a tiled wavefront (navfn_kernels.hip: k_navfn_wf_*): rounds are queued a batch at a time, the per-plan
 // status (done / which array / rounds) is read between batches; a round launched after its plan has finished leaves at once.
 // seeds = count x 4 (cell, value) pairs (cell < 0: unused), stop_cells = count cells whose potential ends the search.
-static int runWavefront(navgpu_navfn* h, uint32_t first, uint32_t count, const NavfnWfRule& rule, const int32_t* seed_cells, const float* seed_vals,
+static int runWavefront(navgpu_navfn* h, uint32_t first, uint32_t count, const NavfnWfRule& rule_in, const int32_t* seed_cells, const float* seed_vals,
                         const int32_t* stop_cells, int at_start) {
   NavfnDev& nv = h->nv;
   constexpr int kTile = 32, kMaxRounds = 8192, kBatch = 16;
+  NavfnWfRule rule = rule_in;
+  rule.max_sweeps = getenv("NAVGPU_DEBUG_WF_SWEEPS") ? std::max(1, atoi(getenv("NAVGPU_DEBUG_WF_SWEEPS"))) : 32;  // (a tile the front crosses once settles within 32; measured: 4 ... 160 give the same plan time)
   if (!nv.potalt) {
     nv.wf_tiles_x = (nv.nx + kTile - 1) / kTile;
     nv.wf_tiles_y = (nv.ny + kTile - 1) / kTile;
