@@ -3547,7 +3547,9 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   }
   __syncthreads();
 #ifdef NAVGPU_SCORE_TIMING
-  if (PREP == 2 && (tid & 63) == 0) {
+  // (one workgroup in 256 reports: with every wave adding to the same few words the atomics themselves stretched the launch sixfold
+  // and made the prologue look like 39 % of a workgroup's residence; sampled, it is 6 %)
+  if (PREP == 2 && (tid & 63) == 0 && (blockIdx.x & 15) == 3 && (blockIdx.y & 15) == 5) {
     const unsigned long long ts3 = wall_clock64();
     atomicAdd(&g_score_stats[16], ts1 - ts0);  // image load, per wave
     atomicAdd(&g_score_stats[22], ts0a - ts0);  // ... of which: staging of footprint / axis samples up to the first barrier
