@@ -267,6 +267,11 @@ def test_navfn_wavefront_willow_cases(orc, willow):
         assert _check_wavefront_plan(orc, nf, k, res[k], willow, goal, start, 0)
         path, _, _ = orc.navfn_plan(willow, goal, start, cost_mode=0)
         assert _hausdorff(nf.path(k), path) <= 1.0
+    # at_start off: the whole reachable map settles (no early stop), both searches at once
+    res = nf.plan_wavefront(goals, starts, at_start=False)
+    for k, (start, goal) in enumerate(WILLOW_CASES):
+        assert _check_wavefront_plan(orc, nf, k, res[k], willow, goal, start, 0, at_start=False)
+        assert res[k].cycles > first[k][2]
     res = nf.plan_wavefront(goals, starts)
     for k in range(2):
         assert res[k].cycles == first[k][2]
