@@ -214,6 +214,11 @@ int navgpu_fleet_create(const navgpu_fleet_desc* desc, navgpu_fleet** out);
 int navgpu_fleet_destroy(navgpu_fleet* fleet);
 int navgpu_sync(navgpu_fleet* fleet);
 void* navgpu_stream(navgpu_fleet* fleet); /* the fleet's hipStream_t */
+/* Fault injection for tests (the counterpart of the reference's ObstacleLayer::addStaticObservation test hook,
+ * costmap_2d/plugins/obstacle_layer.cpp:450-464): device allocations of this fleet larger than max_bytes fail with
+ * NAVGPU_ERR_HIP from now on; 0 = no limit (default).  Used to check that a failed reconfigure leaves the previous
+ * configuration in force. */
+int navgpu_fleet_set_alloc_limit(navgpu_fleet* fleet, uint64_t max_bytes);
 
 /* Costmap2D origin per instance (costmap_2d.h origin_x_/origin_y_); origins_xy = count x {x,y}.
  * replaces: LayeredCostmap::resizeMap origin arguments (layered_costmap.cpp:67-77) */

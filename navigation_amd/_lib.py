@@ -198,6 +198,7 @@ SYMBOLS = [
     ("navgpu_fleet_create", C.c_int, [C.POINTER(FleetDesc), C.POINTER(vp)]),
     ("navgpu_fleet_destroy", C.c_int, [vp]),
     ("navgpu_sync", C.c_int, [vp]),
+    ("navgpu_fleet_set_alloc_limit", C.c_int, [vp, C.c_uint64]),
     ("navgpu_stream", vp, [vp]),
     ("navgpu_fleet_set_origin", C.c_int, [vp, u32, u32, vp]),
     ("navgpu_fleet_get_origin", C.c_int, [vp, u32, u32, vp]),

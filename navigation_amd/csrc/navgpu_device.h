@@ -32,6 +32,13 @@ constexpr int kCareRows = 128, kCareWords = 4;  // bounded wavefronts: extent of
 #ifndef NAVGPU_SCORE_THREADS
 #define NAVGPU_SCORE_THREADS 256
 #endif
+// A/B and trace switches read from the environment exist in tool builds only (make EXTRA=-DNAVGPU_DEBUG_SWITCHES, tools/):
+// the library that is loaded into move_base reads no environment variable.
+#ifdef NAVGPU_DEBUG_SWITCHES
+#define NAVGPU_DEBUG_ENV(name) getenv(name)
+#else
+#define NAVGPU_DEBUG_ENV(name) ((const char*)nullptr)
+#endif
 constexpr int kScoreThreads = NAVGPU_SCORE_THREADS;  // samples per k_score workgroup  // vertices kept in registers/LDS by the kernels
 
 struct InstCostmapState {  // per-instance state that persists across update cycles (device resident)
@@ -142,7 +149,7 @@ struct PlannerDev {
   uint32_t* bfs_levels;       // [n][3] levels the last wavefront of (robot, grid) ran: predicts the next one's length
   uint32_t* bfs_order;        // [n * 3] items of a launch sorted longest first, stored at first * 3 (k_samples)
   uint32_t bfs_grids;         // wavefronts per robot: 3 (DWA: path, goal, goal_front) or 2 (legacy TrajectoryPlanner)
-  const uint32_t* within;     // [n][ny][W] MapCell::within_robot bits of path_map_ (legacy planner), else null
+  uint32_t* within;           // legacy planner: [n][ny][W] MapCell::within_robot bits of path_map_ on entry to launch_bfs, whose k_free_bits ORs the costmap's free bits in (= path_map_'s traversable-cell bitmap); else null
   uint32_t win;               // edge (cells) of the costmap window staged in LDS by k_score
   uint32_t fp_rcells;         // Chebyshev radius (cells) that contains every footprint cell around the centre cell
   uint32_t fp_chunk;          // cells of the longest footprint edge (+1): picks the k_score<CHUNK> instantiation
@@ -211,7 +218,7 @@ void launch_shift_u32(const uint32_t* src, uint32_t* dst, const CostmapDev& cm, 
 
 void launch_cell_costs(const PlannerDev& pl, uint32_t inst, float4* out, hipStream_t s);
 void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s);
-void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order = nullptr, bool free_ready = false, int n_whole = -1);
+void launch_bfs(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s, const uint32_t* order = nullptr, bool free_ready = false);
 uint32_t launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s);  // returns blocks per instance
 void launch_select(const PlannerDev& pl, uint32_t first, uint32_t count, uint32_t n_blocks, hipStream_t s);
 // the poses of up to 64 robots as one kernel-argument block (< 4 KB)
@@ -230,12 +237,9 @@ struct PoseChunk {
 static_assert(sizeof(PoseChunk) <= 4096, "kernel arguments are limited to 4 KB");
 void launch_stage_poses(const PoseChunk& c, hipStream_t s);
 void launch_sincos(const double* th, uint32_t n, double* sn, double* cs, hipStream_t s);
-size_t bfs_lds_bytes(uint32_t nx, uint32_t ny);
-bool bfs_bounded_applies(const PlannerDev& pl);  // the wavefront kernel launch_bfs picks for this map can stop at the robot's box
 size_t score_table_bytes(const PlannerDev& pl);
 size_t score_window_bytes(uint32_t win);
 size_t score_prep_bytes(const PlannerDev& pl);
-bool bfs_lds_resident(uint32_t nx, uint32_t ny);
 size_t bfs_scratch_words(uint32_t nx, uint32_t ny);
 uint32_t score_table_rows(const PlannerDev& pl, uint32_t win);
 

@@ -132,6 +132,7 @@ struct navgpu_fleet {
   float* d_explicit = nullptr;                  // [3]
   int8_t* d_occ = nullptr;
   float4* d_cell_costs = nullptr;                // [cells] navgpu_planner_cost_cloud
+  size_t alloc_limit = 0;                       // fault injection (navgpu_fleet_set_alloc_limit); 0 = none
   // profiling
   bool profiling = false;
   uint32_t prof_mask = ~0u;                     // kernels bracketed by events while profiling (navgpu_profile_select)
@@ -144,11 +145,10 @@ struct navgpu_fleet {
   int alloc(T** p, size_t count) {
     void* q = nullptr;
     size_t bytes = std::max<size_t>(count * sizeof(T), 16);
-    if (const char* lim = getenv("NAVGPU_DEBUG_ALLOC_LIMIT"))  // tests: make a large allocation fail on purpose
-      if (bytes > strtoull(lim, nullptr, 10)) {
-        g_last_error = "hipMalloc: refused by NAVGPU_DEBUG_ALLOC_LIMIT";
-        return NAVGPU_ERR_HIP;
-      }
+    if (alloc_limit && bytes > alloc_limit) {  // navgpu_fleet_set_alloc_limit: tests make a large allocation fail on purpose
+      g_last_error = "hipMalloc: refused by navgpu_fleet_set_alloc_limit";
+      return NAVGPU_ERR_HIP;
+    }
     hipError_t e = hipMalloc(&q, bytes);
     if (e != hipSuccess) {
       g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e);

@@ -226,7 +226,7 @@ int navgpu_fleet_create(const navgpu_fleet_desc* d, navgpu_fleet** out) {
   f->h_fp_spec.assign((size_t)n * kMaxFootprint * 2, 0.0);
   f->h_fp_n.assign(n, 0);
   f->grid_partial.assign(n, 0);
-  f->bounded_grids = getenv("NAVGPU_DEBUG_COMPLETE_GRIDS") == nullptr;  // A/B timing only; the API switch is navgpu_planner_set_bounded_map_grids
+  f->bounded_grids = true;  // navgpu_planner_set_bounded_map_grids
   f->h_box.assign((size_t)n * 4, 0);
   f->inputs_gen.assign(n, 0);
   f->cycle_gen.assign(n, 0);
@@ -282,6 +282,12 @@ int navgpu_sync(navgpu_fleet* f) {
   return NAVGPU_OK;
 }
 void* navgpu_stream(navgpu_fleet* f) { return f ? (void*)f->stream : nullptr; }
+int navgpu_fleet_set_alloc_limit(navgpu_fleet* f, uint64_t max_bytes) {
+  if (!f) return NAVGPU_ERR_INVALID;
+  FleetGuard guard_(f);
+  f->alloc_limit = (size_t)max_bytes;
+  return NAVGPU_OK;
+}
 
 int navgpu_fleet_set_origin(navgpu_fleet* f, uint32_t first, uint32_t count, const double* xy) {
   if (!f || !xy || !f->rangeOk(first, count)) return NAVGPU_ERR_INVALID;
@@ -990,7 +996,7 @@ static double reachMetres(const navgpu_dwa_config& c, const float vel[3], const 
   return hypot(bx, by) * c.sim_time * 1.001 + fabs(c.forward_point_distance);
 }
 static uint32_t bfsReachCells(const navgpu_fleet* f, const navgpu_robot_state& s, double goal_x, double goal_y) {
-  if (!f->bounded_grids || !bfs_bounded_applies(f->pl)) return 0;
+  if (!f->bounded_grids) return 0;  // (every wavefront kernel can stop at the robot's box)
   if (f->pl.mg_generic) return 0;  // (a sideways-shifted look-up leaves the box the reach is derived for: whole grids)
   const double reach = reachMetres(f->pl.cfg, s.vel, nullptr);
   const double cells = ceil(reach / f->pl.res) + kBoxMarginCells;
@@ -1017,8 +1023,7 @@ static bool robotBox(const navgpu_fleet* f, uint32_t i, const float pos[3], uint
 }
 // finish the grids of robots whose last wavefronts stopped early; fails when their inputs have changed since
 extern "C++" int navgpu::ensureCompleteGrids(navgpu_fleet* f, uint32_t first, uint32_t count) {
-  static const bool raw = getenv("NAVGPU_DEBUG_RAW_GRIDS") != nullptr;  // tools/probe_levels.py: look at what a bounded search left
-  if (raw) return NAVGPU_OK;
+  if (NAVGPU_DEBUG_ENV("NAVGPU_DEBUG_RAW_GRIDS")) return NAVGPU_OK;  // tool builds only (tools/probe_levels.py): look at what a bounded search left
   for (uint32_t i = first; i < first + count; ++i)
     if (f->grid_partial[i] && f->cycle_gen[i] != f->inputs_gen[i]) {
       g_last_error = "MapGrids of instance " + std::to_string(i) + " were searched inside the robot's box only and the costmap / plan they came from has changed; "
@@ -1307,24 +1312,27 @@ int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
     pl.result = f->hp_result + (size_t)f->res_slot * f->desc.n_instances;
   }
   pl.bfs_bounded = 1;  // per robot: bfs_reach (0 = whole grid)
-  int n_whole = 0;  // robots that search their whole grids this cycle (near the end of their plan, off the map, bounding off)
   for (uint32_t i = first; i < first + count; ++i) {
     f->grid_partial[i] = robotBox(f, i, f->hp_state[i].pos, f->hp_reach[i], &f->h_box[(size_t)4 * i]) ? 1 : 0;
-    n_whole += f->grid_partial[i] ? 0 : 1;
     f->cycle_gen[i] = f->inputs_gen[i];
   }
   launch_samples(pl, first, count, f->stream);
+#ifdef NAVGPU_DEBUG_SWITCHES  // tool builds only (tools/trace_bfs.py): per-item phase stamps of the wavefront launch, written to the named file
   if (getenv("NAVGPU_DEBUG_BFS_TRACE") && !pl.bfs_trace) f->alloc(&pl.bfs_trace, (size_t)f->desc.n_instances * 3 * 8);
-  PROFILED(f, NAVGPU_K_BFS, launch_bfs(pl, first, count, f->stream, pl.bfs_order + (size_t)first * 3, true, n_whole));
+#endif
+  PROFILED(f, NAVGPU_K_BFS, launch_bfs(pl, first, count, f->stream, pl.bfs_order + (size_t)first * 3, true));
+#ifdef NAVGPU_DEBUG_SWITCHES
   if (pl.bfs_trace) {
     std::vector<unsigned long long> h((size_t)count * 24);
     hipMemcpyAsync(h.data(), pl.bfs_trace, h.size() * 8, hipMemcpyDeviceToHost, f->stream);
     waitStream(f->stream);
-    FILE* fp = fopen(getenv("NAVGPU_DEBUG_BFS_TRACE"), "w");
-    for (size_t i = 0; i < (size_t)count * 3; ++i)
-      fprintf(fp, "%zu %llu %llu %llu %llu %llu %llu %llu %llu\n", i, h[8 * i], h[8 * i + 1] & 0xFFFFFFFFFFFFull, h[8 * i + 1] >> 48, h[8 * i + 2], h[8 * i + 3], h[8 * i + 4], h[8 * i + 5], h[8 * i + 6]);
-    fclose(fp);
+    if (FILE* fp = fopen(getenv("NAVGPU_DEBUG_BFS_TRACE"), "w")) {
+      for (size_t i = 0; i < (size_t)count * 3; ++i)
+        fprintf(fp, "%zu %llu %llu %llu %llu %llu %llu %llu %llu\n", i, h[8 * i], h[8 * i + 1] & 0xFFFFFFFFFFFFull, h[8 * i + 1] >> 48, h[8 * i + 2], h[8 * i + 3], h[8 * i + 4], h[8 * i + 5], h[8 * i + 6]);
+      fclose(fp);
+    }
   }
+#endif
   uint32_t n_blocks = 0;
   PROFILED(f, NAVGPU_K_SCORE, n_blocks = launch_score(pl, first, count, nullptr, f->stream));
   PROFILED(f, NAVGPU_K_SELECT, launch_select(pl, first, count, n_blocks, f->stream));
@@ -1367,17 +1375,8 @@ int navgpu_planner_results(navgpu_fleet* f, uint32_t first, uint32_t count, navg
   FleetGuard guard_(f);
   // zero-copy: the results already sit in pinned host memory once the stream has drained (an explicit
   // D2H copy was measured at ~4 ms per call when another HIP user, e.g. PyTorch, shares the process)
-  static const bool dbg = getenv("NAVGPU_DEBUG_TIMING") != nullptr;
-  timespec t0, t1, t2;
-  if (dbg) clock_gettime(CLOCK_MONOTONIC, &t0);
   HIP_TRY(waitStream(f->stream));
-  if (dbg) clock_gettime(CLOCK_MONOTONIC, &t1);
   memcpy(results, f->hp_result + (size_t)f->res_slot * f->desc.n_instances + first, sizeof(navgpu_plan_result) * count);
-  if (dbg) {
-    clock_gettime(CLOCK_MONOTONIC, &t2);
-    fprintf(stderr, "results: wait %.3f ms, memcpy %.3f ms\n", (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6,
-            (t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_nsec - t1.tv_nsec) * 1e-6);
-  }
   return NAVGPU_OK;
 }
 

@@ -160,7 +160,7 @@ static int runWavefront(navgpu_navfn* h, uint32_t first, uint32_t count, const N
   NavfnDev& nv = h->nv;
   constexpr int kTile = 32, kMaxRounds = 8192, kBatch = 16;
   NavfnWfRule rule = rule_in;
-  rule.max_sweeps = getenv("NAVGPU_DEBUG_WF_SWEEPS") ? std::max(1, atoi(getenv("NAVGPU_DEBUG_WF_SWEEPS"))) : 32;  // (a tile the front crosses once settles within 32; measured: 4 ... 160 give the same plan time)
+  rule.max_sweeps = NAVGPU_DEBUG_ENV("NAVGPU_DEBUG_WF_SWEEPS") ? std::max(1, atoi(NAVGPU_DEBUG_ENV("NAVGPU_DEBUG_WF_SWEEPS"))) : 32;  // (a tile the front crosses once settles within 32; measured: 4 ... 160 give the same plan time)
   if (!nv.potalt) {
     nv.wf_tiles_x = (nv.nx + kTile - 1) / kTile;
     nv.wf_tiles_y = (nv.ny + kTile - 1) / kTile;

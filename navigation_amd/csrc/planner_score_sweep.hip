@@ -1,0 +1,603 @@
+// k_score_sweep (gfx950): the product form of the scoring launch - use_dwa with a fixed step count (discretize_by_time)
+// and DWAPlanner's own MapGrid options - as a SCREENED SWEEP plus QUEUED FOOTPRINT WALKS inside one workgroup.
+//   SimpleTrajectoryGenerator::generateTrajectory / computeNewPositions (simple_trajectory_generator.cpp:180-276)
+//   SimpleScoredSamplingPlanner::scoreTrajectory (simple_scored_sampling_planner.cpp:50-79), critic order of
+//     dwa_planner.cpp:167-173: oscillation, obstacle, goal_front, alignment, path, goal
+//   ObstacleCostFunction::scoreTrajectory / footprintCost (obstacle_cost_function.cpp:74-142),
+//   WorldModel::footprintCost (world_model.h:65-86), CostmapModel::footprintCost / lineCost / pointCost
+//     (costmap_model.cpp:50-142), LineIterator (line_iterator.h:38-139)
+//   MapGridCostFunction::scoreTrajectory (map_grid_cost_function.cpp:75-129, aggregation Last)
+//   OscillationCostFunction::scoreTrajectory (oscillation_cost_function.cpp:166-176)
+//
+// Why two phases.  One lane rolls one sample out.  89 % of the trajectory points pass the per-cell screens of the robot's
+// LDS image (planner_score.hip builds it: nothing in reach of the footprint can fail, the path / goal grids hold a distance
+// here) in ~60 vector instructions; the others have to walk the footprint's outline through the costmap window, ~1 000
+// instructions with a few dozen dependent LDS round trips.  Walked where they come up (rounds 1-3: k_score_tab), a wave pays
+// for a walk whenever one of its lanes needs one - 11 % of the wave-steps, at 57 % lane density - and its 20 steps are serial.
+// Here the sweep only DECIDES: a point that needs its footprint walked is appended to a queue in LDS (pose, owner lane, step)
+// and the lane moves on.  Every kSweepBlockSteps steps the workgroup meets, all 256 lanes take queue entries - whoever
+// pushed them - and walk them side by side (every lane busy, no wave waiting for another's obstacle), and report to the
+// owner: a failed point (obstacle_cost_function.cpp:127-131 -> -6) ends the owner's rollout at the next block, the last
+// point's cost (or every point's, with sum_scores) is added up in the owner's word.  The critics' precedence is untouched:
+// scoreTrajectory returns the code of the FIRST critic in the list that fails anywhere on the trajectory, the obstacle
+// critic is the first of those a walk can fail, and the other critics' failures are kept by order as before.
+// A full queue stalls the lanes that could not push: they take the same step again in the next block.
+#include "planner_score.h"
+
+namespace navgpu {
+
+constexpr int kSweepThreads = NAVGPU_SCORE_TAB_THREADS;
+#ifndef NAVGPU_SWEEP_BLOCK_STEPS
+#define NAVGPU_SWEEP_BLOCK_STEPS 5
+#endif
+#ifndef NAVGPU_SWEEP_QUEUE
+#define NAVGPU_SWEEP_QUEUE 512
+#endif
+constexpr int kSweepBlockSteps = NAVGPU_SWEEP_BLOCK_STEPS;  // trajectory points a lane sweeps between two walk phases
+constexpr int kSweepQueue = NAVGPU_SWEEP_QUEUE;             // walk entries a workgroup holds (12 B each)
+constexpr uint32_t kWalkFailed = 0x80000000u;               // s_obs[owner]: a walked point failed; low bits: summed costs
+
+template <int CHUNK>
+__global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score_sweep(PlannerDev pl, uint32_t first) {
+  constexpr int THREADS = kSweepThreads;
+  extern __shared__ __align__(16) uint8_t s_dyn[];
+  uint8_t* s_win = s_dyn;
+  __shared__ double s_fp[2 * kMaxFootprint];
+  __shared__ float s_axis[3][kMaxAxis];
+  __shared__ double s_rc[THREADS / 64];
+  __shared__ int s_ri[THREADS / 64];
+  __shared__ int s_cnt[2];
+  __shared__ float s_qx[kSweepQueue], s_qy[kSweepQueue];
+  __shared__ uint32_t s_qt[kSweepQueue];  // owner lane | step << 8 | table row << 16 | cost wanted << 31
+  __shared__ uint32_t s_obs[THREADS];
+  __shared__ uint32_t s_qn[2];
+
+  const uint32_t inst = first + blockIdx.y;
+  const uint32_t tid = threadIdx.x;
+  __builtin_amdgcn_s_setprio(3);  // a new workgroup's waves are the youngest on their SIMDs: get the image in before yielding
+  const navgpu_dwa_config& c = pl.cfg;
+  const Geom g = geomOf(pl, inst);
+  const navgpu_robot_state st = pl.state[inst];
+  const uint8_t* master = pl.master + (size_t)inst * pl.cells_padded;
+  const uint32_t* dpath = pl.path + (size_t)inst * pl.cells;
+  const uint32_t* dgoal = pl.goal + (size_t)inst * pl.cells;
+  const uint32_t* dfront = pl.goal_front + (size_t)inst * pl.cells;
+  const int32_t* cnt = pl.axis_count + 4 * inst;
+  const int n_samples = cnt[3];
+  const uint32_t nfp = pl.fp_n[inst];
+  const int win = (int)pl.win;
+
+  // ---- stage (one batch of loads, one barrier): footprint, per-axis samples, the robot's image
+  constexpr int kAxisChunks = (3 * kMaxAxis + THREADS - 1) / THREADS;
+  const double pre_fp = pl.fp_spec[(size_t)inst * kMaxFootprint * 2 + (tid < 2 * nfp ? tid : 0)];
+  float pre_axis[kAxisChunks];
+#pragma unroll
+  for (int u = 0; u < kAxisChunks; ++u) {
+    const uint32_t i = min(tid + (uint32_t)u * THREADS, 3u * kMaxAxis - 1), a = i / kMaxAxis, k = i - a * kMaxAxis;
+    pre_axis[u] = pl.axis_samples[((size_t)inst * 3 + a) * pl.max_axis + min(k, pl.max_axis - 1)];
+    if (k >= pl.max_axis) pre_axis[u] = 0.f;
+  }
+  if (tid == 0) s_cnt[0] = s_cnt[1] = 0;
+  if (tid < 2) s_qn[tid] = 0;
+  s_obs[tid] = 0;
+  int wx0, wy0;
+  {  // window origin: robot cell (floor of the map coordinate, also valid when the robot is off the map)
+    double fx = floor(((double)st.pos[0] - g.ox) / g.res), fy = floor(((double)st.pos[1] - g.oy) / g.res);
+    fx = fmin(fmax(fx, -1.0e6), 1.0e6);
+    fy = fmin(fmax(fy, -1.0e6), 1.0e6);
+    wx0 = (int)fx - win / 2;
+    wy0 = (int)fy - win / 2;
+  }
+  const int win_bytes = (win * win + 15) & ~15;
+  const int nw = (win + 31) >> 5;
+  const bool walk_swap = pl.cfg.allow_unknown != 0;  // the window bytes are kept in walk order (planner_score.hip)
+  const uint32_t walk_fail = walk_swap ? 255u : 254u;
+  const int K = (int)pl.tab_steps;
+  const int tnfp = (int)pl.tab_nfp;
+  const int lrows = (int)pl.tab_rows;
+  double* s_trig = reinterpret_cast<double*>(s_dyn + win_bytes + score_bits_bytes(win));  // [rows][K][4] cs, sn, cs2, sn2
+  double* s_rot = s_trig + (size_t)lrows * K * 4;                                          // [rows][K][tnfp][2]
+  float* s_th = reinterpret_cast<float*>(s_rot + (size_t)lrows * K * tnfp * 2);            // [rows][K]
+  // Lane mapping.  Lanes are v_theta-major so that a wave shares one heading sequence.  The v_theta rows are cut into groups
+  // of tab_rows (what the LDS budget holds); a group takes bpg consecutive workgroups, which enumerate its rows x (vx, vy)
+  // pairs.  Blocks past the last group idle.
+  const int nxy = max(cnt[0] * cnt[1], 1);
+  int t_row_base, t_rows, t_li0;
+  {
+    const int R = (int)pl.tab_rows;
+    const int bpg = (nxy * R + THREADS - 1) / THREADS;
+    const int gi = (int)blockIdx.x / bpg;
+    t_row_base = gi * R;
+    t_rows = min(max(cnt[2] - t_row_base, 0), R);
+    t_li0 = ((int)blockIdx.x - gi * bpg) * THREADS;
+    if (t_li0 >= t_rows * nxy) {  // no sample for this workgroup (the last group's share is rounded up to the largest)
+      if (tid == 0) {
+        pl.part_cost[(size_t)inst * pl.score_blocks + blockIdx.x] = 1.0e300;
+        pl.part_index[(size_t)inst * pl.score_blocks + blockIdx.x] = 0x7FFFFFFF;
+      }
+      return;
+    }
+  }
+  {  // window + screens, and of the tables only the v_theta rows this workgroup's samples use, at their usual place
+    const uint4* img = reinterpret_cast<const uint4*>(pl.prep + (size_t)inst * pl.prep_stride);
+    uint4* lds = reinterpret_cast<uint4*>(s_dyn);
+    const int last = max(t_rows, 1) - 1;
+    const int r0 = min(t_li0 / nxy, last);
+    const int r1 = min((t_li0 + THREADS - 1) / nxy, last);
+    const int n16w = (int)((win_bytes + score_bits_bytes(win)) >> 4);
+    const int ncopy = r1 - r0 + 1;
+    const int n_trig = ncopy * K * 2, n_rot = ncopy * K * tnfp;  // 32 B per entry, 16 B per vertex
+    const int l_trig = n16w + r0 * K * 2, g_trig = n16w + (t_row_base + r0) * K * 2;
+    const int l_rot = n16w + lrows * K * 2 + r0 * K * tnfp, g_rot = n16w + (int)pl.tab_nth * K * 2 + (t_row_base + r0) * K * tnfp;
+    const int n16t = n16w + n_trig + n_rot;
+    const float* g_th = reinterpret_cast<const float*>(img + n16w + (size_t)pl.tab_nth * K * (2 + tnfp)) + t_row_base * K;
+    auto srcOf = [&](int i) { return i < n16w ? i : (i < n16w + n_trig ? g_trig + (i - n16w) : g_rot + (i - n16w - n_trig)); };
+    auto dstOf = [&](int i) { return i < n16w ? i : (i < n16w + n_trig ? l_trig + (i - n16w) : l_rot + (i - n16w - n_trig)); };
+    constexpr int kBatch = 4;  // 16-byte loads a lane has in flight (4 x 256 lanes x 16 B = 16 KB: a configs[2] image whole)
+    uint4 v[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) v[u] = img[srcOf(min((int)tid + u * THREADS, n16t - 1))];
+    const int th_i = r0 * K + (int)tid, th_n = (r0 + ncopy) * K;
+    const float th_v = g_th[min(th_i, max(th_n - 1, 0))];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u)
+      if ((int)tid + u * THREADS < n16t) lds[dstOf((int)tid + u * THREADS)] = v[u];
+    if (th_i < th_n) s_th[th_i] = th_v;
+    if (tid < 2 * nfp) s_fp[tid] = pre_fp;
+#pragma unroll
+    for (int u = 0; u < kAxisChunks; ++u) {
+      const uint32_t i = tid + (uint32_t)u * THREADS;
+      if (i < 3u * kMaxAxis) s_axis[i / kMaxAxis][i % kMaxAxis] = pre_axis[u];
+    }
+    for (int i = (int)tid + kBatch * THREADS; i < n16t; i += THREADS) lds[dstOf(i)] = img[srcOf(i)];  // larger images: the rest
+    for (int i = th_i + THREADS; i < th_n; i += THREADS) s_th[i] = g_th[i];
+  }
+  __syncthreads();
+  __builtin_amdgcn_s_setprio(0);
+
+  // NOTE: the LDS read is unconditional (clamped index) and the global fallback sits in its own rarely-taken branch; a
+  // `cond ? lds[i] : global[j]` form makes hipcc merge both into one FLAT load.
+  auto inWin = [&](int x, int y) { return (unsigned)(x - wx0) < (unsigned)win && (unsigned)(y - wy0) < (unsigned)win; };
+  auto cellCost = [&](int x, int y) -> uint8_t {
+    const bool in = inWin(x, y);
+    uint32_t v = s_win[in ? (y - wy0) * win + (x - wx0) : 0];
+    asm volatile("" : "+v"(v));  // pin the ds_read here so it cannot be re-merged with the global load below
+    if (walk_swap && v >= 254u) v ^= 1u;  // back from walk order
+    if (__builtin_expect(!in, 0)) v = master[y * g.nx + x];
+    return (uint8_t)v;
+  };
+  const double inv_res = pl.inv_res;
+  // Costmap2D::worldToMap (costmap_2d.cpp:208-220) with the two fp64 divisions replaced by a multiply; exact: whenever the
+  // product is not clear of an integer by 1e-7 (error bound 5e-10 below 1e6 cells) the division is redone.
+  auto w2m = [&](double wx, double wy, uint32_t& mx, uint32_t& my) -> bool {
+    const double dx = wx - g.ox, dy = wy - g.oy;
+    const double qx = dx * inv_res, qy = dy * inv_res;
+    double fx = floor(qx), fy = floor(qy);
+    const double rx = qx - fx, ry = qy - fy;
+    if (__builtin_expect(fmin(rx, ry) < 1.0e-7 || fmax(rx, ry) > 1.0 - 1.0e-7, 0)) {
+      fx = !(dx >= 0.0) ? -1.0 : (qx >= 1.0e6 ? 1.0e6 : (double)(int)(dx / g.res));  // wx < origin -> false (costmap_2d.cpp:210)
+      fy = !(dy >= 0.0) ? -1.0 : (qy >= 1.0e6 ? 1.0e6 : (double)(int)(dy / g.res));
+    }
+    // v_cvt_i32_f64 saturates (a point left of / below the origin floors to a negative cell, one far beyond the grid to
+    // INT_MAX: both fail the size test as unsigned numbers), which a C++ cast does not promise
+    int ix, iy;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(ix) : "v"(fx));
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(iy) : "v"(fy));
+    mx = (uint32_t)ix;
+    my = (uint32_t)iy;
+    return mx < g.nx && my < g.ny;
+  };
+  const uint8_t fail_span = (pl.cfg.allow_unknown != 0) ? 0 : 1;  // pointCost: 254, and 255 unless allow_unknown
+
+  // ---- CostmapModel::footprintCost at pose (x, y) with the rotated vertices of table entry te: bad = some vertex is off the
+  // map or some outline cell fails pointCost (-> footprint_cost < 0); else f_cost = the largest cost on the outline.
+  // Per edge one chunk of Bresenham cells with all ds_reads in flight (the addresses do not depend on the bytes read);
+  // cells past the end re-read the first cell, cells past a lethal cell cannot change the outcome.
+  auto walkFootprint = [&](const double x, const double y, const int te, double& f_cost) -> bool {
+    bool bad = false;
+    int fx0 = 0, fy0 = 0, pxc = 0, pyc = 0;
+    uint32_t mx_cost = 0;  // maximum over the perimeter cells, in walk order
+    for (uint32_t v = 0; v <= nfp && !bad; ++v) {
+      int vx, vy;
+      if (v < nfp) {
+        const double wx = x + s_rot[(te * tnfp + v) * 2], wy = y + s_rot[(te * tnfp + v) * 2 + 1];  // world_model.h:72-73
+        uint32_t ux, uy;
+        if (!w2m(wx, wy, ux, uy)) {
+          bad = true;
+          break;
+        }
+        vx = (int)ux;
+        vy = (int)uy;
+        if (v == 0) {
+          fx0 = vx;
+          fy0 = vy;
+          pxc = vx;
+          pyc = vy;
+          continue;
+        }
+      } else {  // closing edge: last -> first
+        vx = fx0;
+        vy = fy0;
+      }
+      // lineCost over LineIterator(pxc, pyc, vx, vy)
+      int deltax = vx - pxc, deltay = vy - pyc;
+      deltax = deltax < 0 ? -deltax : deltax;
+      deltay = deltay < 0 ? -deltay : deltay;
+      int lx = pxc, ly = pyc;
+      int xinc1, xinc2, yinc1, yinc2, den, num, numadd, numpixels;
+      xinc1 = xinc2 = (vx >= pxc) ? 1 : -1;
+      yinc1 = yinc2 = (vy >= pyc) ? 1 : -1;
+      if (deltax >= deltay) {
+        xinc1 = 0;
+        yinc2 = 0;
+        den = deltax;
+        num = deltax / 2;
+        numadd = deltay;
+        numpixels = deltax;
+      } else {
+        xinc2 = 0;
+        yinc1 = 0;
+        den = deltay;
+        num = deltay / 2;
+        numadd = deltax;
+        numpixels = deltay;
+      }
+      if (__builtin_expect(inWin(pxc, pyc) && inWin(vx, vy), 1)) {  // every cell of the line lies in the endpoints' bounding box
+        const uint8_t* pw = s_win + ((pyc - wy0) * win + (pxc - wx0));
+        const uint8_t* const pw_first = pw;
+        const int inc1 = yinc1 * win + xinc1, inc2 = yinc2 * win + xinc2;
+        for (int cp = 0; cp <= numpixels && !bad; cp += CHUNK) {
+          uint32_t cellv[CHUNK];
+#pragma unroll
+          for (int u = 0; u < CHUNK; ++u) {
+            cellv[u] = *((cp + u <= numpixels) ? pw : pw_first);
+            num += numadd;
+            if (num >= den) {
+              num -= den;
+              pw += inc1;
+            }
+            pw += inc2;
+          }
+#pragma unroll
+          for (int u = 0; u < CHUNK; ++u) mx_cost = max(mx_cost, cellv[u]);
+          bad = mx_cost >= walk_fail;
+        }
+      } else {
+        for (int cp = 0; cp <= numpixels; ++cp) {
+          const uint8_t cc = master[ly * g.nx + lx];
+          if ((uint8_t)(cc - kLethal) <= fail_span) {
+            bad = true;
+            break;
+          }
+          const uint32_t ct = (walk_swap && cc >= 254) ? (cc ^ 1u) : cc;  // walk order, like the LDS bytes
+          mx_cost = ct > mx_cost ? ct : mx_cost;
+          num += numadd;
+          if (num >= den) {
+            num -= den;
+            lx += xinc1;
+            ly += yinc1;
+          }
+          lx += xinc2;
+          ly += yinc2;
+        }
+      }
+      pxc = vx;
+      pyc = vy;
+    }
+    f_cost = (walk_swap && mx_cost == 254u) ? 255.0 : (double)mx_cost;  // an allowed NO_INFORMATION cell costs 255
+    return bad;
+  };
+
+  // ---- lane -> sample slot (x-outer, y, theta-inner, as the reference enumerates: what results are keyed by)
+  const int li = t_li0 + (int)tid;
+  const int t_row = divSmall(li, nxy);  // row within the group = row of the tables in LDS
+  const int t_r = li - t_row * nxy;     // index of the (vx, vy) pair, x-outer
+  const int t_ith = t_row_base + t_row;
+  const bool in_range = n_samples > 0 && t_row < t_rows;
+  const int sidx = t_r * cnt[2] + t_ith;
+  double total = -1.0;
+  int status = NAVGPU_SAMPLE_REJECTED;
+
+  float vs[3] = {0.f, 0.f, 0.f};
+  bool reject = true;
+  if (in_range) {
+    const int nyv = cnt[1];
+    const int ix = divSmall(t_r, nyv), iy = t_r - ix * nyv;
+    vs[0] = s_axis[0][ix];
+    vs[1] = s_axis[1][iy];
+    vs[2] = s_axis[2][t_ith];
+    // generateTrajectory: reject tests (:193-200); the step count is the tables' (ceil(sim_time / sim_granularity), host)
+    const double vmag = hyp2((double)vs[0], (double)vs[1]);
+    const double eps = 1e-4;
+    reject = false;
+    if ((c.min_trans_vel >= 0 && vmag + eps < c.min_trans_vel) && (c.min_rot_vel >= 0 && fabs((double)vs[2]) + eps < c.min_rot_vel)) reject = true;
+    if (c.max_trans_vel >= 0 && vmag - eps > c.max_trans_vel) reject = true;
+    if (K <= 0) reject = true;  // `return num_steps > 0` (:250)
+  }
+  if (!reject) status = NAVGPU_SAMPLE_SCORED;
+  const double dt = pl.tab_dt;
+  const double xv = vs[0], yv = vs[1], thv = vs[2];  // traj.xv_, yv_, thetav_
+  const uint32_t osc = pl.osc_flags[inst];
+  const bool osc_fail = ((osc & NAVGPU_OSC_FORWARD_POS_ONLY) && xv < 0.0) || ((osc & NAVGPU_OSC_FORWARD_NEG_ONLY) && xv > 0.0) ||
+                        ((osc & NAVGPU_OSC_STRAFE_POS_ONLY) && yv < 0.0) || ((osc & NAVGPU_OSC_STRAFE_NEG_ONLY) && yv > 0.0) ||
+                        ((osc & NAVGPU_OSC_ROT_POS_ONLY) && thv < 0.0) || ((osc & NAVGPU_OSC_ROT_NEG_ONLY) && thv > 0.0);
+  const double sc_obs = pl.scale_obstacle, sc_gf = pl.scale_goal, sc_al = pl.align_on[inst] ? pl.scale_path : 0.0, sc_path = pl.scale_path,
+               sc_goal = pl.scale_goal;
+  const bool en_obs = sc_obs != 0, en_gf = sc_gf != 0, en_al = sc_al != 0, en_path = sc_path != 0, en_goal = sc_goal != 0;
+  // first_fail: order index of the earliest critic in the list that has failed (1 obstacle .. 5 goal), 6 = none; fail_code its
+  // code - the only one scoreTrajectory's in-order sum can return (simple_scored_sampling_planner.cpp:59-66)
+  int first_fail = 6;
+  int fail_code = 0;
+  uint32_t d_gf = 0, d_al = 0, d_path = 0, d_goal = 0;  // the map-grid critics' values (aggregation Last: the final point's)
+  const double fpd = c.forward_point_distance;
+  const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
+  if (en_obs && nfp == 0) {  // "Footprint spec is empty" (obstacle_cost_function.cpp:78-82)
+    fail_code = -9;
+    first_fail = 1;
+  }
+  // a critic is live while no critic before it in the order has failed; the lowest enabled order decides when nothing is
+  // left to evaluate
+  const int min_order = en_obs ? 1 : en_gf ? 2 : en_al ? 3 : en_path ? 4 : en_goal ? 5 : 6;
+  // the forward point (x + fpd cos, y + fpd sin) stays on the map whenever the centre cell is this many cells away from every
+  // border; only then may a step skip its worldToMap
+  const uint32_t fwd_margin = (uint32_t)fmin(ceil(fabs(fpd) * inv_res) + 1.0, 1.0e6);
+  const bool fwd_screen = !(en_gf || en_al) || (2u * fwd_margin < g.nx && 2u * fwd_margin < g.ny);
+  const uint32_t fwd_lo = (en_gf || en_al) ? fwd_margin : 0u, fwd_nx = g.nx - 2u * fwd_lo, fwd_ny = g.ny - 2u * fwd_lo;
+  uint32_t fb_off = (uint32_t)win_bytes;  // (in a vector register: as a scalar it is spilled and read back with v_readlane at every point)
+  asm volatile("" : "+v"(fb_off));
+  const uint4* s_fb4 = reinterpret_cast<const uint4*>(s_dyn + fb_off);
+  const bool scr_sum = c.sum_scores != 0;  // the obstacle screen: dilated "not free" with sum_scores, else dilated "can fail"
+  const bool screen_on = fwd_screen && (nfp >= 3 || !en_obs);
+  // the forward-margin test is only needed when the LDS window reaches into the margin band of the map (wave-uniform)
+  const bool need_margin = !((uint32_t)wx0 - fwd_lo < fwd_nx && (uint32_t)(wx0 + win - 1) - fwd_lo < fwd_nx && (uint32_t)wy0 - fwd_lo < fwd_ny &&
+                             (uint32_t)(wy0 + win - 1) - fwd_lo < fwd_ny);
+
+  float px = st.pos[0], py = st.pos[1];
+  int step = 0;
+  bool alive = in_range && !reject && !osc_fail && first_fail > min_order;
+  const uint32_t lane = tid & 63u;
+  for (uint32_t blk = 0;; ++blk) {
+    // ---- sweep: up to kSweepBlockSteps points per lane
+    for (int it = 0; it < kSweepBlockSteps; ++it) {
+      if (alive && step < K) {
+        const int te = t_row * K + step;
+        const double x = px, y = py;
+        const double cs = s_trig[4 * te], sn = s_trig[4 * te + 1];
+        uint32_t cx = 0, cy = 0;
+        const bool ok_c = w2m(x, y, cx, cy);
+        // ---- screen: on every point but the last a critic can only FAIL (its value is overwritten: aggregation Last; with
+        // sum_scores the obstacle critic adds the point's cost, which is 0 when everything in reach is free).  One 16-byte
+        // LDS read says whether any critic could fail here; if none can, the point is done.  The screen word is read whatever
+        // the point is (clamped address) and the NEXT pose is computed while that read is in flight.
+        const bool in_w = ok_c && inWin((int)cx, (int)cy);
+        const int lxw = in_w ? (int)cx - wx0 : 0;
+        const uint4 fbw = s_fb4[(in_w ? (int)cy - wy0 : 0) * nw + (lxw >> 5)];
+        // ---- advance (computeNewPositions :253-260): fp64 on fp32 state, rounded back to fp32 (the heading is the tables')
+        const double cs2 = s_trig[4 * te + 2], sn2 = s_trig[4 * te + 3];
+        const float nxp = (float)(px + (vs[0] * cs + vs[1] * cs2) * dt);
+        const float nyp = (float)(py + (vs[0] * sn + vs[1] * sn2) * dt);
+        // (a critic that has already failed, or that follows one that has, cannot change the outcome any more)
+        const uint32_t scr_z = first_fail > 4 ? 0xFFFFFFFFu : 0u, scr_w = first_fail > 5 ? 0xFFFFFFFFu : 0u;
+        const uint32_t any = (scr_sum ? fbw.x : fbw.y) | (fbw.z & scr_z) | (fbw.w & scr_w);
+        const bool margin_ok = !need_margin || ((cx - fwd_lo < fwd_nx) && (cy - fwd_lo < fwd_ny));
+        const bool last_pt = step == K - 1;
+        const bool screened = screen_on && !last_pt && in_w && !((any >> (lxw & 31)) & 1u) && margin_ok;
+        bool stall = false;
+        if (!screened) {
+          // ---- obstacle critic: decide here, walk later
+          if (en_obs) {
+            if (!ok_c) {  // CostmapModel::footprintCost: centre off the map -> -1 -> -6 (obstacle_cost_function.cpp:127-131)
+              fail_code = -6;
+              first_fail = 1;
+            } else if (nfp < 3) {  // the centre cell alone (costmap_model.cpp:63-72)
+              const uint8_t cc = cellCost(cx, cy);
+              if (cc == kLethal || cc == kInscribed || (cc == kNoInfo && c.allow_unknown == 0)) {
+                fail_code = -6;
+                first_fail = 1;
+              } else if (scr_sum || last_pt) {
+                atomicAdd(&s_obs[tid], (uint32_t)cc);  // occ = max(f_cost, centre cell) = the cell's cost
+              }
+            } else {
+              // all_free: every cell the footprint can touch is FREE_SPACE -> the point costs exactly 0.  Without sum_scores
+              // only the LAST point's footprint cost survives (cost = f_cost), the earlier points only have to be legal: no
+              // failing cell in reach is enough.
+              bool need_walk = true;
+              if (in_w) {
+                const bool not_free = (fbw.x >> (lxw & 31)) & 1u, can_fail = (fbw.y >> (lxw & 31)) & 1u;
+                need_walk = not_free && (scr_sum || last_pt || can_fail);
+              }
+              const unsigned long long pm = __ballot(need_walk);
+              if (pm != 0ull) {  // one LDS atomic per wave and step
+                const int leader = __ffsll((long long)pm) - 1;
+                uint32_t base = 0;
+                if ((int)lane == leader) base = atomicAdd(&s_qn[blk & 1u], (uint32_t)__popcll(pm));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                const uint32_t slot = base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+                if (need_walk) {
+                  if (slot < (uint32_t)kSweepQueue) {
+                    s_qx[slot] = px;
+                    s_qy[slot] = py;
+                    s_qt[slot] = tid | ((uint32_t)step << 8) | ((uint32_t)t_row << 16) | ((scr_sum || last_pt) ? 0x80000000u : 0u);
+                  } else {
+                    stall = true;  // the queue is full: this point is taken again in the next block
+                  }
+                }
+              }
+            }
+          }
+          if (!stall && first_fail > 1) {
+            if ((en_path && 4 < first_fail) || (en_goal && 5 < first_fail)) {
+              if (!ok_c) {
+                fail_code = -4;
+                first_fail = (en_path && 4 < first_fail) ? 4 : 5;
+              } else {
+                const uint32_t cell = cy * g.nx + cx;
+                // A point of the window whose path / goal screen bit is clear cannot fail that critic (the bit IS the failure
+                // test, taken from this cycle's grid by the prep launch), and of the distances only the LAST point's survives
+                const bool look_p = last_pt || !in_w || ((fbw.z >> (lxw & 31)) & 1u);
+                const bool look_g = last_pt || !in_w || ((fbw.w >> (lxw & 31)) & 1u);
+                if (en_path && 4 < first_fail && look_p) {
+                  const uint32_t d = dpath[cell];
+                  if (d == N_obst) {
+                    fail_code = -3;
+                    first_fail = 4;
+                  } else if (d == N_unreach) {
+                    fail_code = -2;
+                    first_fail = 4;
+                  } else
+                    d_path = d;
+                }
+                if (en_goal && 5 < first_fail && look_g) {
+                  const uint32_t d = dgoal[cell];
+                  if (d == N_obst) {
+                    fail_code = -3;
+                    first_fail = 5;
+                  } else if (d == N_unreach) {
+                    fail_code = -2;
+                    first_fail = 5;
+                  } else
+                    d_goal = d;
+                }
+              }
+            }
+            if ((en_gf && 2 < first_fail) || (en_al && 3 < first_fail)) {
+              double sx = x, sy = y;
+              if (fpd != 0.0) {
+                sx = x + fpd * cs;
+                sy = y + fpd * sn;
+              }
+              uint32_t ux, uy;
+              if (!w2m(sx, sy, ux, uy)) {
+                fail_code = -4;
+                first_fail = (en_gf && 2 < first_fail) ? 2 : 3;
+              } else if (last_pt) {  // aggregation Last: only the final point's value survives
+                const uint32_t cell = uy * g.nx + ux;
+                if (en_gf && 2 < first_fail) d_gf = dfront[cell];
+                if (en_al && 3 < first_fail) d_al = dpath[cell];
+              }
+            }
+          }
+          alive = first_fail > min_order;
+        }
+        if (!stall) {
+          px = nxp;
+          py = nyp;
+          ++step;
+        }
+      }
+    }
+    __syncthreads();  // the block's entries are in the queue
+    // ---- walk: the workgroup's lanes take the entries, whoever pushed them
+    const int nq = (int)min(s_qn[blk & 1u], (uint32_t)kSweepQueue);
+    for (int e = (int)tid; e < nq; e += THREADS) {
+      const uint32_t tag = s_qt[e];
+      const double x = s_qx[e], y = s_qy[e];
+      const int e_step = (int)((tag >> 8) & 0xFFu), e_row = (int)((tag >> 16) & 0x7FFFu);
+      const uint32_t owner = tag & 0xFFu;
+      double f_cost = 0.0;
+      const bool bad = walkFootprint(x, y, e_row * K + e_step, f_cost);
+      if (bad) {
+        atomicOr(&s_obs[owner], kWalkFailed);
+      } else if (tag >> 31) {
+        // the centre is on the map here (a point off the map never gets into the queue), so the -7 branch
+        // (obstacle_cost_function.cpp:135-137) cannot fire; occ_cost = max(max(0, footprint_cost), centre cell)
+        uint32_t cx, cy;
+        w2m(x, y, cx, cy);
+        const double occ = fmax(fmax(0.0, f_cost), (double)cellCost(cx, cy));
+        atomicAdd(&s_obs[owner], (uint32_t)occ);
+      }
+    }
+    if (tid == 0) s_qn[(blk + 1u) & 1u] = 0;  // (last touched before the previous block's second barrier)
+    const int more = __syncthreads_or(alive && step < K);
+    if (alive && (s_obs[tid] & kWalkFailed)) {  // a walked point of this lane failed: footprint_cost < 0 -> -6
+      fail_code = -6;
+      first_fail = 1;
+      alive = false;
+    }
+    if (!more) break;
+  }
+
+  if (in_range && !reject) {
+    if (osc_fail) {
+      total = -5.0;
+    } else if (first_fail < 6) {
+      total = (double)fail_code;
+    } else {
+      // scoreTrajectory's sum in critic order (a term that is 0 is not scaled: `if (cost != 0) cost *= scale`)
+      total = 0.0;
+      auto add = [&](bool en, double value, double scale) {
+        if (!en) return;
+        double cost = value;
+        if (cost != 0) cost *= scale;
+        total += cost;
+      };
+      add(en_obs, (double)(s_obs[tid] & ~kWalkFailed), sc_obs);
+      add(en_gf, (double)d_gf, sc_gf);
+      add(en_al, (double)d_al, sc_al);
+      add(en_path, (double)d_path, sc_path);
+      add(en_goal, (double)d_goal, sc_goal);
+    }
+  }
+  if (in_range && pl.sample_cost) {
+    pl.sample_cost[(size_t)inst * pl.max_samples + sidx] = total;
+    pl.sample_status[(size_t)inst * pl.max_samples + sidx] = status;
+  }
+
+  // ---- workgroup argmin (lowest index wins ties == first strict minimum of the sequential loop)
+  const bool valid = in_range && status == NAVGPU_SAMPLE_SCORED && total >= 0.0;
+  double bc = valid ? total : 1.0e300;
+  int bi = valid ? sidx : 0x7FFFFFFF;
+  for (int off = 32; off > 0; off >>= 1) {
+    double oc = __shfl_down(bc, off);
+    int oi = __shfl_down(bi, off);
+    if (oc < bc || (oc == bc && oi < bi)) {
+      bc = oc;
+      bi = oi;
+    }
+  }
+  const unsigned long long m_scored = __ballot(in_range && status == NAVGPU_SAMPLE_SCORED);
+  const unsigned long long m_valid = __ballot(valid);
+  if ((tid & 63) == 0) {
+    s_rc[tid >> 6] = bc;
+    s_ri[tid >> 6] = bi;
+    atomicAdd(&s_cnt[0], __popcll(m_scored));
+    atomicAdd(&s_cnt[1], __popcll(m_valid));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < THREADS / 64; ++w)
+      if (s_rc[w] < bc || (s_rc[w] == bc && s_ri[w] < bi)) {
+        bc = s_rc[w];
+        bi = s_ri[w];
+      }
+    pl.part_cost[(size_t)inst * pl.score_blocks + blockIdx.x] = bc;
+    pl.part_index[(size_t)inst * pl.score_blocks + blockIdx.x] = bi;
+    if (s_cnt[0]) atomicAdd(&pl.counters[2 * inst], s_cnt[0]);
+    if (s_cnt[1]) atomicAdd(&pl.counters[2 * inst + 1], s_cnt[1]);
+  }
+}
+
+// The sweep takes every launch of the table variant (use_dwa, discretize_by_time, DWAPlanner's own MapGrid options): its tags
+// hold 8 bits of lane and of step.
+bool score_sweep_applies(const PlannerDev& pl) {
+  return pl.use_tables && !pl.mg_generic && pl.tab_steps >= 1 && pl.tab_steps <= 255 && kSweepThreads <= 256;
+}
+uint32_t launch_score_sweep(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
+  const size_t lds = score_window_bytes(pl.win) + score_table_lds_bytes(pl);
+  // row groups x workgroups per group, for the largest (vx, vy) grid the configuration can produce
+  const uint32_t max_nxy = pl.max_samples / std::max(pl.tab_nth, 1u), groups = (pl.tab_nth + pl.tab_rows - 1) / pl.tab_rows;
+  const uint32_t blocks = std::min(groups * ((max_nxy * pl.tab_rows + kSweepThreads - 1) / kSweepThreads), pl.score_blocks);
+#define NAVGPU_SCORE_SWEEP(C)                                                                                                        \
+  {                                                                                                                                  \
+    if (lds > 40 * 1024) hipFuncSetAttribute((const void*)k_score_sweep<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+    hipLaunchKernelGGL(k_score_sweep<C>, dim3(blocks, count), dim3(kSweepThreads), lds, s, pl, first);                               \
+  }
+  if (pl.fp_chunk <= 6) NAVGPU_SCORE_SWEEP(6)
+  else if (pl.fp_chunk <= 9) NAVGPU_SCORE_SWEEP(9)
+  else if (pl.fp_chunk <= 12) NAVGPU_SCORE_SWEEP(12)
+  else NAVGPU_SCORE_SWEEP(16)
+#undef NAVGPU_SCORE_SWEEP
+  return blocks;
+}
+
+}  // namespace navgpu

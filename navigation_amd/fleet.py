@@ -60,6 +60,10 @@ class Fleet:
     def sync(self):
         check(self.L.navgpu_sync(self.h), "navgpu_sync")
 
+    def set_alloc_limit(self, max_bytes):
+        """fault injection for tests: device allocations larger than max_bytes fail from now on (0 = no limit)"""
+        check(self.L.navgpu_fleet_set_alloc_limit(self.h, int(max_bytes)), "fleet_set_alloc_limit")
+
     def origins(self):
         """Current Costmap2D origins (they move with a rolling window)."""
         o = np.zeros((self.n, 2), np.float64)

@@ -141,12 +141,12 @@ def test_inflation_configure_failure_keeps_previous_configuration(nav, orc):
     fl.inflate(boxes=[[0, 0, n, n]] * 2)
     want = fl.master()
     assert np.array_equal(want[0], orc.inflate(maps[0], 0.05, 0.55, 10.0, 0.2, exact=True))
-    os.environ["NAVGPU_DEBUG_ALLOC_LIMIT"] = str(1 << 20)  # the heaps (2 x 5 x 16384 x 16 B = 2.6 MB) cannot be allocated
+    fl.set_alloc_limit(1 << 20)  # the heaps (2 x 5 x 16384 x 16 B = 2.6 MB) cannot be allocated
     try:
         with pytest.raises(Exception):
             fl.configure_inflation(1.0, 3.0, 0.35, priority_queue_order=True)
     finally:
-        del os.environ["NAVGPU_DEBUG_ALLOC_LIMIT"]
+        fl.set_alloc_limit(0)
     fl.upload(N.GRID_MASTER, maps)
     fl.inflate(boxes=[[0, 0, n, n]] * 2)  # old radius, old table, exact mode - and no launch on null heaps
     assert np.array_equal(fl.master(), want)

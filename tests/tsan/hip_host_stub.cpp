@@ -54,7 +54,7 @@ void launch_cell_costs(const PlannerDev&, uint32_t, float4*, hipStream_t) {}
 void launch_samples(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t) {
   for (uint32_t i = first; i < first + count; ++i) pl.axis_samples[(size_t)i * 3 * pl.max_axis] = 1.0f;  // touches the table a reconfigure re-allocates
 }
-void launch_bfs(const PlannerDev&, uint32_t, uint32_t, hipStream_t, const uint32_t*, bool, int) {}
+void launch_bfs(const PlannerDev&, uint32_t, uint32_t, hipStream_t, const uint32_t*, bool) {}
 uint32_t launch_score(const PlannerDev& pl, uint32_t first, uint32_t count, const float*, hipStream_t) {
   for (uint32_t i = first; i < first + count; ++i) pl.part_cost[(size_t)i * pl.score_blocks + pl.score_blocks - 1] = 1.0;
   return 1;
@@ -73,12 +73,9 @@ void launch_stage_poses(const PoseChunk& c, hipStream_t) {
   memcpy(c.bfs_reach + c.first, c.reach, sizeof(uint32_t) * c.count);
 }
 void launch_sincos(const double*, uint32_t, double*, double*, hipStream_t) {}
-size_t bfs_lds_bytes(uint32_t, uint32_t) { return 0; }
-bool bfs_bounded_applies(const PlannerDev&) { return true; }
 size_t score_table_bytes(const PlannerDev&) { return 1024; }
 size_t score_window_bytes(uint32_t win) { return (size_t)win * win; }
 size_t score_prep_bytes(const PlannerDev& pl) { return (size_t)pl.win * pl.win + 4096; }
-bool bfs_lds_resident(uint32_t, uint32_t) { return true; }
 size_t bfs_scratch_words(uint32_t, uint32_t) { return 0; }
 uint32_t score_table_rows(const PlannerDev&, uint32_t) { return 4; }
 void launch_navfn_costmap(const NavfnDev&, uint32_t, uint32_t, const uint8_t*, size_t, int, int, hipStream_t) {}
