@@ -1021,6 +1021,7 @@ uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, c
     if (lds_prep > 48 * 1024) hipFuncSetAttribute((const void*)k_score_prep_tab, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_prep);
     hipLaunchKernelGGL(k_score_prep_tab, dim3(1, count), dim3(kScorePrepThreads), lds_prep, s, pl, first);
     pl.tab_bytes = (uint32_t)score_table_lds_bytes(pl);
+    if (score_sweep_applies(pl) && !NAVGPU_DEBUG_ENV("NAVGPU_DEBUG_NO_SWEEP")) return launch_score_sweep(pl, first, count, s);
     const size_t lds = win_bytes + score_table_lds_bytes(pl);
     // row groups x workgroups per group, for the largest (vx, vy) grid the configuration can produce
     const uint32_t max_nxy = pl.max_samples / std::max(pl.tab_nth, 1u), groups = (pl.tab_nth + pl.tab_rows - 1) / pl.tab_rows;

@@ -187,39 +187,77 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
     my = (uint32_t)iy;
     return mx < g.nx && my < g.ny;
   };
-  const uint8_t fail_span = (pl.cfg.allow_unknown != 0) ? 0 : 1;  // pointCost: 254, and 255 unless allow_unknown
 
-  // ---- CostmapModel::footprintCost at pose (x, y) with the rotated vertices of table entry te: bad = some vertex is off the
-  // map or some outline cell fails pointCost (-> footprint_cost < 0); else f_cost = the largest cost on the outline.
-  // Per edge one chunk of Bresenham cells with all ds_reads in flight (the addresses do not depend on the bytes read);
-  // cells past the end re-read the first cell, cells past a lethal cell cannot change the outcome.
-  auto walkFootprint = [&](const double x, const double y, const int te, double& f_cost) -> bool {
-    bool bad = false;
-    int fx0 = 0, fy0 = 0, pxc = 0, pyc = 0;
-    uint32_t mx_cost = 0;  // maximum over the perimeter cells, in walk order
-    for (uint32_t v = 0; v <= nfp && !bad; ++v) {
-      int vx, vy;
-      if (v < nfp) {
-        const double wx = x + s_rot[(te * tnfp + v) * 2], wy = y + s_rot[(te * tnfp + v) * 2 + 1];  // world_model.h:72-73
-        uint32_t ux, uy;
-        if (!w2m(wx, wy, ux, uy)) {
-          bad = true;
-          break;
-        }
+  // ---- CostmapModel::footprintCost at pose (x, y) with the rotated vertices of table entry te (costmap_model.cpp:50-142):
+  // returns true when some vertex is off the map (footprint_cost = -1); else mx = the largest byte on the outline, in walk
+  // order (>= walk_fail: some cell fails pointCost).  STRAIGHT-LINE: the vertex / edge loop runs nfp times for every lane
+  // (a scalar counter), an edge is one chunk of Bresenham cells (LineIterator, line_iterator.h:38-139) whose addresses do
+  // not depend on the bytes read - all ds_reads of a chunk in flight, cells past the end re-read the first cell - and nothing
+  // leaves early: a lethal cell or an off-map vertex cannot be undone by what is read after it.  (As nested loops with
+  // breaks the same walk compiled to ~950 vector and as many scalar instructions, most of them exec-mask bookkeeping.)
+  // outside: an edge's end points are not both inside the LDS window (never, with a correctly sized window): the caller
+  // repeats the walk on the costmap itself (walkCostmap).
+  auto walkWindow = [&](const double x, const double y, const int te, uint32_t& mx, bool& outside) -> bool {
+    const double* rot = s_rot + (size_t)te * tnfp * 2;
+    bool off = false;
+    outside = false;
+    mx = 0;
+    uint32_t ux, uy;
+    off |= !w2m(x + rot[0], y + rot[1], ux, uy);  // world_model.h:72-73 (the rotation is the tables')
+    const int fx0 = (int)ux, fy0 = (int)uy;
+    int pxc = fx0, pyc = fy0;
+    for (uint32_t v = 1; v <= nfp; ++v) {  // edges v-1 -> v, and last -> first
+      int vx = fx0, vy = fy0;
+      if (v < nfp) {  // (wave-uniform)
+        off |= !w2m(x + rot[2 * v], y + rot[2 * v + 1], ux, uy);
         vx = (int)ux;
         vy = (int)uy;
-        if (v == 0) {
-          fx0 = vx;
-          fy0 = vy;
-          pxc = vx;
-          pyc = vy;
-          continue;
-        }
-      } else {  // closing edge: last -> first
-        vx = fx0;
-        vy = fy0;
       }
-      // lineCost over LineIterator(pxc, pyc, vx, vy)
+      const int dx = vx - pxc, dy = vy - pyc;
+      const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+      const bool xmaj = adx >= ady;
+      const int sx = (vx >= pxc) ? 1 : -1, sy = (vy >= pyc) ? win : -win;
+      const int den = max(adx, ady), numadd = min(adx, ady), numpixels = den;
+      int num = den >> 1;
+      const bool in = inWin(pxc, pyc) && inWin(vx, vy);  // every cell of the line lies in the end points' bounding box
+      outside |= !in;
+      const int inc1 = in ? (xmaj ? sy : sx) : 0, inc2 = in ? (xmaj ? sx : sy) : 0;
+      int addr = in ? (pyc - wy0) * win + (pxc - wx0) : 0;
+      const int addr_first = addr;
+      int cp = 0;
+      do {
+        uint32_t cellv[CHUNK];
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) {
+          cellv[u] = s_win[(cp + u <= numpixels) ? addr : addr_first];
+          num += numadd;
+          const bool ge = num >= den;
+          num -= ge ? den : 0;
+          addr += (ge ? inc1 : 0) + inc2;
+        }
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) mx = max(mx, cellv[u]);
+        cp += CHUNK;
+      } while (__ballot(cp <= numpixels) != 0ull);  // (a second chunk only for edges longer than the launch's CHUNK)
+      pxc = vx;
+      pyc = vy;
+    }
+    return off;
+  };
+  // the same walk on the costmap in HBM, cell by cell, for an outline that leaves the LDS window (vertices known on the map)
+  auto walkCostmap = [&](const double x, const double y, const int te) -> uint32_t {
+    const double* rot = s_rot + (size_t)te * tnfp * 2;
+    uint32_t mx = 0, ux, uy;
+    w2m(x + rot[0], y + rot[1], ux, uy);
+    const int fx0 = (int)ux, fy0 = (int)uy;
+    int pxc = fx0, pyc = fy0;
+    for (uint32_t v = 1; v <= nfp; ++v) {
+      int vx = fx0, vy = fy0;
+      if (v < nfp) {
+        w2m(x + rot[2 * v], y + rot[2 * v + 1], ux, uy);
+        vx = (int)ux;
+        vy = (int)uy;
+      }
       int deltax = vx - pxc, deltay = vy - pyc;
       deltax = deltax < 0 ? -deltax : deltax;
       deltay = deltay < 0 ? -deltay : deltay;
@@ -242,50 +280,23 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
         numadd = deltax;
         numpixels = deltay;
       }
-      if (__builtin_expect(inWin(pxc, pyc) && inWin(vx, vy), 1)) {  // every cell of the line lies in the endpoints' bounding box
-        const uint8_t* pw = s_win + ((pyc - wy0) * win + (pxc - wx0));
-        const uint8_t* const pw_first = pw;
-        const int inc1 = yinc1 * win + xinc1, inc2 = yinc2 * win + xinc2;
-        for (int cp = 0; cp <= numpixels && !bad; cp += CHUNK) {
-          uint32_t cellv[CHUNK];
-#pragma unroll
-          for (int u = 0; u < CHUNK; ++u) {
-            cellv[u] = *((cp + u <= numpixels) ? pw : pw_first);
-            num += numadd;
-            if (num >= den) {
-              num -= den;
-              pw += inc1;
-            }
-            pw += inc2;
-          }
-#pragma unroll
-          for (int u = 0; u < CHUNK; ++u) mx_cost = max(mx_cost, cellv[u]);
-          bad = mx_cost >= walk_fail;
+      for (int cp = 0; cp <= numpixels; ++cp) {
+        const uint32_t cc = master[ly * g.nx + lx];
+        const uint32_t ct = (walk_swap && cc >= 254u) ? (cc ^ 1u) : cc;  // walk order, like the LDS bytes
+        mx = ct > mx ? ct : mx;
+        num += numadd;
+        if (num >= den) {
+          num -= den;
+          lx += xinc1;
+          ly += yinc1;
         }
-      } else {
-        for (int cp = 0; cp <= numpixels; ++cp) {
-          const uint8_t cc = master[ly * g.nx + lx];
-          if ((uint8_t)(cc - kLethal) <= fail_span) {
-            bad = true;
-            break;
-          }
-          const uint32_t ct = (walk_swap && cc >= 254) ? (cc ^ 1u) : cc;  // walk order, like the LDS bytes
-          mx_cost = ct > mx_cost ? ct : mx_cost;
-          num += numadd;
-          if (num >= den) {
-            num -= den;
-            lx += xinc1;
-            ly += yinc1;
-          }
-          lx += xinc2;
-          ly += yinc2;
-        }
+        lx += xinc2;
+        ly += yinc2;
       }
       pxc = vx;
       pyc = vy;
     }
-    f_cost = (walk_swap && mx_cost == 254u) ? 255.0 : (double)mx_cost;  // an allowed NO_INFORMATION cell costs 255
-    return bad;
+    return mx;
   };
 
   // ---- lane -> sample slot (x-outer, y, theta-inner, as the reference enumerates: what results are keyed by)
@@ -353,137 +364,168 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
                              (uint32_t)(wy0 + win - 1) - fwd_lo < fwd_ny);
 
   float px = st.pos[0], py = st.pos[1];
-  int step = 0;
-  bool alive = in_range && !reject && !osc_fail && first_fail > min_order;
+  int step = 0;  // the lane's next trajectory point; stops at K or where the rollout ended
+  // all-ones while the lane's rollout goes on (kept as a mask in a vector register: as a bool the compiler branches on it)
+  uint32_t alive_m = (in_range && !reject && !osc_fail && first_fail > min_order) ? 0xFFFFFFFFu : 0u;
+#ifdef NAVGPU_SWEEP_X_NOSTEPS  // timing experiment: prologue + epilogue only
+  alive_m = 0;
+#endif
+  const bool margin_on = __builtin_amdgcn_readfirstlane((int)need_margin) != 0;
   const uint32_t lane = tid & 63u;
+  const int te0 = t_row * K;
+  const double vxd = vs[0], vyd = vs[1];
+  // the path / goal screens count while their critics are live (a critic that has failed, or that follows one that has, cannot
+  // change the outcome any more); all-ones where the launch has no screen at all
+  uint32_t scr_z = 0xFFFFFFFFu, scr_w = 0xFFFFFFFFu;
+  const uint32_t scr_off = screen_on ? 0u : 0xFFFFFFFFu;
   for (uint32_t blk = 0;; ++blk) {
-    // ---- sweep: up to kSweepBlockSteps points per lane
-    for (int it = 0; it < kSweepBlockSteps; ++it) {
-      if (alive && step < K) {
-        const int te = t_row * K + step;
+    // ---- sweep: up to kSweepBlockSteps points per lane.  The screened path is STRAIGHT-LINE for the whole wave - lanes whose
+    // rollout is over compute along (their state is never read again) - and ends in one wave-uniform branch: does any live
+    // lane have to look closer?  (Written with the usual per-lane conditions the compiler spends as many scalar instructions
+    // on exec-mask bookkeeping as the point costs in vector ones, and the scalar unit is shared by a CU's four SIMDs.)
+    if (__ballot(alive_m != 0u) != 0ull) {
+      for (int it = 0; it < kSweepBlockSteps; ++it) {
+        const int sc = min(step, K - 1);
+        const int te = te0 + sc;
         const double x = px, y = py;
         const double cs = s_trig[4 * te], sn = s_trig[4 * te + 1];
-        uint32_t cx = 0, cy = 0;
+        uint32_t cx, cy;
         const bool ok_c = w2m(x, y, cx, cy);
         // ---- screen: on every point but the last a critic can only FAIL (its value is overwritten: aggregation Last; with
         // sum_scores the obstacle critic adds the point's cost, which is 0 when everything in reach is free).  One 16-byte
         // LDS read says whether any critic could fail here; if none can, the point is done.  The screen word is read whatever
         // the point is (clamped address) and the NEXT pose is computed while that read is in flight.
-        const bool in_w = ok_c && inWin((int)cx, (int)cy);
-        const int lxw = in_w ? (int)cx - wx0 : 0;
-        const uint4 fbw = s_fb4[(in_w ? (int)cy - wy0 : 0) * nw + (lxw >> 5)];
+        const uint32_t lx = cx - (uint32_t)wx0, ly = cy - (uint32_t)wy0;
+        bool in_w = max(lx, ly) < (uint32_t)win;
+        uint32_t force = (sc == K - 1) ? 0xFFFFFFFFu : scr_off;  // no screen for the last point, or for this launch
+        if (margin_on) {  // (wave-uniform, rare: the window reaches beyond the map or into the forward point's margin band)
+          in_w = in_w && ok_c;
+          if (!((cx - fwd_lo < fwd_nx) && (cy - fwd_lo < fwd_ny))) force = 0xFFFFFFFFu;
+        }
+        const uint32_t fb_i = in_w ? ly * (uint32_t)nw + (lx >> 5) : 0u;
+        const uint4 fbw = s_fb4[fb_i];
         // ---- advance (computeNewPositions :253-260): fp64 on fp32 state, rounded back to fp32 (the heading is the tables')
         const double cs2 = s_trig[4 * te + 2], sn2 = s_trig[4 * te + 3];
-        const float nxp = (float)(px + (vs[0] * cs + vs[1] * cs2) * dt);
-        const float nyp = (float)(py + (vs[0] * sn + vs[1] * sn2) * dt);
-        // (a critic that has already failed, or that follows one that has, cannot change the outcome any more)
-        const uint32_t scr_z = first_fail > 4 ? 0xFFFFFFFFu : 0u, scr_w = first_fail > 5 ? 0xFFFFFFFFu : 0u;
-        const uint32_t any = (scr_sum ? fbw.x : fbw.y) | (fbw.z & scr_z) | (fbw.w & scr_w);
-        const bool margin_ok = !need_margin || ((cx - fwd_lo < fwd_nx) && (cy - fwd_lo < fwd_ny));
-        const bool last_pt = step == K - 1;
-        const bool screened = screen_on && !last_pt && in_w && !((any >> (lxw & 31)) & 1u) && margin_ok;
-        bool stall = false;
-        if (!screened) {
-          // ---- obstacle critic: decide here, walk later
-          if (en_obs) {
-            if (!ok_c) {  // CostmapModel::footprintCost: centre off the map -> -1 -> -6 (obstacle_cost_function.cpp:127-131)
-              fail_code = -6;
-              first_fail = 1;
-            } else if (nfp < 3) {  // the centre cell alone (costmap_model.cpp:63-72)
-              const uint8_t cc = cellCost(cx, cy);
-              if (cc == kLethal || cc == kInscribed || (cc == kNoInfo && c.allow_unknown == 0)) {
+        const float nxp = (float)(px + (vxd * cs + vyd * cs2) * dt);
+        const float nyp = (float)(py + (vxd * sn + vyd * sn2) * dt);
+        const uint32_t any = (scr_sum ? fbw.x : fbw.y) | (fbw.z & scr_z) | (fbw.w & scr_w) | force | (in_w ? 0u : 0xFFFFFFFFu);
+        const bool unscr = ((any >> (lx & 31u)) & alive_m & 1u) != 0u;
+        px = nxp;
+        py = nyp;
+        step -= (int)alive_m;  // (+1 while alive)
+        if (__ballot(unscr) != 0ull) {  // (wave-uniform)
+          if (unscr) {
+            const bool last_pt = sc == K - 1;
+            const bool on_map = cx < g.nx && cy < g.ny;  // (= ok_c)
+            const int lxw = (int)lx;
+            bool stall = false;
+            // ---- obstacle critic: decide here, walk later
+            if (en_obs) {
+              if (!on_map) {  // CostmapModel::footprintCost: centre off the map -> -1 -> -6 (obstacle_cost_function.cpp:127-131)
                 fail_code = -6;
                 first_fail = 1;
-              } else if (scr_sum || last_pt) {
-                atomicAdd(&s_obs[tid], (uint32_t)cc);  // occ = max(f_cost, centre cell) = the cell's cost
-              }
-            } else {
-              // all_free: every cell the footprint can touch is FREE_SPACE -> the point costs exactly 0.  Without sum_scores
-              // only the LAST point's footprint cost survives (cost = f_cost), the earlier points only have to be legal: no
-              // failing cell in reach is enough.
-              bool need_walk = true;
-              if (in_w) {
-                const bool not_free = (fbw.x >> (lxw & 31)) & 1u, can_fail = (fbw.y >> (lxw & 31)) & 1u;
-                need_walk = not_free && (scr_sum || last_pt || can_fail);
-              }
-              const unsigned long long pm = __ballot(need_walk);
-              if (pm != 0ull) {  // one LDS atomic per wave and step
-                const int leader = __ffsll((long long)pm) - 1;
-                uint32_t base = 0;
-                if ((int)lane == leader) base = atomicAdd(&s_qn[blk & 1u], (uint32_t)__popcll(pm));
-                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-                const uint32_t slot = base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-                if (need_walk) {
-                  if (slot < (uint32_t)kSweepQueue) {
-                    s_qx[slot] = px;
-                    s_qy[slot] = py;
-                    s_qt[slot] = tid | ((uint32_t)step << 8) | ((uint32_t)t_row << 16) | ((scr_sum || last_pt) ? 0x80000000u : 0u);
-                  } else {
-                    stall = true;  // the queue is full: this point is taken again in the next block
+              } else if (nfp < 3) {  // the centre cell alone (costmap_model.cpp:63-72)
+                const uint8_t cc = cellCost(cx, cy);
+                if (cc == kLethal || cc == kInscribed || (cc == kNoInfo && c.allow_unknown == 0)) {
+                  fail_code = -6;
+                  first_fail = 1;
+                } else if (scr_sum || last_pt) {
+                  atomicAdd(&s_obs[tid], (uint32_t)cc);  // occ = max(f_cost, centre cell) = the cell's cost
+                }
+              } else {
+                // all_free: every cell the footprint can touch is FREE_SPACE -> the point costs exactly 0.  Without sum_scores
+                // only the LAST point's footprint cost survives (cost = f_cost), the earlier points only have to be legal: no
+                // failing cell in reach is enough.
+                bool need_walk = true;
+                if (in_w) {
+                  const bool not_free = (fbw.x >> (lxw & 31)) & 1u, can_fail = (fbw.y >> (lxw & 31)) & 1u;
+                  need_walk = not_free && (scr_sum || last_pt || can_fail);
+                }
+#ifdef NAVGPU_SWEEP_X_NOWALK  // timing experiment: the sweep alone
+                need_walk = false;
+#endif
+                const unsigned long long pm = __ballot(need_walk);
+                if (pm != 0ull) {  // one LDS atomic per wave and step
+                  const int leader = __ffsll((long long)pm) - 1;
+                  uint32_t base = 0;
+                  if ((int)lane == leader) base = atomicAdd(&s_qn[blk & 1u], (uint32_t)__popcll(pm));
+                  base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                  const uint32_t slot = base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+                  if (need_walk) {
+                    if (slot < (uint32_t)kSweepQueue) {
+                      s_qx[slot] = (float)x;
+                      s_qy[slot] = (float)y;
+                      s_qt[slot] = tid | ((uint32_t)sc << 8) | ((uint32_t)t_row << 16) | ((scr_sum || last_pt) ? 0x80000000u : 0u);
+                    } else {
+                      stall = true;  // the queue is full: this point is taken again in the next block
+                    }
                   }
                 }
               }
             }
-          }
-          if (!stall && first_fail > 1) {
-            if ((en_path && 4 < first_fail) || (en_goal && 5 < first_fail)) {
-              if (!ok_c) {
-                fail_code = -4;
-                first_fail = (en_path && 4 < first_fail) ? 4 : 5;
-              } else {
-                const uint32_t cell = cy * g.nx + cx;
-                // A point of the window whose path / goal screen bit is clear cannot fail that critic (the bit IS the failure
-                // test, taken from this cycle's grid by the prep launch), and of the distances only the LAST point's survives
-                const bool look_p = last_pt || !in_w || ((fbw.z >> (lxw & 31)) & 1u);
-                const bool look_g = last_pt || !in_w || ((fbw.w >> (lxw & 31)) & 1u);
-                if (en_path && 4 < first_fail && look_p) {
-                  const uint32_t d = dpath[cell];
-                  if (d == N_obst) {
-                    fail_code = -3;
-                    first_fail = 4;
-                  } else if (d == N_unreach) {
-                    fail_code = -2;
-                    first_fail = 4;
-                  } else
-                    d_path = d;
+            if (!stall && first_fail > 1) {
+              if ((en_path && 4 < first_fail) || (en_goal && 5 < first_fail)) {
+                if (!on_map) {
+                  fail_code = -4;
+                  first_fail = (en_path && 4 < first_fail) ? 4 : 5;
+                } else {
+                  const uint32_t cell = cy * g.nx + cx;
+                  // A point of the window whose path / goal screen bit is clear cannot fail that critic (the bit IS the failure
+                  // test, taken from this cycle's grid by the prep launch), and of the distances only the LAST point's survives
+                  const bool look_p = last_pt || !in_w || ((fbw.z >> (lxw & 31)) & 1u);
+                  const bool look_g = last_pt || !in_w || ((fbw.w >> (lxw & 31)) & 1u);
+                  if (en_path && 4 < first_fail && look_p) {
+                    const uint32_t d = dpath[cell];
+                    if (d == N_obst) {
+                      fail_code = -3;
+                      first_fail = 4;
+                    } else if (d == N_unreach) {
+                      fail_code = -2;
+                      first_fail = 4;
+                    } else
+                      d_path = d;
+                  }
+                  if (en_goal && 5 < first_fail && look_g) {
+                    const uint32_t d = dgoal[cell];
+                    if (d == N_obst) {
+                      fail_code = -3;
+                      first_fail = 5;
+                    } else if (d == N_unreach) {
+                      fail_code = -2;
+                      first_fail = 5;
+                    } else
+                      d_goal = d;
+                  }
                 }
-                if (en_goal && 5 < first_fail && look_g) {
-                  const uint32_t d = dgoal[cell];
-                  if (d == N_obst) {
-                    fail_code = -3;
-                    first_fail = 5;
-                  } else if (d == N_unreach) {
-                    fail_code = -2;
-                    first_fail = 5;
-                  } else
-                    d_goal = d;
+              }
+              if ((en_gf && 2 < first_fail) || (en_al && 3 < first_fail)) {
+                double sx = x, sy = y;
+                if (fpd != 0.0) {
+                  sx = x + fpd * cs;
+                  sy = y + fpd * sn;
+                }
+                uint32_t ux, uy;
+                if (!w2m(sx, sy, ux, uy)) {
+                  fail_code = -4;
+                  first_fail = (en_gf && 2 < first_fail) ? 2 : 3;
+                } else if (last_pt) {  // aggregation Last: only the final point's value survives
+                  const uint32_t cell = uy * g.nx + ux;
+                  if (en_gf && 2 < first_fail) d_gf = dfront[cell];
+                  if (en_al && 3 < first_fail) d_al = dpath[cell];
                 }
               }
+              scr_z = first_fail > 4 ? 0xFFFFFFFFu : 0u;  // (first_fail only changes in here)
+              scr_w = first_fail > 5 ? 0xFFFFFFFFu : 0u;
             }
-            if ((en_gf && 2 < first_fail) || (en_al && 3 < first_fail)) {
-              double sx = x, sy = y;
-              if (fpd != 0.0) {
-                sx = x + fpd * cs;
-                sy = y + fpd * sn;
-              }
-              uint32_t ux, uy;
-              if (!w2m(sx, sy, ux, uy)) {
-                fail_code = -4;
-                first_fail = (en_gf && 2 < first_fail) ? 2 : 3;
-              } else if (last_pt) {  // aggregation Last: only the final point's value survives
-                const uint32_t cell = uy * g.nx + ux;
-                if (en_gf && 2 < first_fail) d_gf = dfront[cell];
-                if (en_al && 3 < first_fail) d_al = dpath[cell];
-              }
+            if (stall) {  // back to the point as it was: (float)x is the old px exactly
+              px = (float)x;
+              py = (float)y;
+              step = sc;
             }
+            alive_m = first_fail > min_order ? 0xFFFFFFFFu : 0u;
           }
-          alive = first_fail > min_order;
         }
-        if (!stall) {
-          px = nxp;
-          py = nyp;
-          ++step;
-        }
+        alive_m = step < K ? alive_m : 0u;
       }
     }
     __syncthreads();  // the block's entries are in the queue
@@ -494,13 +536,17 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
       const double x = s_qx[e], y = s_qy[e];
       const int e_step = (int)((tag >> 8) & 0xFFu), e_row = (int)((tag >> 16) & 0x7FFFu);
       const uint32_t owner = tag & 0xFFu;
-      double f_cost = 0.0;
-      const bool bad = walkFootprint(x, y, e_row * K + e_step, f_cost);
-      if (bad) {
+      const int te = e_row * K + e_step;
+      uint32_t mx_cost;
+      bool outside;
+      const bool off = walkWindow(x, y, te, mx_cost, outside);
+      if (__builtin_expect(outside && !off, 0)) mx_cost = walkCostmap(x, y, te);
+      if (off || mx_cost >= walk_fail) {  // footprint_cost < 0
         atomicOr(&s_obs[owner], kWalkFailed);
       } else if (tag >> 31) {
         // the centre is on the map here (a point off the map never gets into the queue), so the -7 branch
         // (obstacle_cost_function.cpp:135-137) cannot fire; occ_cost = max(max(0, footprint_cost), centre cell)
+        const double f_cost = (walk_swap && mx_cost == 254u) ? 255.0 : (double)mx_cost;  // an allowed NO_INFORMATION cell costs 255
         uint32_t cx, cy;
         w2m(x, y, cx, cy);
         const double occ = fmax(fmax(0.0, f_cost), (double)cellCost(cx, cy));
@@ -508,11 +554,11 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
       }
     }
     if (tid == 0) s_qn[(blk + 1u) & 1u] = 0;  // (last touched before the previous block's second barrier)
-    const int more = __syncthreads_or(alive && step < K);
-    if (alive && (s_obs[tid] & kWalkFailed)) {  // a walked point of this lane failed: footprint_cost < 0 -> -6
+    const int more = __syncthreads_or(alive_m != 0u);
+    if ((s_obs[tid] & kWalkFailed) != 0u && first_fail > 1) {  // a walked point of this lane failed: footprint_cost < 0 -> -6 (also after its last point)
       fail_code = -6;
       first_fail = 1;
-      alive = false;
+      alive_m = 0;
     }
     if (!more) break;
   }

@@ -23,9 +23,9 @@ out, tag = sys.argv[1], sys.argv[2]
 # profiled regions of the library (navgpu_kernel_name) <- the device kernels they launch
 GROUPS = {"k_obstacle": ("k_obstacle",), "k_merge": ("k_merge",), "k_inflate": ("k_inflate", "k_inflate_bits", "k_inflate_pq"),
           "k_bfs": ("k_bfs", "k_bfs_rows", "k_bfs_rows2", "k_bfs_wave", "k_bfs_global", "k_free_bits"),
-          "k_score": ("k_score_tab", "k_score_gen", "k_score_prep_tab", "k_score_prep_gen"), "k_select": ("k_select",),
+          "k_score": ("k_score_sweep", "k_score_tab", "k_score_gen", "k_score_prep_tab", "k_score_prep_gen"), "k_select": ("k_select",),
           "k_samples": ("k_samples",)}
-MAIN = {"k_score": ("k_score_tab", "k_score_gen"), "k_bfs": ("k_bfs", "k_bfs_rows", "k_bfs_rows2", "k_bfs_wave", "k_bfs_global")}
+MAIN = {"k_score": ("k_score_sweep", "k_score_tab", "k_score_gen"), "k_bfs": ("k_bfs", "k_bfs_rows", "k_bfs_rows2", "k_bfs_wave", "k_bfs_global")}
 N_SIMD, N_CU, N_XCD = 1024, 256, 8
 
 
