@@ -240,6 +240,7 @@ void launch_sincos(const double* th, uint32_t n, double* sn, double* cs, hipStre
 size_t score_table_bytes(const PlannerDev& pl);
 size_t score_window_bytes(uint32_t win);
 size_t score_prep_bytes(const PlannerDev& pl);
+size_t score_prep_slot_bytes(const PlannerDev& pl);
 size_t bfs_scratch_words(uint32_t nx, uint32_t ny);
 uint32_t score_table_rows(const PlannerDev& pl, uint32_t win);
 

@@ -768,7 +768,7 @@ static void updateWindow(navgpu_fleet* f) {
 static int ensurePrep(navgpu_fleet* f) {
   PlannerDev tmp = f->pl;
   tmp.use_tables = 1;  // upper bound: the image with tables, whatever the launch decides
-  const size_t need = (score_prep_bytes(tmp) + 255) & ~(size_t)255;
+  const size_t need = (score_prep_slot_bytes(tmp) + 255) & ~(size_t)255;
   if (f->pl.prep && need <= f->pl.prep_stride) return NAVGPU_OK;
   HIP_TRY(waitStream(f->stream));
   f->release(f->pl.prep);

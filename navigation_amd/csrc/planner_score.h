@@ -37,6 +37,11 @@ __device__ __forceinline__ int divSmall(int n, int d) {
   return q;
 }
 
+// behind a robot's image in pl.prep (k_score_prep_tab writes them, k_score_sweep reads them): kScoreAuxBytes of per-robot scalars
+// and one byte per (vx, vy) pair, at the END of the robot's slot
+constexpr uint32_t kScoreAuxBytes = 64;
+__host__ __device__ inline uint32_t score_prep_reject_bytes(const PlannerDev& pl) { return (pl.max_axis * pl.max_axis + 255u) & ~255u; }
+__host__ __device__ inline uint32_t score_prep_reject_offset(const PlannerDev& pl) { return pl.prep_stride - score_prep_reject_bytes(pl); }
 size_t score_table_row_bytes(const PlannerDev& pl);
 size_t score_table_lds_bytes(const PlannerDev& pl);
 // k_score_sweep (planner_score_sweep.hip): the launch for use_dwa && discretize_by_time with DWAPlanner's own MapGrid options

@@ -305,6 +305,41 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     const uint32_t n16 = pl.prep_bytes >> 4;
     if (PREP == 1) {
       for (uint32_t i = tid; i < n16; i += blockDim.x) img[i] = lds[i];
+      if (TABLES) {
+        // What every lane of the sweep launch would otherwise work out again: the robot's scalars (two fp64 divisions, a ceil)
+        // and the generator's reject tests of the (vx, vy) pairs (a compensated fp64 square root each) - behind the image.
+        uint8_t* rej = pl.prep + (size_t)inst * pl.prep_stride + score_prep_reject_offset(pl);
+        int32_t* aux = reinterpret_cast<int32_t*>(rej - kScoreAuxBytes);
+        if (tid == 0) {
+          const double inv_res = pl.inv_res, fpd = c.forward_point_distance;
+          const bool en_fwd = pl.scale_goal != 0 || (pl.align_on[inst] && pl.scale_path != 0);  // goal_front or alignment critic on
+          // the forward point (x + fpd cos, y + fpd sin) stays on the map whenever the centre cell is this many cells away from
+          // every border; only then may a step skip its worldToMap
+          const uint32_t fwd_margin = (uint32_t)fmin(ceil(fabs(fpd) * inv_res) + 1.0, 1.0e6);
+          const bool fwd_screen = !en_fwd || (2u * fwd_margin < g.nx && 2u * fwd_margin < g.ny);
+          const uint32_t fwd_lo = en_fwd ? fwd_margin : 0u, fwd_nx = g.nx - 2u * fwd_lo, fwd_ny = g.ny - 2u * fwd_lo;
+          // the forward-margin test is only needed when the LDS window reaches into the margin band of the map
+          const bool need_margin = !((uint32_t)wx0 - fwd_lo < fwd_nx && (uint32_t)(wx0 + win - 1) - fwd_lo < fwd_nx && (uint32_t)wy0 - fwd_lo < fwd_ny &&
+                                     (uint32_t)(wy0 + win - 1) - fwd_lo < fwd_ny);
+          aux[0] = wx0;
+          aux[1] = wy0;
+          aux[2] = (int32_t)fwd_lo;
+          aux[3] = (int32_t)fwd_nx;
+          aux[4] = (int32_t)fwd_ny;
+          aux[5] = need_margin ? 1 : 0;
+          aux[6] = fwd_screen ? 1 : 0;
+          aux[7] = 0;
+        }
+        // generateTrajectory's reject tests (simple_trajectory_generator.cpp:193-200), the part that depends on (vx, vy) only:
+        // bit 0: vmag + eps < min_trans_vel (rejects together with the v_theta half), bit 1: vmag - eps > max_trans_vel
+        const int nyv = max(cnt[1], 1), nxyv = cnt[0] * cnt[1];
+        for (int i = tid; i < nxyv; i += blockDim.x) {
+          const int ix = i / nyv, iy = i - ix * nyv;
+          const double vmag = hyp2((double)s_axis[0][ix], (double)s_axis[1][iy]);
+          const double eps = 1e-4;
+          rej[i] = (uint8_t)(((c.min_trans_vel >= 0 && vmag + eps < c.min_trans_vel) ? 1 : 0) | ((c.max_trans_vel >= 0 && vmag - eps > c.max_trans_vel) ? 2 : 0));
+        }
+      }
       return;
     }
     if (!TABLES) {
@@ -993,6 +1028,9 @@ uint32_t score_table_rows(const PlannerDev& pl, uint32_t win) {
 }
 size_t score_prep_bytes(const PlannerDev& pl) {  // the LDS image k_score_prep* stores per robot
   return score_window_bytes(pl.win) + (pl.use_tables ? score_table_bytes(pl) : 0);
+}
+size_t score_prep_slot_bytes(const PlannerDev& pl) {  // a robot's slot of pl.prep: the image, the sweep launch's scalars, the pairs' reject bytes
+  return ((score_prep_bytes(pl) + 255) & ~(size_t)255) + kScoreAuxBytes + score_prep_reject_bytes(pl);
 }
 uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, const float* explicit_sample, hipStream_t s) {
   PlannerDev pl = pl_in;

@@ -36,24 +36,34 @@ constexpr int kSweepThreads = NAVGPU_SCORE_TAB_THREADS;
 constexpr int kSweepBlockSteps = NAVGPU_SWEEP_BLOCK_STEPS;  // trajectory points a lane sweeps between two walk phases
 constexpr int kSweepQueue = NAVGPU_SWEEP_QUEUE;             // walk entries a workgroup holds (12 B each)
 constexpr uint32_t kWalkFailed = 0x80000000u;               // s_obs[owner]: a walked point failed; low bits: summed costs
+#ifdef NAVGPU_SWEEP_TIMING  // experiment builds only (tools/probe_sweep_timing.py): where a wave's time goes, one workgroup in 16 reports
+__device__ unsigned long long g_sweep_stats[16];
+#define SW_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define SW_ACC(i, x) sw_t[i] += (x)
+#else
+#define SW_STAMP(v)
+#define SW_ACC(i, x)
+#endif
 
 template <int CHUNK>
 __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score_sweep(PlannerDev pl, uint32_t first) {
   constexpr int THREADS = kSweepThreads;
   extern __shared__ __align__(16) uint8_t s_dyn[];
   uint8_t* s_win = s_dyn;
-  __shared__ double s_fp[2 * kMaxFootprint];
-  __shared__ float s_axis[3][kMaxAxis];
   __shared__ double s_rc[THREADS / 64];
   __shared__ int s_ri[THREADS / 64];
   __shared__ int s_cnt[2];
   __shared__ float s_qx[kSweepQueue], s_qy[kSweepQueue];
-  __shared__ uint32_t s_qt[kSweepQueue];  // owner lane | step << 8 | table row << 16 | cost wanted << 31
+  __shared__ uint32_t s_qt[kSweepQueue];  // owner lane | step << 10 | table row << 17 | cost wanted << 31
   __shared__ uint32_t s_obs[THREADS];
   __shared__ uint32_t s_qn[2];
 
   const uint32_t inst = first + blockIdx.y;
   const uint32_t tid = threadIdx.x;
+#ifdef NAVGPU_SWEEP_TIMING
+  unsigned long long sw_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  SW_STAMP(sw0);
   __builtin_amdgcn_s_setprio(3);  // a new workgroup's waves are the youngest on their SIMDs: get the image in before yielding
   const navgpu_dwa_config& c = pl.cfg;
   const Geom g = geomOf(pl, inst);
@@ -67,27 +77,19 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   const uint32_t nfp = pl.fp_n[inst];
   const int win = (int)pl.win;
 
-  // ---- stage (one batch of loads, one barrier): footprint, per-axis samples, the robot's image
-  constexpr int kAxisChunks = (3 * kMaxAxis + THREADS - 1) / THREADS;
-  const double pre_fp = pl.fp_spec[(size_t)inst * kMaxFootprint * 2 + (tid < 2 * nfp ? tid : 0)];
-  float pre_axis[kAxisChunks];
-#pragma unroll
-  for (int u = 0; u < kAxisChunks; ++u) {
-    const uint32_t i = min(tid + (uint32_t)u * THREADS, 3u * kMaxAxis - 1), a = i / kMaxAxis, k = i - a * kMaxAxis;
-    pre_axis[u] = pl.axis_samples[((size_t)inst * 3 + a) * pl.max_axis + min(k, pl.max_axis - 1)];
-    if (k >= pl.max_axis) pre_axis[u] = 0.f;
-  }
+  // ---- stage (one batch of loads, one barrier): the robot's image; the lane's own sample and reject byte come straight from HBM
   if (tid == 0) s_cnt[0] = s_cnt[1] = 0;
   if (tid < 2) s_qn[tid] = 0;
   s_obs[tid] = 0;
-  int wx0, wy0;
-  {  // window origin: robot cell (floor of the map coordinate, also valid when the robot is off the map)
-    double fx = floor(((double)st.pos[0] - g.ox) / g.res), fy = floor(((double)st.pos[1] - g.oy) / g.res);
-    fx = fmin(fmax(fx, -1.0e6), 1.0e6);
-    fy = fmin(fmax(fy, -1.0e6), 1.0e6);
-    wx0 = (int)fx - win / 2;
-    wy0 = (int)fy - win / 2;
-  }
+  // the robot's scalars, worked out once by k_score_prep_tab (planner_score.hip): window origin (robot cell - win / 2), the
+  // forward point's margin band, whether this launch can screen at all; and the loads the lanes need later, issued now
+  const uint8_t* rej_bytes = pl.prep + (size_t)inst * pl.prep_stride + score_prep_reject_offset(pl);
+  const int32_t* aux = reinterpret_cast<const int32_t*>(rej_bytes - kScoreAuxBytes);
+  const int wx0 = aux[0], wy0 = aux[1];
+  const uint32_t fwd_lo = (uint32_t)aux[2], fwd_nx = (uint32_t)aux[3], fwd_ny = (uint32_t)aux[4];
+  const bool need_margin = aux[5] != 0, fwd_screen = aux[6] != 0;
+  const uint32_t osc = pl.osc_flags[inst];
+  const int32_t align_on = pl.align_on[inst];
   const int win_bytes = (win * win + 15) & ~15;
   const int nw = (win + 31) >> 5;
   const bool walk_swap = pl.cfg.allow_unknown != 0;  // the window bytes are kept in walk order (planner_score.hip)
@@ -97,7 +99,6 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   const int lrows = (int)pl.tab_rows;
   double* s_trig = reinterpret_cast<double*>(s_dyn + win_bytes + score_bits_bytes(win));  // [rows][K][4] cs, sn, cs2, sn2
   double* s_rot = s_trig + (size_t)lrows * K * 4;                                          // [rows][K][tnfp][2]
-  float* s_th = reinterpret_cast<float*>(s_rot + (size_t)lrows * K * tnfp * 2);            // [rows][K]
   // Lane mapping.  Lanes are v_theta-major so that a wave shares one heading sequence.  The v_theta rows are cut into groups
   // of tab_rows (what the LDS budget holds); a group takes bpg consecutive workgroups, which enumerate its rows x (vx, vy)
   // pairs.  Blocks past the last group idle.
@@ -118,6 +119,19 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
       return;
     }
   }
+  // ---- lane -> sample slot (x-outer, y, theta-inner, as the reference enumerates: what results are keyed by), and its loads
+  const int li = t_li0 + (int)tid;
+  const int t_row = divSmall(li, nxy);  // row within the group = row of the tables in LDS
+  const int t_r = li - t_row * nxy;     // index of the (vx, vy) pair, x-outer
+  const int t_ith = t_row_base + t_row;
+  const bool in_range = n_samples > 0 && t_row < t_rows;
+  const int sidx = t_r * cnt[2] + t_ith;
+  const int nyv = max(cnt[1], 1);
+  const int s_ix = divSmall(t_r, nyv), s_iy = t_r - s_ix * nyv;
+  const float* axis = pl.axis_samples + (size_t)inst * 3 * pl.max_axis;
+  const uint32_t amax = pl.max_axis - 1u;
+  const float vs0 = axis[min((uint32_t)s_ix, amax)], vs1 = axis[pl.max_axis + min((uint32_t)s_iy, amax)], vs2 = axis[2u * pl.max_axis + min((uint32_t)t_ith, amax)];
+  const uint32_t rej_xy = rej_bytes[in_range ? t_r : 0];  // the (vx, vy) pair's half of the reject tests (k_score_prep_tab)
   {  // window + screens, and of the tables only the v_theta rows this workgroup's samples use, at their usual place
     const uint4* img = reinterpret_cast<const uint4*>(pl.prep + (size_t)inst * pl.prep_stride);
     uint4* lds = reinterpret_cast<uint4*>(s_dyn);
@@ -130,30 +144,23 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
     const int l_trig = n16w + r0 * K * 2, g_trig = n16w + (t_row_base + r0) * K * 2;
     const int l_rot = n16w + lrows * K * 2 + r0 * K * tnfp, g_rot = n16w + (int)pl.tab_nth * K * 2 + (t_row_base + r0) * K * tnfp;
     const int n16t = n16w + n_trig + n_rot;
-    const float* g_th = reinterpret_cast<const float*>(img + n16w + (size_t)pl.tab_nth * K * (2 + tnfp)) + t_row_base * K;
     auto srcOf = [&](int i) { return i < n16w ? i : (i < n16w + n_trig ? g_trig + (i - n16w) : g_rot + (i - n16w - n_trig)); };
     auto dstOf = [&](int i) { return i < n16w ? i : (i < n16w + n_trig ? l_trig + (i - n16w) : l_rot + (i - n16w - n_trig)); };
     constexpr int kBatch = 4;  // 16-byte loads a lane has in flight (4 x 256 lanes x 16 B = 16 KB: a configs[2] image whole)
     uint4 v[kBatch];
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) v[u] = img[srcOf(min((int)tid + u * THREADS, n16t - 1))];
-    const int th_i = r0 * K + (int)tid, th_n = (r0 + ncopy) * K;
-    const float th_v = g_th[min(th_i, max(th_n - 1, 0))];
 #pragma unroll
     for (int u = 0; u < kBatch; ++u)
       if ((int)tid + u * THREADS < n16t) lds[dstOf((int)tid + u * THREADS)] = v[u];
-    if (th_i < th_n) s_th[th_i] = th_v;
-    if (tid < 2 * nfp) s_fp[tid] = pre_fp;
-#pragma unroll
-    for (int u = 0; u < kAxisChunks; ++u) {
-      const uint32_t i = tid + (uint32_t)u * THREADS;
-      if (i < 3u * kMaxAxis) s_axis[i / kMaxAxis][i % kMaxAxis] = pre_axis[u];
-    }
     for (int i = (int)tid + kBatch * THREADS; i < n16t; i += THREADS) lds[dstOf(i)] = img[srcOf(i)];  // larger images: the rest
-    for (int i = th_i + THREADS; i < th_n; i += THREADS) s_th[i] = g_th[i];
   }
+  SW_STAMP(sw1a);
   __syncthreads();
   __builtin_amdgcn_s_setprio(0);
+  SW_STAMP(sw1);
+  SW_ACC(0, sw1a - sw0);
+  SW_ACC(1, sw1 - sw1a);
 
   // NOTE: the LDS read is unconditional (clamped index) and the global fallback sits in its own rarely-taken branch; a
   // `cond ? lds[i] : global[j]` form makes hipcc merge both into one FLAT load.
@@ -299,40 +306,18 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
     return mx;
   };
 
-  // ---- lane -> sample slot (x-outer, y, theta-inner, as the reference enumerates: what results are keyed by)
-  const int li = t_li0 + (int)tid;
-  const int t_row = divSmall(li, nxy);  // row within the group = row of the tables in LDS
-  const int t_r = li - t_row * nxy;     // index of the (vx, vy) pair, x-outer
-  const int t_ith = t_row_base + t_row;
-  const bool in_range = n_samples > 0 && t_row < t_rows;
-  const int sidx = t_r * cnt[2] + t_ith;
   double total = -1.0;
   int status = NAVGPU_SAMPLE_REJECTED;
-
-  float vs[3] = {0.f, 0.f, 0.f};
-  bool reject = true;
-  if (in_range) {
-    const int nyv = cnt[1];
-    const int ix = divSmall(t_r, nyv), iy = t_r - ix * nyv;
-    vs[0] = s_axis[0][ix];
-    vs[1] = s_axis[1][iy];
-    vs[2] = s_axis[2][t_ith];
-    // generateTrajectory: reject tests (:193-200); the step count is the tables' (ceil(sim_time / sim_granularity), host)
-    const double vmag = hyp2((double)vs[0], (double)vs[1]);
-    const double eps = 1e-4;
-    reject = false;
-    if ((c.min_trans_vel >= 0 && vmag + eps < c.min_trans_vel) && (c.min_rot_vel >= 0 && fabs((double)vs[2]) + eps < c.min_rot_vel)) reject = true;
-    if (c.max_trans_vel >= 0 && vmag - eps > c.max_trans_vel) reject = true;
-    if (K <= 0) reject = true;  // `return num_steps > 0` (:250)
-  }
-  if (!reject) status = NAVGPU_SAMPLE_SCORED;
+  const float vs[3] = {vs0, vs1, vs2};
+  // generateTrajectory: reject tests (:193-200); the step count is the tables' (ceil(sim_time / sim_granularity), host)
+  const bool reject = !in_range || ((rej_xy & 1u) && (c.min_rot_vel >= 0 && fabs((double)vs2) + 1e-4 < c.min_rot_vel)) || (rej_xy & 2u) || K <= 0;  // `return num_steps > 0` (:250)
+  if (in_range && !reject) status = NAVGPU_SAMPLE_SCORED;
   const double dt = pl.tab_dt;
   const double xv = vs[0], yv = vs[1], thv = vs[2];  // traj.xv_, yv_, thetav_
-  const uint32_t osc = pl.osc_flags[inst];
   const bool osc_fail = ((osc & NAVGPU_OSC_FORWARD_POS_ONLY) && xv < 0.0) || ((osc & NAVGPU_OSC_FORWARD_NEG_ONLY) && xv > 0.0) ||
                         ((osc & NAVGPU_OSC_STRAFE_POS_ONLY) && yv < 0.0) || ((osc & NAVGPU_OSC_STRAFE_NEG_ONLY) && yv > 0.0) ||
                         ((osc & NAVGPU_OSC_ROT_POS_ONLY) && thv < 0.0) || ((osc & NAVGPU_OSC_ROT_NEG_ONLY) && thv > 0.0);
-  const double sc_obs = pl.scale_obstacle, sc_gf = pl.scale_goal, sc_al = pl.align_on[inst] ? pl.scale_path : 0.0, sc_path = pl.scale_path,
+  const double sc_obs = pl.scale_obstacle, sc_gf = pl.scale_goal, sc_al = align_on ? pl.scale_path : 0.0, sc_path = pl.scale_path,
                sc_goal = pl.scale_goal;
   const bool en_obs = sc_obs != 0, en_gf = sc_gf != 0, en_al = sc_al != 0, en_path = sc_path != 0, en_goal = sc_goal != 0;
   // first_fail: order index of the earliest critic in the list that has failed (1 obstacle .. 5 goal), 6 = none; fail_code its
@@ -340,6 +325,11 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   int first_fail = 6;
   int fail_code = 0;
   uint32_t d_gf = 0, d_al = 0, d_path = 0, d_goal = 0;  // the map-grid critics' values (aggregation Last: the final point's)
+  // The distance grids are read ONCE per lane, after the rollout, all loads in flight together (a look-up where it comes up is a
+  // dependent L2 round trip in the middle of a wave's sweep: the points that looked closer took 1.7 us each).  Until then:
+  //   fail_cell  cell where the path / goal critic failed by its screen bit (the bit IS the test; the grid says which code)
+  //   last_c, last_f  centre and forward cell of the final point; last_f = ~0: that point was never reached
+  uint32_t fail_cell = 0xFFFFFFFFu, last_c = 0, last_f = 0xFFFFFFFFu;
   const double fpd = c.forward_point_distance;
   const uint32_t N_obst = pl.cells, N_unreach = pl.cells + 1;
   if (en_obs && nfp == 0) {  // "Footprint spec is empty" (obstacle_cost_function.cpp:78-82)
@@ -349,20 +339,11 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   // a critic is live while no critic before it in the order has failed; the lowest enabled order decides when nothing is
   // left to evaluate
   const int min_order = en_obs ? 1 : en_gf ? 2 : en_al ? 3 : en_path ? 4 : en_goal ? 5 : 6;
-  // the forward point (x + fpd cos, y + fpd sin) stays on the map whenever the centre cell is this many cells away from every
-  // border; only then may a step skip its worldToMap
-  const uint32_t fwd_margin = (uint32_t)fmin(ceil(fabs(fpd) * inv_res) + 1.0, 1.0e6);
-  const bool fwd_screen = !(en_gf || en_al) || (2u * fwd_margin < g.nx && 2u * fwd_margin < g.ny);
-  const uint32_t fwd_lo = (en_gf || en_al) ? fwd_margin : 0u, fwd_nx = g.nx - 2u * fwd_lo, fwd_ny = g.ny - 2u * fwd_lo;
   uint32_t fb_off = (uint32_t)win_bytes;  // (in a vector register: as a scalar it is spilled and read back with v_readlane at every point)
   asm volatile("" : "+v"(fb_off));
   const uint4* s_fb4 = reinterpret_cast<const uint4*>(s_dyn + fb_off);
   const bool scr_sum = c.sum_scores != 0;  // the obstacle screen: dilated "not free" with sum_scores, else dilated "can fail"
   const bool screen_on = fwd_screen && (nfp >= 3 || !en_obs);
-  // the forward-margin test is only needed when the LDS window reaches into the margin band of the map (wave-uniform)
-  const bool need_margin = !((uint32_t)wx0 - fwd_lo < fwd_nx && (uint32_t)(wx0 + win - 1) - fwd_lo < fwd_nx && (uint32_t)wy0 - fwd_lo < fwd_ny &&
-                             (uint32_t)(wy0 + win - 1) - fwd_lo < fwd_ny);
-
   float px = st.pos[0], py = st.pos[1];
   int step = 0;  // the lane's next trajectory point; stops at K or where the rollout ended
   // all-ones while the lane's rollout goes on (kept as a mask in a vector register: as a bool the compiler branches on it)
@@ -378,7 +359,10 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   // change the outcome any more); all-ones where the launch has no screen at all
   uint32_t scr_z = 0xFFFFFFFFu, scr_w = 0xFFFFFFFFu;
   const uint32_t scr_off = screen_on ? 0u : 0xFFFFFFFFu;
+  SW_STAMP(sw2);
+  SW_ACC(2, sw2 - sw1);
   for (uint32_t blk = 0;; ++blk) {
+    SW_STAMP(sb0);
     // ---- sweep: up to kSweepBlockSteps points per lane.  The screened path is STRAIGHT-LINE for the whole wave - lanes whose
     // rollout is over compute along (their state is never read again) - and ends in one wave-uniform branch: does any live
     // lane have to look closer?  (Written with the usual per-lane conditions the compiler spends as many scalar instructions
@@ -414,6 +398,7 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
         py = nyp;
         step -= (int)alive_m;  // (+1 while alive)
         if (__ballot(unscr) != 0ull) {  // (wave-uniform)
+          SW_STAMP(ss0);
           if (unscr) {
             const bool last_pt = sc == K - 1;
             const bool on_map = cx < g.nx && cy < g.ny;  // (= ok_c)
@@ -455,7 +440,7 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
                     if (slot < (uint32_t)kSweepQueue) {
                       s_qx[slot] = (float)x;
                       s_qy[slot] = (float)y;
-                      s_qt[slot] = tid | ((uint32_t)sc << 8) | ((uint32_t)t_row << 16) | ((scr_sum || last_pt) ? 0x80000000u : 0u);
+                      s_qt[slot] = tid | ((uint32_t)sc << 10) | ((uint32_t)t_row << 17) | ((scr_sum || last_pt) ? 0x80000000u : 0u);
                     } else {
                       stall = true;  // the queue is full: this point is taken again in the next block
                     }
@@ -470,31 +455,35 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
                   first_fail = (en_path && 4 < first_fail) ? 4 : 5;
                 } else {
                   const uint32_t cell = cy * g.nx + cx;
-                  // A point of the window whose path / goal screen bit is clear cannot fail that critic (the bit IS the failure
-                  // test, taken from this cycle's grid by the prep launch), and of the distances only the LAST point's survives
-                  const bool look_p = last_pt || !in_w || ((fbw.z >> (lxw & 31)) & 1u);
-                  const bool look_g = last_pt || !in_w || ((fbw.w >> (lxw & 31)) & 1u);
-                  if (en_path && 4 < first_fail && look_p) {
-                    const uint32_t d = dpath[cell];
-                    if (d == N_obst) {
-                      fail_code = -3;
+                  if (last_pt) {
+                    last_c = cell;  // aggregation Last: the final point's distances survive (read after the rollout)
+                  } else if (in_w) {
+                    // A point of the window whose path / goal screen bit is clear cannot fail that critic (the bit IS the failure
+                    // test, taken from this cycle's grid by the prep launch); a set bit fails it: -3 or -2, the grid says which
+                    if (en_path && 4 < first_fail && ((fbw.z >> (lxw & 31)) & 1u)) {
+                      fail_code = 0;
                       first_fail = 4;
-                    } else if (d == N_unreach) {
-                      fail_code = -2;
-                      first_fail = 4;
-                    } else
-                      d_path = d;
-                  }
-                  if (en_goal && 5 < first_fail && look_g) {
-                    const uint32_t d = dgoal[cell];
-                    if (d == N_obst) {
-                      fail_code = -3;
+                      fail_cell = cell;
+                    } else if (en_goal && 5 < first_fail && ((fbw.w >> (lxw & 31)) & 1u)) {
+                      fail_code = 0;
                       first_fail = 5;
-                    } else if (d == N_unreach) {
-                      fail_code = -2;
-                      first_fail = 5;
-                    } else
-                      d_goal = d;
+                      fail_cell = cell;
+                    }
+                  } else {  // outside the LDS window (never, with a correctly sized one): look the grids up here
+                    if (en_path && 4 < first_fail) {
+                      const uint32_t d = dpath[cell];
+                      if (d == N_obst || d == N_unreach) {
+                        fail_code = d == N_obst ? -3 : -2;
+                        first_fail = 4;
+                      }
+                    }
+                    if (en_goal && 5 < first_fail) {
+                      const uint32_t d = dgoal[cell];
+                      if (d == N_obst || d == N_unreach) {
+                        fail_code = d == N_obst ? -3 : -2;
+                        first_fail = 5;
+                      }
+                    }
                   }
                 }
               }
@@ -508,11 +497,11 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
                 if (!w2m(sx, sy, ux, uy)) {
                   fail_code = -4;
                   first_fail = (en_gf && 2 < first_fail) ? 2 : 3;
-                } else if (last_pt) {  // aggregation Last: only the final point's value survives
-                  const uint32_t cell = uy * g.nx + ux;
-                  if (en_gf && 2 < first_fail) d_gf = dfront[cell];
-                  if (en_al && 3 < first_fail) d_al = dpath[cell];
+                } else if (last_pt) {
+                  last_f = uy * g.nx + ux;
                 }
+              } else if (last_pt) {
+                last_f = 0;  // (reached; no forward critic to read for)
               }
               scr_z = first_fail > 4 ? 0xFFFFFFFFu : 0u;  // (first_fail only changes in here)
               scr_w = first_fail > 5 ? 0xFFFFFFFFu : 0u;
@@ -524,18 +513,25 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
             }
             alive_m = first_fail > min_order ? 0xFFFFFFFFu : 0u;
           }
+          SW_STAMP(ss1);
+          SW_ACC(4, ss1 - ss0);
+          SW_ACC(9, 1);
         }
         alive_m = step < K ? alive_m : 0u;
       }
     }
+    SW_STAMP(sb1);
+    SW_ACC(3, sb1 - sb0);
     __syncthreads();  // the block's entries are in the queue
+    SW_STAMP(sb2);
+    SW_ACC(5, sb2 - sb1);
     // ---- walk: the workgroup's lanes take the entries, whoever pushed them
     const int nq = (int)min(s_qn[blk & 1u], (uint32_t)kSweepQueue);
     for (int e = (int)tid; e < nq; e += THREADS) {
       const uint32_t tag = s_qt[e];
       const double x = s_qx[e], y = s_qy[e];
-      const int e_step = (int)((tag >> 8) & 0xFFu), e_row = (int)((tag >> 16) & 0x7FFFu);
-      const uint32_t owner = tag & 0xFFu;
+      const int e_step = (int)((tag >> 10) & 0x7Fu), e_row = (int)((tag >> 17) & 0x3FFFu);
+      const uint32_t owner = tag & 0x3FFu;
       const int te = e_row * K + e_step;
       uint32_t mx_cost;
       bool outside;
@@ -554,7 +550,11 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
       }
     }
     if (tid == 0) s_qn[(blk + 1u) & 1u] = 0;  // (last touched before the previous block's second barrier)
+    SW_STAMP(sb3);
+    SW_ACC(6, sb3 - sb2);
     const int more = __syncthreads_or(alive_m != 0u);
+    SW_STAMP(sb4);
+    SW_ACC(7, sb4 - sb3);
     if ((s_obs[tid] & kWalkFailed) != 0u && first_fail > 1) {  // a walked point of this lane failed: footprint_cost < 0 -> -6 (also after its last point)
       fail_code = -6;
       first_fail = 1;
@@ -563,6 +563,32 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
     if (!more) break;
   }
 
+  {  // ---- the distance grids, once: every load in flight before the first is used (clamped addresses; unused ones are ignored)
+    const bool reached = last_f != 0xFFFFFFFFu && first_fail > 1;  // the final point was scored (and no walk failed since)
+    const uint32_t cmax = pl.cells - 1u;
+    const uint32_t v_fail = (first_fail == 4 ? dpath : dgoal)[min(fail_cell, cmax)];
+    const uint32_t v_gf = dfront[min(last_f, cmax)], v_al = dpath[min(last_f, cmax)];
+    const uint32_t v_path = dpath[min(last_c, cmax)], v_goal = dgoal[min(last_c, cmax)];
+    if ((first_fail == 4 || first_fail == 5) && fail_code == 0) fail_code = v_fail == N_obst ? -3 : -2;
+    if (reached) {  // in the critics' order; a critic that failed earlier on the trajectory (or follows one that did) is not read
+      if (en_gf && 2 < first_fail) d_gf = v_gf;
+      if (en_al && 3 < first_fail) d_al = v_al;
+      if (en_path && 4 < first_fail) {
+        if (v_path == N_obst || v_path == N_unreach) {
+          fail_code = v_path == N_obst ? -3 : -2;
+          first_fail = 4;
+        } else
+          d_path = v_path;
+      }
+      if (en_goal && 5 < first_fail) {
+        if (v_goal == N_obst || v_goal == N_unreach) {
+          fail_code = v_goal == N_obst ? -3 : -2;
+          first_fail = 5;
+        } else
+          d_goal = v_goal;
+      }
+    }
+  }
   if (in_range && !reject) {
     if (osc_fail) {
       total = -5.0;
@@ -621,12 +647,20 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
     if (s_cnt[0]) atomicAdd(&pl.counters[2 * inst], s_cnt[0]);
     if (s_cnt[1]) atomicAdd(&pl.counters[2 * inst + 1], s_cnt[1]);
   }
+#ifdef NAVGPU_SWEEP_TIMING
+  if ((tid & 63u) == 0 && (blockIdx.x & 3u) == 1 && (blockIdx.y & 3u) == 2) {
+    const unsigned long long sw9 = __builtin_amdgcn_s_memtime();
+    sw_t[8] = sw9 - sw0;
+    for (int i = 0; i < 10; ++i) atomicAdd(&g_sweep_stats[i], sw_t[i]);
+    atomicAdd(&g_sweep_stats[10], 1ull);
+  }
+#endif
 }
 
 // The sweep takes every launch of the table variant (use_dwa, discretize_by_time, DWAPlanner's own MapGrid options): its tags
-// hold 8 bits of lane and of step.
+// hold 10 bits of lane, 7 of step and 14 of table row.
 bool score_sweep_applies(const PlannerDev& pl) {
-  return pl.use_tables && !pl.mg_generic && pl.tab_steps >= 1 && pl.tab_steps <= 255 && kSweepThreads <= 256;
+  return pl.use_tables && !pl.mg_generic && pl.tab_steps >= 1 && pl.tab_steps <= 127 && pl.tab_rows < (1u << 14) && kSweepThreads <= 1024;
 }
 uint32_t launch_score_sweep(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
   const size_t lds = score_window_bytes(pl.win) + score_table_lds_bytes(pl);
@@ -645,5 +679,16 @@ uint32_t launch_score_sweep(const PlannerDev& pl, uint32_t first, uint32_t count
 #undef NAVGPU_SCORE_SWEEP
   return blocks;
 }
+
+#ifdef NAVGPU_SWEEP_TIMING
+extern "C" int navgpu_debug_sweep_stats(unsigned long long* out16, int reset) {
+  if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sweep_stats), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_stats), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 
 }  // namespace navgpu

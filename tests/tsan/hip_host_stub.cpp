@@ -76,6 +76,7 @@ void launch_sincos(const double*, uint32_t, double*, double*, hipStream_t) {}
 size_t score_table_bytes(const PlannerDev&) { return 1024; }
 size_t score_window_bytes(uint32_t win) { return (size_t)win * win; }
 size_t score_prep_bytes(const PlannerDev& pl) { return (size_t)pl.win * pl.win + 4096; }
+size_t score_prep_slot_bytes(const PlannerDev& pl) { return (size_t)pl.win * pl.win + 4096 + 64 + 256 * 256; }
 size_t bfs_scratch_words(uint32_t, uint32_t) { return 0; }
 uint32_t score_table_rows(const PlannerDev&, uint32_t) { return 4; }
 void launch_navfn_costmap(const NavfnDev&, uint32_t, uint32_t, const uint8_t*, size_t, int, int, hipStream_t) {}

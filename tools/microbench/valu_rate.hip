@@ -49,6 +49,46 @@ __global__ void k(float* out, int iters, long long* cyc) {
 #define X(i) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f[i]) : "v"(d[i]));
       REP8(X) REP8(X) REP8(X) REP8(X)
 #undef X
+    } else if (KIND == 7) {
+#define X(i) asm volatile("v_floor_f64 %0, %0" : "+v"(d[i]));
+      REP8(X) REP8(X) REP8(X) REP8(X)
+#undef X
+    } else if (KIND == 8) {
+#define X(i) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(u[i]) : "v"(d[i]));
+      REP8(X) REP8(X) REP8(X) REP8(X)
+#undef X
+    } else if (KIND == 9) {
+#define X(i) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[i]) : "v"(f[i]));
+      REP8(X) REP8(X) REP8(X) REP8(X)
+#undef X
+    } else if (KIND == 10) {
+#define X(i) asm volatile("v_min_f64 %0, %0, %0" : "+v"(d[i]));
+      REP8(X) REP8(X) REP8(X) REP8(X)
+#undef X
+    } else if (KIND == 11) {
+#define X(i) asm volatile("v_cmp_gt_f64 vcc, %0, %0" : : "v"(d[i]) : "vcc");
+      REP8(X) REP8(X) REP8(X) REP8(X)
+#undef X
+    } else if (KIND == 12) {
+#define X(i) asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(u[i]) : : "vcc");
+      REP8(X) REP8(X) REP8(X) REP8(X)
+#undef X
+    } else if (KIND == 13) {  // scalar ALU: how many per clock does a CU's scalar unit retire with W waves per SIMD asking?
+      uint32_t s0 = it, s1 = it + 1, s2 = it + 2, s3 = it + 3;
+#define X(i) asm volatile("s_add_u32 %0, %0, %1\n s_add_u32 %1, %1, %2\n s_add_u32 %2, %2, %3\n s_add_u32 %3, %3, %0" : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
+      REP8(X)
+#undef X
+      u[0] += s0 + s1 + s2 + s3;
+    } else if (KIND == 14) {  // exec-mask bookkeeping as the compiler emits it around a divergent if
+#define X(i) asm volatile("s_and_saveexec_b64 s[20:21], vcc\n s_or_b64 exec, exec, s[20:21]\n s_and_saveexec_b64 s[22:23], vcc\n s_or_b64 exec, exec, s[22:23]" : : : "s20", "s21", "s22", "s23", "scc");
+      REP8(X)
+#undef X
+    } else if (KIND == 15) {  // VALU and SALU interleaved 1:1 in one wave: do they overlap across waves?
+      uint32_t s0 = it, s1 = it + 1;
+#define X(i) asm volatile("v_add_u32 %0, %0, %0\n s_add_u32 %1, %1, %2\n v_add_u32 %0, %0, %0\n s_add_u32 %2, %2, %1\n v_add_u32 %0, %0, %0\n s_add_u32 %1, %1, %2\n v_add_u32 %0, %0, %0\n s_add_u32 %2, %2, %1" : "+v"(u[i]), "+s"(s0), "+s"(s1) : : "scc");
+      REP8(X)
+#undef X
+      u[0] += s0 + s1;
     }
   }
   long long t1 = clock64();
@@ -107,5 +147,14 @@ int main() {
   run<2>("v_add_u32", out, cyc);
   run<5>("v_mul_lo_u32", out, cyc);
   run<6>("v_cvt_f32_f64", out, cyc);
+  run<7>("v_floor_f64", out, cyc);
+  run<8>("v_cvt_i32_f64", out, cyc);
+  run<9>("v_cvt_f64_f32", out, cyc);
+  run<10>("v_min_f64", out, cyc);
+  run<11>("v_cmp_gt_f64", out, cyc);
+  run<12>("v_cndmask_b32", out, cyc);
+  run<13>("s_add_u32", out, cyc);
+  run<14>("saveexec pair", out, cyc);
+  run<15>("v_add+s_add 1:1 (per pair: x2)", out, cyc);
   return 0;
 }
