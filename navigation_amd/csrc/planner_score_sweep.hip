@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   __shared__ uint32_t s_obs[THREADS];
   __shared__ uint32_t s_qn[2];
 
-  const uint32_t inst = first + blockIdx.y;
+  const uint32_t inst = first + blockIdx.z;  // grid: x = workgroup within its row group, y = row group, z = robot (a robot's workgroups are dispatched together)
   const uint32_t tid = threadIdx.x;
 #ifdef NAVGPU_SWEEP_TIMING
   unsigned long long sw_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -103,21 +103,16 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   // of tab_rows (what the LDS budget holds); a group takes bpg consecutive workgroups, which enumerate its rows x (vx, vy)
   // pairs.  Blocks past the last group idle.
   const int nxy = max(cnt[0] * cnt[1], 1);
-  int t_row_base, t_rows, t_li0;
-  {
-    const int R = (int)pl.tab_rows;
-    const int bpg = (nxy * R + THREADS - 1) / THREADS;
-    const int gi = (int)blockIdx.x / bpg;
-    t_row_base = gi * R;
-    t_rows = min(max(cnt[2] - t_row_base, 0), R);
-    t_li0 = ((int)blockIdx.x - gi * bpg) * THREADS;
-    if (t_li0 >= t_rows * nxy) {  // no sample for this workgroup (the last group's share is rounded up to the largest)
-      if (tid == 0) {
-        pl.part_cost[(size_t)inst * pl.score_blocks + blockIdx.x] = 1.0e300;
-        pl.part_index[(size_t)inst * pl.score_blocks + blockIdx.x] = 0x7FFFFFFF;
-      }
-      return;
+  const uint32_t part_slot = blockIdx.y * gridDim.x + blockIdx.x;
+  const int t_row_base = (int)blockIdx.y * (int)pl.tab_rows;
+  const int t_rows = min(max(cnt[2] - t_row_base, 0), (int)pl.tab_rows);
+  const int t_li0 = (int)blockIdx.x * THREADS;
+  if (t_li0 >= t_rows * nxy) {  // no sample for this workgroup (the grid is sized for the largest (vx, vy) grid the configuration allows)
+    if (tid == 0) {
+      pl.part_cost[(size_t)inst * pl.score_blocks + part_slot] = 1.0e300;
+      pl.part_index[(size_t)inst * pl.score_blocks + part_slot] = 0x7FFFFFFF;
     }
+    return;
   }
   // ---- lane -> sample slot (x-outer, y, theta-inner, as the reference enumerates: what results are keyed by), and its loads
   const int li = t_li0 + (int)tid;
@@ -136,8 +131,8 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
     const uint4* img = reinterpret_cast<const uint4*>(pl.prep + (size_t)inst * pl.prep_stride);
     uint4* lds = reinterpret_cast<uint4*>(s_dyn);
     const int last = max(t_rows, 1) - 1;
-    const int r0 = min(t_li0 / nxy, last);
-    const int r1 = min((t_li0 + THREADS - 1) / nxy, last);
+    const int r0 = min(divSmall(t_li0, nxy), last);
+    const int r1 = min(divSmall(t_li0 + THREADS - 1, nxy), last);
     const int n16w = (int)((win_bytes + score_bits_bytes(win)) >> 4);
     const int ncopy = r1 - r0 + 1;
     const int n_trig = ncopy * K * 2, n_rot = ncopy * K * tnfp;  // 32 B per entry, 16 B per vertex
@@ -642,13 +637,13 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
         bc = s_rc[w];
         bi = s_ri[w];
       }
-    pl.part_cost[(size_t)inst * pl.score_blocks + blockIdx.x] = bc;
-    pl.part_index[(size_t)inst * pl.score_blocks + blockIdx.x] = bi;
+    pl.part_cost[(size_t)inst * pl.score_blocks + part_slot] = bc;
+    pl.part_index[(size_t)inst * pl.score_blocks + part_slot] = bi;
     if (s_cnt[0]) atomicAdd(&pl.counters[2 * inst], s_cnt[0]);
     if (s_cnt[1]) atomicAdd(&pl.counters[2 * inst + 1], s_cnt[1]);
   }
 #ifdef NAVGPU_SWEEP_TIMING
-  if ((tid & 63u) == 0 && (blockIdx.x & 3u) == 1 && (blockIdx.y & 3u) == 2) {
+  if ((tid & 63u) == 0 && (blockIdx.x & 3u) == 1 && (blockIdx.z & 3u) == 2) {
     const unsigned long long sw9 = __builtin_amdgcn_s_memtime();
     sw_t[8] = sw9 - sw0;
     for (int i = 0; i < 10; ++i) atomicAdd(&g_sweep_stats[i], sw_t[i]);
@@ -659,18 +654,23 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
 
 // The sweep takes every launch of the table variant (use_dwa, discretize_by_time, DWAPlanner's own MapGrid options): its tags
 // hold 10 bits of lane, 7 of step and 14 of table row.
+static uint32_t score_sweep_blocks(const PlannerDev& pl) {
+  const uint32_t max_nxy = pl.max_samples / std::max(pl.tab_nth, 1u), groups = (pl.tab_nth + std::max(pl.tab_rows, 1u) - 1) / std::max(pl.tab_rows, 1u);
+  return groups * ((max_nxy * pl.tab_rows + kSweepThreads - 1) / kSweepThreads);
+}
 bool score_sweep_applies(const PlannerDev& pl) {
-  return pl.use_tables && !pl.mg_generic && pl.tab_steps >= 1 && pl.tab_steps <= 127 && pl.tab_rows < (1u << 14) && kSweepThreads <= 1024;
+  return pl.use_tables && !pl.mg_generic && score_sweep_blocks(pl) <= pl.score_blocks && pl.tab_steps >= 1 && pl.tab_steps <= 127 && pl.tab_rows < (1u << 14) && kSweepThreads <= 1024;
 }
 uint32_t launch_score_sweep(const PlannerDev& pl, uint32_t first, uint32_t count, hipStream_t s) {
   const size_t lds = score_window_bytes(pl.win) + score_table_lds_bytes(pl);
   // row groups x workgroups per group, for the largest (vx, vy) grid the configuration can produce
   const uint32_t max_nxy = pl.max_samples / std::max(pl.tab_nth, 1u), groups = (pl.tab_nth + pl.tab_rows - 1) / pl.tab_rows;
-  const uint32_t blocks = std::min(groups * ((max_nxy * pl.tab_rows + kSweepThreads - 1) / kSweepThreads), pl.score_blocks);
+  const uint32_t bpg = (max_nxy * pl.tab_rows + kSweepThreads - 1) / kSweepThreads;
+  const uint32_t blocks = groups * bpg;  // (<= score_blocks: score_sweep_applies)
 #define NAVGPU_SCORE_SWEEP(C)                                                                                                        \
   {                                                                                                                                  \
     if (lds > 40 * 1024) hipFuncSetAttribute((const void*)k_score_sweep<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-    hipLaunchKernelGGL(k_score_sweep<C>, dim3(blocks, count), dim3(kSweepThreads), lds, s, pl, first);                               \
+    hipLaunchKernelGGL(k_score_sweep<C>, dim3(bpg, groups, count), dim3(kSweepThreads), lds, s, pl, first);                               \
   }
   if (pl.fp_chunk <= 6) NAVGPU_SCORE_SWEEP(6)
   else if (pl.fp_chunk <= 9) NAVGPU_SCORE_SWEEP(9)
