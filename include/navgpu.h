@@ -155,7 +155,13 @@ typedef struct {
   int32_t discretize_by_time; /* SimpleTrajectoryGenerator::initialise(..., discretize_by_time)  */
   int32_t sum_scores;         /* ObstacleCostFunction::setSumScores                               */
   int32_t allow_unknown;      /* explicit (reference reads an uninitialised member)  */
-  int32_t reserved;
+  /* Which function computeNewPositions' unqualified cos(pos[2]) / sin(pos[2]) names for its FLOAT argument
+   * (simple_trajectory_generator.cpp:253-260) depends on the reference's build, not on its source:
+   *   0  ::cos(double) - only the C declarations in scope: the fork's own Kinetic / GCC 5 toolchain (default);
+   *   1  the float overload - libstdc++ >= 6 puts std::cos(float) into the global namespace once <math.h> is in scope, and
+   *      vel[0] * cos(pos[2]) becomes a float product (the M_PI_2 + pos[2] terms stay double).
+   * INTEGRATION.md has a three-line probe that tells which one a workspace builds. */
+  int32_t rollout_trig;
 } navgpu_dwa_config;
 
 /* Robot state for one planner cycle, already narrowed to float the way DWAPlanner::findBestPath

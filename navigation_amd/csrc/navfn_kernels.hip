@@ -408,7 +408,10 @@ __global__ __launch_bounds__(kWfThreads) void k_navfn_wf_round(NavfnDev nv, uint
     const bool in = gx < nx && gy < ny;
     sP[row + 1][col + 1] = in ? Pin[gy * nx + gx] : kPotHigh;
     const uint8_t c = in ? cost[gy * nx + gx] : (uint8_t)kCostObs;
-    sH[row][col] = wfCellCost(rule, c);  // < 0 = not updated ("don't propagate into obstacles", :483)
+    // < 0 = not updated ("don't propagate into obstacles", :483).  global_planner: rows 0 and ny - 1 are never updated either - the
+    // reference's updateCell would read potential[n - nx] / [n + nx] outside its arrays there (its outlineMap makes those rows lethal by
+    // default; with outline_map off the checker, GlobalPlannerOracle::dijkstraFixedPoint, leaves them out the same way)
+    sH[row][col] = (rule.global_planner && (gy == 0 || gy == ny - 1)) ? -1.0f : wfCellCost(rule, c);
   }
   if (tid < 128) {
     const int side = tid >> 5, j = tid & 31;  // 0: row above, 1: row below, 2: column left, 3: column right

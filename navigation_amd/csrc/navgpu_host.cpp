@@ -723,80 +723,108 @@ int navgpu_inflation_configure(navgpu_fleet* f, const navgpu_inflation_params* p
   return NAVGPU_OK;
 }
 
-static void updateWindow(navgpu_fleet* f) {
+// The k_score image geometry (window, footprint chunk, heading tables) of a planner configuration `pl` with the given footprints,
+// worked out IN `pl` - a copy the caller commits only once everything the new configuration needs has been allocated.
+static void planWindow(const navgpu_fleet* f, PlannerDev& pl, const std::vector<uint32_t>& fp_n, const std::vector<double>& fp_spec, double fp_radius) {
   // costmap window staged in LDS by k_score: everything a trajectory's footprint or shifted
   // point can touch.  Results never depend on it (cells outside fall back to global loads).
-  const navgpu_dwa_config& c = f->pl.cfg;
+  const navgpu_dwa_config& c = pl.cfg;
   double vmax;
   if (c.max_trans_vel >= 0)
     vmax = c.max_trans_vel + 1e-4;
   else
     vmax = hypot(std::max(fabs(c.min_vel_x), fabs(c.max_vel_x)), std::max(fabs(c.min_vel_y), fabs(c.max_vel_y)));
-  double reach = vmax * c.sim_time + std::max(f->fp_radius, fabs(c.forward_point_distance));
-  double cells = ceil(reach / f->pl.res) + 2;
+  double reach = vmax * c.sim_time + std::max(fp_radius, fabs(c.forward_point_distance));
+  double cells = ceil(reach / pl.res) + 2;
   uint32_t win = (uint32_t)std::min(cells * 2 + 1, 240.0);
-  f->pl.win = win;
-  f->pl.fp_rcells = (uint32_t)ceil(f->fp_radius / f->pl.res) + 1;  // vertex cells lie within this Chebyshev radius of the centre cell
+  pl.win = win;
+  pl.fp_rcells = (uint32_t)ceil(fp_radius / pl.res) + 1;  // vertex cells lie within this Chebyshev radius of the centre cell
   {  // longest footprint edge in cells (both end cells included) over all instances
     double max_edge = 0.0;
     for (uint32_t i = 0; i < f->desc.n_instances; ++i) {
-      const uint32_t nv = f->h_fp_n[i];
-      const double* q = &f->h_fp_spec[(size_t)i * kMaxFootprint * 2];
+      const uint32_t nv = fp_n[i];
+      const double* q = &fp_spec[(size_t)i * kMaxFootprint * 2];
       for (uint32_t a = 0; a < nv; ++a) {
         const uint32_t b = (a + 1) % nv;
         max_edge = std::max(max_edge, std::max(fabs(q[2 * a] - q[2 * b]), fabs(q[2 * a + 1] - q[2 * b + 1])));
         max_edge = std::max(max_edge, hypot(q[2 * a] - q[2 * b], q[2 * a + 1] - q[2 * b + 1]));
       }
     }
-    f->pl.fp_chunk = (uint32_t)ceil(max_edge / f->pl.res) + 1;
+    pl.fp_chunk = (uint32_t)ceil(max_edge / pl.res) + 1;
   }
   // shared heading tables (k_score<TABLES>): constant velocity + fixed step count only
   uint32_t max_nfp = 0;
-  for (uint32_t v : f->h_fp_n) max_nfp = std::max(max_nfp, v);
-  f->pl.use_tables = 0;
+  for (uint32_t v : fp_n) max_nfp = std::max(max_nfp, v);
+  pl.use_tables = 0;
   if (c.use_dwa && c.discretize_by_time && max_nfp <= 8) {
-    f->pl.tab_steps = (uint32_t)ceil(c.sim_time / c.sim_granularity);
-    f->pl.tab_dt = c.sim_time / (int)f->pl.tab_steps;
-    f->pl.tab_nfp = max_nfp;
-    f->pl.tab_nth = (uint32_t)std::max(c.vth_samples, 2) + 1;
-    f->pl.tab_rows = f->pl.tab_steps >= 1 && f->pl.tab_steps <= f->pl.max_sim_steps ? score_table_rows(f->pl, win) : 0;
-    if (f->pl.tab_rows >= 1) f->pl.use_tables = 1;
+    pl.tab_steps = (uint32_t)ceil(c.sim_time / c.sim_granularity);
+    pl.tab_dt = c.sim_time / (int)pl.tab_steps;
+    pl.tab_nfp = max_nfp;
+    pl.tab_nth = (uint32_t)std::max(c.vth_samples, 2) + 1;
+    pl.tab_rows = pl.tab_steps >= 1 && pl.tab_steps <= pl.max_sim_steps ? score_table_rows(pl, win) : 0;
+    if (pl.tab_rows >= 1) pl.use_tables = 1;
   }
 }
 
-// (re)allocate the per-robot LDS images of k_score for the current window / table geometry
-static int ensurePrep(navgpu_fleet* f) {
-  PlannerDev tmp = f->pl;
+// A buffer for the per-robot LDS images of k_score that fits geometry `pl`: *fresh = a new allocation (the caller swaps it in and
+// releases the old one once nothing can fail any more), or nullptr when the current buffer is large enough.
+static int allocPrep(navgpu_fleet* f, const PlannerDev& pl, uint8_t** fresh, uint32_t* stride) {
+  PlannerDev tmp = pl;
   tmp.use_tables = 1;  // upper bound: the image with tables, whatever the launch decides
   const size_t need = (score_prep_slot_bytes(tmp) + 255) & ~(size_t)255;
+  *fresh = nullptr;
+  *stride = f->pl.prep_stride;
   if (f->pl.prep && need <= f->pl.prep_stride) return NAVGPU_OK;
-  HIP_TRY(waitStream(f->stream));
-  f->release(f->pl.prep);
-  f->pl.prep = nullptr;
-  int rc = f->alloc(&f->pl.prep, (size_t)f->desc.n_instances * need);
+  int rc = f->alloc(fresh, (size_t)f->desc.n_instances * need);
   if (rc != NAVGPU_OK) return rc;
-  f->pl.prep_stride = (uint32_t)need;
+  *stride = (uint32_t)need;
   return NAVGPU_OK;
 }
 
+// All-or-nothing (the threading contract of navgpu.h): the new footprint, the window it implies and the image buffer that window
+// needs are prepared on the side; the fleet changes only when nothing can fail any more.
 int navgpu_set_footprint(navgpu_fleet* f, uint32_t first, uint32_t count, const double* xy, uint32_t nv) {
   if (!f || !f->rangeOk(first, count) || (nv && !xy)) return NAVGPU_ERR_INVALID;
   FleetGuard guard_(f);
   if (nv > f->desc.max_footprint || nv > (uint32_t)kMaxFootprint) return NAVGPU_ERR_CAPACITY;
+  std::vector<uint32_t> fp_n = f->h_fp_n;
+  std::vector<double> fp_spec = f->h_fp_spec;
+  double fp_radius = f->fp_radius;
   for (uint32_t i = first; i < first + count; ++i) {
-    f->h_fp_n[i] = nv;
-    for (uint32_t k = 0; k < nv * 2; ++k) f->h_fp_spec[(size_t)i * kMaxFootprint * 2 + k] = xy[k];
+    fp_n[i] = nv;
+    for (uint32_t k = 0; k < nv * 2; ++k) fp_spec[(size_t)i * kMaxFootprint * 2 + k] = xy[k];
   }
-  for (uint32_t k = 0; k < nv; ++k) f->fp_radius = std::max(f->fp_radius, hypot(xy[2 * k], xy[2 * k + 1]));
-  if (f->fp_radius / f->cm.res > 500) return NAVGPU_ERR_CAPACITY;  // polygon column span must fit the 1024-column LDS table
-  HIP_TRY(hipMemcpyAsync(f->pl.fp_spec + (size_t)first * kMaxFootprint * 2, &f->h_fp_spec[(size_t)first * kMaxFootprint * 2],
-                         sizeof(double) * kMaxFootprint * 2 * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(hipMemcpyAsync(f->pl.fp_n + first, &f->h_fp_n[first], sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream));
-  HIP_TRY(waitStream(f->stream));
+  for (uint32_t k = 0; k < nv; ++k) fp_radius = std::max(fp_radius, hypot(xy[2 * k], xy[2 * k + 1]));
+  if (fp_radius / f->cm.res > 500) return NAVGPU_ERR_CAPACITY;  // polygon column span must fit the 1024-column LDS table
+  PlannerDev np = f->pl;
+  uint8_t* fresh_prep = nullptr;
+  uint32_t stride = f->pl.prep_stride;
   if (f->planner_configured) {
-    updateWindow(f);
-    int rc = ensurePrep(f);
+    planWindow(f, np, fp_n, fp_spec, fp_radius);
+    int rc = allocPrep(f, np, &fresh_prep, &stride);
     if (rc != NAVGPU_OK) return rc;
+  }
+  // ---- commit
+  hipError_t e = waitStream(f->stream);  // queued kernels took their PlannerDev by value: drain before buffers they use go
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(f->pl.fp_spec + (size_t)first * kMaxFootprint * 2, &fp_spec[(size_t)first * kMaxFootprint * 2], sizeof(double) * kMaxFootprint * 2 * count,
+                       hipMemcpyHostToDevice, f->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(f->pl.fp_n + first, &fp_n[first], sizeof(uint32_t) * count, hipMemcpyHostToDevice, f->stream);
+  if (e == hipSuccess) e = waitStream(f->stream);  // (the copies read the local vectors)
+  if (e != hipSuccess) {
+    if (fresh_prep) f->release(fresh_prep);
+    g_last_error = std::string("navgpu_set_footprint: ") + hipGetErrorString(e);
+    return NAVGPU_ERR_HIP;
+  }
+  f->h_fp_n.swap(fp_n);
+  f->h_fp_spec.swap(fp_spec);
+  f->fp_radius = fp_radius;
+  if (f->planner_configured) {
+    uint8_t* keep = fresh_prep ? fresh_prep : f->pl.prep;
+    if (fresh_prep) f->release(f->pl.prep);
+    f->pl = np;
+    f->pl.prep = keep;
+    f->pl.prep_stride = stride;
   }
   return NAVGPU_OK;
 }
@@ -1062,6 +1090,10 @@ static int restageReach(navgpu_fleet* f) {
   }
   HIP_TRY(hipMemcpyAsync(pl.bfs_reach, f->hp_reach, sizeof(uint32_t) * n, hipMemcpyHostToDevice, f->stream));
   f->hp_dma_pending = true;
+  if (f->cycles_in_flight > 1) {  // the next stage waits for THIS copy out of hp_reach, not for a marker recorded before it
+    HIP_TRY(hipEventRecord(f->ev_pl_h2d, f->stream));
+    f->ev_pl_set = true;
+  }
   return NAVGPU_OK;
 }
 
@@ -1099,6 +1131,7 @@ int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
   if (cfg.vx_samples <= 0) cfg.vx_samples = 1;  // dwa_planner.cpp:89-105
   if (cfg.vy_samples <= 0) cfg.vy_samples = 1;
   if (cfg.vth_samples <= 0) cfg.vth_samples = 1;
+  if (cfg.rollout_trig != 0 && cfg.rollout_trig != 1) return NAVGPU_ERR_INVALID;
   const uint32_t max_axis = (uint32_t)std::max(std::max(cfg.vx_samples, cfg.vy_samples), std::max(cfg.vth_samples, 2)) + 1;
   if (max_axis > 128) return NAVGPU_ERR_CAPACITY;
   // step-count capacity (simple_trajectory_generator.cpp:202-212)
@@ -1119,45 +1152,77 @@ int navgpu_planner_configure(navgpu_fleet* f, const navgpu_dwa_config* c) {
                  at = (uint32_t)(std::max(cfg.vth_samples, 2) + 1);
   const uint32_t max_samples = ax * ay * at;
   // capacity of the per-workgroup partial results: the 256-thread launch, and the table launch's row groups (each
-  // rounds its share up to whole workgroups: at most one more per v_theta value, planner_kernels.hip launch_score)
+  // rounds its share up to whole workgroups: at most one more per v_theta value, planner_score*.hip)
   const uint32_t score_blocks = 2 * ((max_samples + std::min(kScoreThreads, NAVGPU_SCORE_TAB_THREADS) - 1) / std::min(kScoreThreads, NAVGPU_SCORE_TAB_THREADS)) + at + 2;
-  if (max_axis != pl.max_axis || max_samples != pl.max_samples) {
-    HIP_TRY(waitStream(f->stream));
+  // All-or-nothing (the threading contract of navgpu.h: a reconfigure that fails leaves the previous configuration in force, and
+  // the control thread may run the next cycle on it): the new configuration is put together in a COPY of the planner state, its
+  // tables and image buffer are allocated on the side, and only when nothing can fail any more is the stream drained, the copy
+  // committed and the old buffers released.
+  PlannerDev np = pl;
+  np.cfg = cfg;
+  np.scale_path = pl.res * cfg.path_distance_bias * 0.5;  // DWAPlanner::reconfigure scales (dwa_planner.cpp:64-75)
+  np.scale_goal = pl.res * cfg.goal_distance_bias * 0.5;
+  np.scale_obstacle = pl.res * cfg.occdist_scale;
+  const bool resize = max_axis != pl.max_axis || max_samples != pl.max_samples;
+  float* n_axis = nullptr;
+  double* n_part_cost = nullptr;
+  int32_t* n_part_index = nullptr;
+  double* n_sample_cost = nullptr;
+  int32_t* n_sample_status = nullptr;
+  uint8_t* n_prep = nullptr;
+  uint32_t n_stride = pl.prep_stride;
+  auto dropNew = [&] {
+    f->release(n_axis);
+    f->release(n_part_cost);
+    f->release(n_part_index);
+    f->release(n_sample_cost);
+    f->release(n_sample_status);
+    f->release(n_prep);
+  };
+  int rc = NAVGPU_OK;
+  if (resize) {
+    np.max_axis = max_axis;
+    np.max_samples = max_samples;
+    np.score_blocks = score_blocks;
+    if (!rc) rc = f->alloc(&n_axis, (size_t)nI * 3 * max_axis);
+    if (!rc) rc = f->alloc(&n_part_cost, (size_t)nI * score_blocks);
+    if (!rc) rc = f->alloc(&n_part_index, (size_t)nI * score_blocks);
+    if (!rc && f->desc.keep_sample_costs) rc = f->alloc(&n_sample_cost, (size_t)nI * max_samples);
+    if (!rc && f->desc.keep_sample_costs) rc = f->alloc(&n_sample_status, (size_t)nI * max_samples);
+  }
+  if (!rc) {
+    planWindow(f, np, f->h_fp_n, f->h_fp_spec, f->fp_radius);
+    rc = allocPrep(f, np, &n_prep, &n_stride);
+  }
+  if (!rc && waitStream(f->stream) != hipSuccess) rc = NAVGPU_ERR_HIP;  // (also the allocations' memsets; kernels queued before took their PlannerDev by value)
+  if (rc) {
+    dropNew();
+    return rc;
+  }
+  // ---- commit: nothing below can fail before the new state is complete
+  if (resize) {
     f->release(pl.axis_samples);
     f->release(pl.part_cost);
     f->release(pl.part_index);
     f->release(pl.sample_cost);
     f->release(pl.sample_status);
-    pl.axis_samples = nullptr;
-    pl.part_cost = nullptr;
-    pl.part_index = nullptr;
-    pl.sample_cost = nullptr;
-    pl.sample_status = nullptr;
-    int rc;
-    if ((rc = f->alloc(&pl.axis_samples, (size_t)nI * 3 * max_axis))) return rc;
-    if ((rc = f->alloc(&pl.part_cost, (size_t)nI * score_blocks))) return rc;
-    if ((rc = f->alloc(&pl.part_index, (size_t)nI * score_blocks))) return rc;
-    if (f->desc.keep_sample_costs) {
-      if ((rc = f->alloc(&pl.sample_cost, (size_t)nI * max_samples))) return rc;
-      if ((rc = f->alloc(&pl.sample_status, (size_t)nI * max_samples))) return rc;
-    }
-    pl.max_axis = max_axis;
-    pl.max_samples = max_samples;
-    pl.score_blocks = score_blocks;
+    np.axis_samples = n_axis;
+    np.part_cost = n_part_cost;
+    np.part_index = n_part_index;
+    np.sample_cost = n_sample_cost;
+    np.sample_status = n_sample_status;
   }
-  pl.cfg = cfg;
-  f->touchInputs(0, nI);  // allow_unknown decides which cells a wavefront may enter
-  // DWAPlanner::reconfigure scales (dwa_planner.cpp:64-75)
-  pl.scale_path = pl.res * cfg.path_distance_bias * 0.5;
-  pl.scale_goal = pl.res * cfg.goal_distance_bias * 0.5;
-  pl.scale_obstacle = pl.res * cfg.occdist_scale;
+  if (n_prep) {
+    f->release(pl.prep);
+    np.prep = n_prep;
+    np.prep_stride = n_stride;
+  }
+  pl = np;
   f->planner_configured = true;
-  updateWindow(f);
-  {
-    int rc = ensurePrep(f);
-    if (rc != NAVGPU_OK) return rc;
-    if ((rc = restageReach(f)) != NAVGPU_OK) return rc;  // new limits, new boxes
-  }
+  f->touchInputs(0, nI);  // allow_unknown decides which cells a wavefront may enter
+  // new limits, new boxes: the staged reach follows from the configuration (a failure here leaves a complete, consistent new
+  // configuration whose boxes are the old ones: searches that are larger or smaller than they need be, never wrong)
+  if ((rc = restageReach(f)) != NAVGPU_OK) return rc;
   HIP_TRY(waitStream(f->stream));
   return NAVGPU_OK;
 }
@@ -1306,10 +1371,10 @@ int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
   FleetGuard guard_(f);
   if (!f->planner_configured || !f->planner_staged) return NAVGPU_ERR_STATE;
   PlannerDev& pl = f->pl;
+  const int prev_slot = f->res_slot;
   if (f->cycles_in_flight > 1) {  // the cycle before this one may still run: its results stay where they are
     if (first != 0 || count != f->desc.n_instances) return NAVGPU_ERR_STATE;
-    f->res_slot ^= 1;
-    pl.result = f->hp_result + (size_t)f->res_slot * f->desc.n_instances;
+    pl.result = f->hp_result + (size_t)(prev_slot ^ 1) * f->desc.n_instances;  // (the slot flips once the launches are out)
   }
   pl.bfs_bounded = 1;  // per robot: bfs_reach (0 = whole grid)
   for (uint32_t i = first; i < first + count; ++i) {
@@ -1336,11 +1401,18 @@ int navgpu_planner_cycle(navgpu_fleet* f, uint32_t first, uint32_t count) {
   uint32_t n_blocks = 0;
   PROFILED(f, NAVGPU_K_SCORE, n_blocks = launch_score(pl, first, count, nullptr, f->stream));
   PROFILED(f, NAVGPU_K_SELECT, launch_select(pl, first, count, n_blocks, f->stream));
+  int rc = checkLaunch();
   if (f->cycles_in_flight > 1) {
-    HIP_TRY(hipEventRecord(f->ev_cycle[f->res_slot], f->stream));
-    f->ev_cycle_set[f->res_slot] = true;
+    const int slot = prev_slot ^ 1;
+    if (rc == NAVGPU_OK && hipEventRecord(f->ev_cycle[slot], f->stream) != hipSuccess) rc = NAVGPU_ERR_HIP;
+    if (rc == NAVGPU_OK) {  // only a cycle whose launches and marker are out becomes "the latest"
+      f->res_slot = slot;
+      f->ev_cycle_set[slot] = true;
+    } else {
+      pl.result = f->hp_result + (size_t)prev_slot * f->desc.n_instances;
+    }
   }
-  return checkLaunch();
+  return rc;
 }
 
 int navgpu_planner_set_cycles_in_flight(navgpu_fleet* f, int32_t cycles) {

@@ -165,15 +165,19 @@ static int runWavefront(navgpu_navfn* h, uint32_t first, uint32_t count, const N
     nv.wf_tiles_x = (nv.nx + kTile - 1) / kTile;
     nv.wf_tiles_y = (nv.ny + kTile - 1) / kTile;
     nv.wf_max_rounds = kMaxRounds;
+    // each buffer is allocated at most once (a call that failed half-way leaves what it got for the next one to complete)
     int rc = 0;
-    if (!rc) rc = h->alloc(&nv.wf_act, (size_t)h->n * 2 * nv.wf_tiles_x * nv.wf_tiles_y);
-    if (!rc) rc = h->alloc(&nv.wf_nchg, (size_t)h->n * kMaxRounds);
-    if (!rc) rc = h->alloc(&nv.wf_min, (size_t)h->n * kMaxRounds);
-    if (!rc) rc = h->alloc(&nv.wf_status, h->n);
-    if (!rc) rc = h->alloc(&h->d_seed_cells, (size_t)h->n * 4);
-    if (!rc) rc = h->alloc(&h->d_seed_vals, (size_t)h->n * 4);
-    if (!rc) rc = h->alloc(&h->d_stop, h->n);
-    if (!rc && hipHostMalloc((void**)&h->h_wf_status, sizeof(NavfnWfStatus) * h->n, hipHostMallocDefault) != hipSuccess) rc = NAVGPU_ERR_HIP;
+    if (!rc && !nv.wf_act) rc = h->alloc(&nv.wf_act, (size_t)h->n * 2 * nv.wf_tiles_x * nv.wf_tiles_y);
+    if (!rc && !nv.wf_nchg) rc = h->alloc(&nv.wf_nchg, (size_t)h->n * kMaxRounds);
+    if (!rc && !nv.wf_min) rc = h->alloc(&nv.wf_min, (size_t)h->n * kMaxRounds);
+    if (!rc && !nv.wf_status) rc = h->alloc(&nv.wf_status, h->n);
+    if (!rc && !h->d_seed_cells) rc = h->alloc(&h->d_seed_cells, (size_t)h->n * 4);
+    if (!rc && !h->d_seed_vals) rc = h->alloc(&h->d_seed_vals, (size_t)h->n * 4);
+    if (!rc && !h->d_stop) rc = h->alloc(&h->d_stop, h->n);
+    if (!rc && !h->h_wf_status && hipHostMalloc((void**)&h->h_wf_status, sizeof(NavfnWfStatus) * h->n, hipHostMallocDefault) != hipSuccess) {
+      h->h_wf_status = nullptr;
+      rc = NAVGPU_ERR_HIP;
+    }
     if (!rc) rc = h->alloc(&nv.potalt, (size_t)h->n * nv.ns_padded);  // last: its presence says the others exist
     if (rc) return rc;
   }
@@ -194,7 +198,11 @@ static int runWavefront(navgpu_navfn* h, uint32_t first, uint32_t count, const N
     all_done = true;
     for (uint32_t k = 0; k < count; ++k) all_done = all_done && h->h_wf_status[first + k].done;
   }
-  if (!all_done) {
+  if (!all_done) {  // no plan: navgpu_navfn_path must not hand out the previous call's
+    for (uint32_t k = 0; k < count; ++k) {
+      h->h_results[first + k].found = 0;
+      h->h_results[first + k].path_length = 0;
+    }
     g_last_error = "tiled wavefront: not settled within 8192 rounds";
     return NAVGPU_ERR_CAPACITY;
   }

@@ -606,8 +606,11 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           } else if (lv[1] != 0.0f) {
             sincos(M_PI_2 + th, &sn2, &cs2);
           }
-          const float nxp = (float)(px + (lv[0] * cs + lv[1] * cs2) * dt);
-          const float nyp = (float)(py + (lv[0] * sn + lv[1] * sn2) * dt);
+          // (rollout_trig 1: cos(pos[2]) names the float function and vel[0] * cos(pos[2]) is a float product - navgpu.h; its value is
+          // taken as the double function's, rounded to float)
+          const double tx = c.rollout_trig ? (double)(lv[0] * (float)cs) : lv[0] * cs, ty = c.rollout_trig ? (double)(lv[0] * (float)sn) : lv[0] * sn;
+          const float nxp = (float)(px + (tx + lv[1] * cs2) * dt);
+          const float nyp = (float)(py + (ty + lv[1] * sn2) * dt);
           const float ntp = (float)(pth + lv[2] * dt);
           // (a critic that has already failed, or that follows one that has, cannot change the outcome any more: scr_z / scr_w)
           const uint32_t any = (scr_sum ? fbw.x : fbw.y) | (fbw.z & scr_z) | (fbw.w & scr_w);

@@ -45,7 +45,9 @@ __device__ unsigned long long g_sweep_stats[16];
 #define SW_ACC(i, x)
 #endif
 
-template <int CHUNK>
+// TRIGF: navgpu_dwa_config::rollout_trig = 1 - computeNewPositions' cos(pos[2]) / sin(pos[2]) name the float functions and
+// vel[0] * cos(pos[2]) is a float product (its value: the table's double, rounded to float)
+template <int CHUNK, bool TRIGF>
 __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score_sweep(PlannerDev pl, uint32_t first) {
   constexpr int THREADS = kSweepThreads;
   extern __shared__ __align__(16) uint8_t s_dyn[];
@@ -53,8 +55,9 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   __shared__ double s_rc[THREADS / 64];
   __shared__ int s_ri[THREADS / 64];
   __shared__ int s_cnt[2];
+  // the walk queue: pose (x, y as floats), tag = owner lane | step << 10 | table row << 17 | cost wanted << 31
   __shared__ float s_qx[kSweepQueue], s_qy[kSweepQueue];
-  __shared__ uint32_t s_qt[kSweepQueue];  // owner lane | step << 10 | table row << 17 | cost wanted << 31
+  __shared__ uint32_t s_qt[kSweepQueue];
   __shared__ uint32_t s_obs[THREADS];
   __shared__ uint32_t s_qn[2];
 
@@ -385,8 +388,9 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
         const uint4 fbw = s_fb4[fb_i];
         // ---- advance (computeNewPositions :253-260): fp64 on fp32 state, rounded back to fp32 (the heading is the tables')
         const double cs2 = s_trig[4 * te + 2], sn2 = s_trig[4 * te + 3];
-        const float nxp = (float)(px + (vxd * cs + vyd * cs2) * dt);
-        const float nyp = (float)(py + (vxd * sn + vyd * sn2) * dt);
+        const double tx = TRIGF ? (double)(vs[0] * (float)cs) : vxd * cs, ty = TRIGF ? (double)(vs[0] * (float)sn) : vxd * sn;
+        const float nxp = (float)(px + (tx + vyd * cs2) * dt);
+        const float nyp = (float)(py + (ty + vyd * sn2) * dt);
         const uint32_t any = (scr_sum ? fbw.x : fbw.y) | (fbw.z & scr_z) | (fbw.w & scr_w) | force | (in_w ? 0u : 0xFFFFFFFFu);
         const bool unscr = ((any >> (lx & 31u)) & alive_m & 1u) != 0u;
         px = nxp;
@@ -667,10 +671,16 @@ uint32_t launch_score_sweep(const PlannerDev& pl, uint32_t first, uint32_t count
   const uint32_t max_nxy = pl.max_samples / std::max(pl.tab_nth, 1u), groups = (pl.tab_nth + pl.tab_rows - 1) / pl.tab_rows;
   const uint32_t bpg = (max_nxy * pl.tab_rows + kSweepThreads - 1) / kSweepThreads;
   const uint32_t blocks = groups * bpg;  // (<= score_blocks: score_sweep_applies)
-#define NAVGPU_SCORE_SWEEP(C)                                                                                                        \
-  {                                                                                                                                  \
-    if (lds > 40 * 1024) hipFuncSetAttribute((const void*)k_score_sweep<C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-    hipLaunchKernelGGL(k_score_sweep<C>, dim3(bpg, groups, count), dim3(kSweepThreads), lds, s, pl, first);                               \
+#define NAVGPU_SCORE_SWEEP(C)                                                                                                             \
+  {                                                                                                                                       \
+    if (lds > 40 * 1024) {                                                                                                                \
+      hipFuncSetAttribute((const void*)k_score_sweep<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+      hipFuncSetAttribute((const void*)k_score_sweep<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+    }                                                                                                                                     \
+    if (pl.cfg.rollout_trig)                                                                                                              \
+      hipLaunchKernelGGL((k_score_sweep<C, true>), dim3(bpg, groups, count), dim3(kSweepThreads), lds, s, pl, first);                      \
+    else                                                                                                                                  \
+      hipLaunchKernelGGL((k_score_sweep<C, false>), dim3(bpg, groups, count), dim3(kSweepThreads), lds, s, pl, first);                     \
   }
   if (pl.fp_chunk <= 6) NAVGPU_SCORE_SWEEP(6)
   else if (pl.fp_chunk <= 9) NAVGPU_SCORE_SWEEP(9)

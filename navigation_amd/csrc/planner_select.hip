@@ -165,8 +165,10 @@ __global__ __launch_bounds__(64) void k_select(PlannerDev pl, uint32_t first, ui
         tr[3 * step + 1] = py;
         tr[3 * step + 2] = s_pth[step];
         const float lx = s_lv[step][0], ly = s_lv[step][1];
-        const float nxp = (float)(px + (lx * s_sc[step][0] + ly * s_sc[step][2]) * dt);
-        const float nyp = (float)(py + (lx * s_sc[step][1] + ly * s_sc[step][3]) * dt);
+        const double tx = c.rollout_trig ? (double)(lx * (float)s_sc[step][0]) : lx * s_sc[step][0];  // (navgpu_dwa_config::rollout_trig)
+        const double ty = c.rollout_trig ? (double)(lx * (float)s_sc[step][1]) : lx * s_sc[step][1];
+        const float nxp = (float)(px + (tx + ly * s_sc[step][2]) * dt);
+        const float nyp = (float)(py + (ty + ly * s_sc[step][3]) * dt);
         px = nxp;
         py = nyp;
       }
@@ -197,8 +199,9 @@ __global__ __launch_bounds__(64) void k_select(PlannerDev pl, uint32_t first, ui
         double sn, cs, sn2 = 0.0, cs2 = 0.0;
         sincos(th, &sn, &cs);
         if (lv[1] != 0.0f) sincos(M_PI_2 + th, &sn2, &cs2);
-        const float nxp = (float)(px + (lv[0] * cs + lv[1] * cs2) * dt);
-        const float nyp = (float)(py + (lv[0] * sn + lv[1] * sn2) * dt);
+        const double tx = c.rollout_trig ? (double)(lv[0] * (float)cs) : lv[0] * cs, ty = c.rollout_trig ? (double)(lv[0] * (float)sn) : lv[0] * sn;
+        const float nxp = (float)(px + (tx + lv[1] * cs2) * dt);
+        const float nyp = (float)(py + (ty + lv[1] * sn2) * dt);
         const float ntp = (float)(pth + lv[2] * dt);
         px = nxp;
         py = nyp;

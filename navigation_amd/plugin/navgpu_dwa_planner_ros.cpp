@@ -103,7 +103,9 @@ void DWAPlannerROS::reconfigureCB(dwa_local_planner::DWAPlannerConfig& config, u
   nh.param("sum_scores", sum_scores, false);        // dwa_planner.cpp:155-157
   nh.param("cheat_factor", cheat, 1.0);             // :181
   nh.param("navgpu_allow_unknown", allow_unknown, true);  // explicit here; uninitialised in the reference
-  c.sum_scores = sum_scores;  c.cheat_factor = cheat;  c.allow_unknown = allow_unknown;  c.reserved = 0;
+  int rollout_trig = 0;
+  nh.param("navgpu_rollout_trig", rollout_trig, 0);       // 0: cos(pos[2]) is ::cos(double) in the reference build being replaced, 1: the float overload
+  c.sum_scores = sum_scores;  c.cheat_factor = cheat;  c.allow_unknown = allow_unknown;  c.rollout_trig = rollout_trig;
   if (navgpu_planner_configure(fleet_, &c) != NAVGPU_OK) ROS_ERROR("navgpu_planner_configure: %s", navgpu_last_error());
 }
 

@@ -42,6 +42,7 @@ DwaConfig toCfg(const navgpu_dwa_config& c) {
   d.oscillation_reset_dist = c.oscillation_reset_dist;
   d.oscillation_reset_angle = c.oscillation_reset_angle;
   d.allow_unknown = c.allow_unknown;
+  d.rollout_trig = c.rollout_trig;
   return d;
 }
 std::vector<Pt2> toPts(const double* xy, uint32_t n) {

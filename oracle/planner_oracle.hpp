@@ -85,6 +85,11 @@ struct DwaConfig {
   double forward_point_distance = 0.325, cheat_factor = 1.0;
   double oscillation_reset_dist = 0.05, oscillation_reset_angle = 0.2;
   int allow_unknown = 1;
+  // Which function the unqualified cos(pos[2]) / sin(pos[2]) of computeNewPositions (simple_trajectory_generator.cpp:253-260) names
+  // for its FLOAT argument is a property of the build, not of the source: 0 = ::cos(double) (only the C declarations in scope - the
+  // fork's Kinetic / GCC 5 toolchain, SURVEY 7 hard part 2), 1 = the float overload (libstdc++ >= 6 with <math.h> in scope puts
+  // std::cos(float) into the global namespace): then vel[0] * cos(pos[2]) is a float product.
+  int rollout_trig = 0;
 };
 
 // base_local_planner/include/base_local_planner/trajectory.h:44-116
@@ -166,10 +171,15 @@ struct TrajectoryGenerator {
     }
   }
 
-  static V3f computeNewPositions(const V3f& pos, const V3f& vel, double dt) {  // :253-260
+  static V3f computeNewPositions(const V3f& pos, const V3f& vel, double dt, int rollout_trig = 0) {  // :253-260
     V3f n;
-    n[0] = pos[0] + (vel[0] * cos((double)pos[2]) + vel[1] * cos(M_PI_2 + pos[2])) * dt;
-    n[1] = pos[1] + (vel[0] * sin((double)pos[2]) + vel[1] * sin(M_PI_2 + pos[2])) * dt;
+    if (rollout_trig) {  // cos(float) -> float: the first product is a float one; M_PI_2 + pos[2] is a double either way
+      n[0] = pos[0] + (vel[0] * cosf(pos[2]) + vel[1] * cos(M_PI_2 + pos[2])) * dt;
+      n[1] = pos[1] + (vel[0] * sinf(pos[2]) + vel[1] * sin(M_PI_2 + pos[2])) * dt;
+    } else {
+      n[0] = pos[0] + (vel[0] * cos((double)pos[2]) + vel[1] * cos(M_PI_2 + pos[2])) * dt;
+      n[1] = pos[1] + (vel[0] * sin((double)pos[2]) + vel[1] * sin(M_PI_2 + pos[2])) * dt;
+    }
     n[2] = pos[2] + vel[2] * dt;
     return n;
   }
@@ -226,7 +236,7 @@ struct TrajectoryGenerator {
       traj.y.push_back(p[1]);
       traj.th.push_back(p[2]);
       if (continued_acceleration) loop_vel = computeNewVelocities(sample, loop_vel, acc, dt);
-      p = computeNewPositions(p, loop_vel, dt);
+      p = computeNewPositions(p, loop_vel, dt, c.rollout_trig);
     }
     return num_steps > 0;
   }

@@ -35,7 +35,7 @@ class DwaConfig(C.Structure):
         "forward_point_distance", "cheat_factor", "oscillation_reset_dist", "oscillation_reset_angle")] + [
         (n, C.c_int32) for n in (
             "vx_samples", "vy_samples", "vth_samples", "use_dwa", "discretize_by_time", "sum_scores",
-            "allow_unknown", "reserved")]
+            "allow_unknown", "rollout_trig")]
 
     def __init__(self, **kw):
         super().__init__()
@@ -45,7 +45,7 @@ class DwaConfig(C.Structure):
                  sim_period=0.05, path_distance_bias=32.0, goal_distance_bias=24.0, occdist_scale=0.01,
                  forward_point_distance=0.325, cheat_factor=1.0, oscillation_reset_dist=0.05,
                  oscillation_reset_angle=0.2, vx_samples=3, vy_samples=10, vth_samples=20, use_dwa=1,
-                 discretize_by_time=0, sum_scores=0, allow_unknown=1, reserved=0)
+                 discretize_by_time=0, sum_scores=0, allow_unknown=1, rollout_trig=0)
         d.update(kw)
         for k, v in d.items():
             setattr(self, k, v)

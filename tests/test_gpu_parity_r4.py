@@ -1,0 +1,156 @@
+"""Parity tests added in round 4 (same bar as the others: the HIP path through the C-ABI against the CPU oracle, bit-exact on
+indices / codes, 1e-5 on cost floats): a planner reconfigure / footprint change that fails half-way leaves the previous
+configuration in force (include/navgpu.h "Threading contract"), the scoring launch's walk queue under pressure, and the rollout's
+float-trig variant."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import L, _inflated_instance, nav  # noqa: F401
+from test_gpu_parity_r3 import _oracle_cycle
+
+pytestmark = pytest.mark.gpu
+
+
+def _cycle_equals_oracle(fl, orc, cfg, insts, fp, res):
+    pos = np.stack([i["pos"] for i in insts]).astype(np.float32)
+    vel = np.stack([i["vel"] for i in insts]).astype(np.float32)
+    plans = np.stack([i["plan"] for i in insts])
+    out = fl.find_best_path(pos, vel, plans)
+    for k, ins in enumerate(insts):
+        o = _oracle_cycle(orc, cfg, ins["master"], ins["pos"], ins["vel"], ins["plan"], fp, res)
+        assert out[k].best_index == o.best_index and abs(out[k].cost - o.cost) <= 1e-5, (k, out[k].best_index, o.best_index)
+        assert out[k].n_samples == o.n_samples and out[k].n_valid == o.n_valid
+
+
+# ----------------------------------------------------------------------------------------------
+# DWAPlanner::reconfigure from the dynamic_reconfigure thread (dwa_planner.cpp:52-110) while the control thread keeps cycling:
+# navgpu_planner_configure / navgpu_set_footprint put the new configuration together on the side - sample tables, partial results,
+# the per-robot image buffer - and commit only when every allocation has succeeded.  With allocations made to fail, the next
+# cycle must run, and give the oracle's answer, under the OLD configuration (it used to launch on freed tables).
+# ----------------------------------------------------------------------------------------------
+def test_planner_configure_failure_keeps_previous_configuration(nav, orc):
+    from navigation_amd import synth
+    N = L(nav)
+    n, nI = 200, 2
+    insts = [_inflated_instance(orc, n, 60 + i, synth) for i in range(nI)]
+    small = nav.DwaConfig(vx_samples=6, vy_samples=4, vth_samples=7, sim_time=1.2, sim_granularity=0.1, discretize_by_time=1)
+    large = nav.DwaConfig(vx_samples=40, vy_samples=30, vth_samples=24, sim_time=1.6, sim_granularity=0.1, discretize_by_time=1)
+    fl = nav.Fleet(nI, n, n, synth.RES, layers=N.LAYER_OBSTACLE, max_sim_steps=64, max_plan=256, keep_sample_costs=True)
+    fl.configure_planner(small)
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.upload(N.GRID_MASTER, np.stack([i["master"] for i in insts]))
+    fl.set_plan()
+    _cycle_equals_oracle(fl, orc, small, insts, synth.FOOTPRINT, synth.RES)
+    # 1. the sample-cost table of the large configuration (2 x 41 x 31 x 25 doubles = 508 KB) cannot be allocated; the axis tables and
+    #    partial results before it can: the failure comes half-way through
+    fl.set_alloc_limit(256 << 10)
+    try:
+        with pytest.raises(Exception):
+            fl.configure_planner(large)
+        _cycle_equals_oracle(fl, orc, small, insts, synth.FOOTPRINT, synth.RES)
+        # 2. a footprint whose window needs a larger image buffer than the limit allows: refused, the old footprint stays
+        big_fp = [[-1.2, -1.2], [1.2, -1.2], [1.2, 1.2], [-1.2, 1.2]]
+        with pytest.raises(Exception):
+            fl.set_footprint(big_fp)
+        _cycle_equals_oracle(fl, orc, small, insts, synth.FOOTPRINT, synth.RES)
+    finally:
+        fl.set_alloc_limit(0)
+    # the same requests succeed once memory is there
+    fl.configure_planner(large)
+    _cycle_equals_oracle(fl, orc, large, insts, synth.FOOTPRINT, synth.RES)
+    fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# k_score_sweep's walk queue under pressure: a robot boxed in by obstacles a few cells away has nearly every trajectory point
+# looked at closely, so the workgroup's queue (512 entries per block of 5 steps) overflows and lanes take points again in the next
+# block; and one in the open never queues anything.  Both against the oracle, every sample's cost and status.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sum_scores", [0, 1])
+def test_score_sweep_queue_overflow_and_empty(nav, orc, sum_scores):
+    from navigation_amd import synth
+    N = L(nav)
+    n = 160
+    cfg = nav.DwaConfig(vx_samples=20, vy_samples=12, vth_samples=9, sim_time=2.0, sim_granularity=0.1, discretize_by_time=1, sum_scores=sum_scores,
+                        occdist_scale=0.02)
+    ocfg = orc.DwaConfig(**cfg.as_dict())
+    masters, insts = [], []
+    for k in range(3):
+        ins = _inflated_instance(orc, n, 80 + k, synth)
+        m = ins["master"].copy()
+        cx, cy = int(ins["pos"][0] / synth.RES), int(ins["pos"][1] / synth.RES)
+        if k == 0:  # open field
+            m[:] = 0
+        elif k == 1:  # low-cost clutter everywhere in reach (never lethal): every point's footprint has to be walked for its cost
+            m[:] = 0
+            m[max(cy - 40, 0):cy + 40, max(cx - 40, 0):cx + 40] = 37
+            m[cy, cx] = 0
+        else:  # lethal posts around the robot, 9 cells away: legality walks at nearly every point, many failures
+            m[:] = 0
+            for dy in range(-30, 31, 6):
+                for dx in range(-30, 31, 6):
+                    if max(abs(dx), abs(dy)) >= 9:
+                        m[cy + dy, cx + dx] = 254
+        ins = dict(ins, master=m)
+        insts.append(ins)
+        masters.append(m)
+    fl = nav.Fleet(3, n, n, synth.RES, layers=N.LAYER_OBSTACLE, max_sim_steps=32, max_plan=256, keep_sample_costs=True)
+    fl.configure_planner(cfg)
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.upload(N.GRID_MASTER, np.stack(masters))
+    fl.set_plan()
+    out = fl.find_best_path(np.stack([i["pos"] for i in insts]).astype(np.float32), np.stack([i["vel"] for i in insts]).astype(np.float32),
+                            np.stack([i["plan"] for i in insts]))
+    for k, ins in enumerate(insts):
+        p = orc.DwaPlanner(ins["master"], synth.RES, 0.0, 0.0, ocfg)
+        p.set_plan()
+        o, _, _, cfull, ost = p.cycle(ins["pos"], ins["vel"], ins["plan"], synth.FOOTPRINT)
+        cost, status, _ = fl.samples(k)
+        assert np.array_equal(status, ost)
+        scored = ost == 1
+        assert np.array_equal(cost[scored] < 0, cfull[scored] < 0), k
+        neg = scored & (cfull < 0)
+        assert np.array_equal(cost[neg], cfull[neg]), k                     # failure codes
+        pos_ = scored & (cfull >= 0)
+        assert np.abs(cost[pos_] - cfull[pos_]).max(initial=0.0) <= 1e-5, k
+        assert out[k].best_index == o.best_index and abs(out[k].cost - o.cost) <= 1e-5
+    fl.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# navgpu_dwa_config::rollout_trig = 1: computeNewPositions' unqualified cos(pos[2]) / sin(pos[2]) name the FLOAT functions (what
+# libstdc++ >= 6 makes of them once <math.h> is in scope; simple_trajectory_generator.cpp:253-260), vel[0] * cos(pos[2]) is a float
+# product.  The same parity bar as the double form, over the table launch (k_score_sweep), the generic one, continued
+# acceleration and sum_scores.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kw", [dict(discretize_by_time=1, sim_granularity=0.1), dict(discretize_by_time=0), dict(discretize_by_time=1, sim_granularity=0.1, use_dwa=0),
+                                dict(discretize_by_time=1, sim_granularity=0.1, sum_scores=1, occdist_scale=0.02)])
+def test_planner_rollout_float_trig(nav, orc, kw):
+    from test_gpu_parity import _check_planner
+    base = dict(vx_samples=7, vy_samples=5, vth_samples=9, sim_time=1.4, rollout_trig=1)
+    base.update(kw)
+    _check_planner(nav, orc, 200, base, n_inst=2, seed0=40, cycles=2, near_obstacles=6)
+
+
+def test_device_float_trig_against_host_libm(nav):
+    """The device's sinf / cosf are its double functions rounded to float (navgpu_device_sincos, then a narrowing): within one unit in
+    the last place of the host libm's float functions - what the reference's build would call - and equal for nearly all headings."""
+    import ctypes as C
+    import ctypes.util
+    import math
+    Lb = nav.lib()
+    libm = C.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    libm.sinf.restype = libm.cosf.restype = C.c_float
+    libm.sinf.argtypes = libm.cosf.argtypes = [C.c_float]
+    rs = np.random.RandomState(11)
+    th32 = np.concatenate([rs.uniform(-2 * math.pi, 2 * math.pi, 1 << 16).astype(np.float32), np.array([0.0, 1e-20, math.pi / 2, math.pi, -math.pi, 100.0], np.float32)])
+    th = th32.astype(np.float64)
+    sn, cs = np.empty_like(th), np.empty_like(th)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert Lb.navgpu_device_sincos(0, ptr(th), len(th), ptr(sn), ptr(cs)) == 0
+    hs = np.array([libm.sinf(float(v)) for v in th32], np.float32)
+    hc = np.array([libm.cosf(float(v)) for v in th32], np.float32)
+    for dev, host in ((sn.astype(np.float32), hs), (cs.astype(np.float32), hc)):
+        ulp = np.abs(dev.view(np.int32).astype(np.int64) - host.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1, ulp.max()
+        assert (ulp != 0).mean() < 0.06

@@ -426,3 +426,27 @@ def test_oracle_rolling_static_layer_identity_equals_shifted_copy(orc):
     want[3:, 1:] = interp[:37, :39]  # master cell (i, j) <-> static cell (i - 1, j - 3)
     assert np.array_equal(m, want)
     assert np.array_equal(o.bounds(), [1, 40, 3, 40])  # the static map's extent (from its cell (0, 0) centre), clipped to the window, every cycle
+
+
+def test_oracle_rollout_trig_switch_is_live(orc):
+    """navgpu_dwa_config::rollout_trig (the float overload of computeNewPositions' cos / sin): the float product differs from the double
+    one by ~1e-9 m per step, which moves the float-rounded pose in some steps of some samples - by one float ulp, never more per step."""
+    rs = np.random.RandomState(3)
+    n_diff = n_steps = 0
+    worst = 0.0
+    for _ in range(400):
+        pos = np.array([rs.uniform(2, 8), rs.uniform(2, 8), rs.uniform(-3.1, 3.1)], np.float32)
+        vel = np.array([0.2, 0.0, 0.1], np.float32)
+        sample = np.array([rs.uniform(0.1, 0.5), rs.uniform(-0.1, 0.1), rs.uniform(-1, 1)], np.float32)
+        tr = []
+        for trig in (0, 1):
+            cfg = orc.DwaConfig(sim_time=2.0, sim_granularity=0.1, discretize_by_time=1, rollout_trig=trig)
+            k, pts, _ = orc.generate_trajectory(cfg, pos, vel, sample)
+            assert k == 20
+            tr.append(pts)
+        assert np.array_equal(tr[0][:, 2], tr[1][:, 2])  # the heading recurrence has no trigonometry in it
+        d = np.abs(tr[0][:, :2] - tr[1][:, :2])
+        n_diff += int((d > 0).any(axis=1).sum())
+        n_steps += k
+        worst = max(worst, float(d.max()))
+    assert 0 < n_diff < 0.5 * n_steps and worst <= 20 * 2.0 ** -21  # (a float ulp at 8 m is 2^-20 m... at most one per step, accumulated)

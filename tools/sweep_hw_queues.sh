@@ -1,3 +1,6 @@
+#!/bin/bash
+# Exploration (run on the GPU box): stream groups x hardware queues (GPU_MAX_HW_QUEUES) for the default bench schedule.
+cd "$GRAFT_REPO_ROOT"
 for q in 4 8; do for g in 4 6 8; do
   GPU_MAX_HW_QUEUES=$q timeout -k 10 200 python bench.py --no-single --no-cpu-baseline --groups $g > gpurun_out/q${q}_g${g}.json 2> gpurun_out/q${q}_g${g}.err
   python - gpurun_out/q${q}_g${g}.json $q $g <<'PY'
