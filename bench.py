@@ -179,29 +179,46 @@ def run_cycles(groups, k0, n, restage=True):
     return k0 + n
 
 
-def hbm_traffic_from_profiles(kernel):
-    """HBM bytes per launch of `kernel` as measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this workload (one
-    full-fleet launch per kernel: tools/collect_profiles.sh runs --groups 1); newest profiles/*_hbm_traffic.json."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
-    if not files:
-        return None, None
+def current_profile():
+    """The rocprofv3 profile the line quotes: profiles/CURRENT.json (written by tools/collect_profiles.sh -> tools/profile_tag.py: tag, git
+    head, a hash of the library's sources, compile flags) - an explicit tag, not the lexically last file - and whether the sources of
+    the build that is RUNNING are the ones it was taken from."""
     try:
-        d = json.load(open(files[-1]))
+        cur = json.load(open(os.path.join(ROOT, "profiles", "CURRENT.json")))
+    except Exception:
+        return None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from profile_tag import sources_sha16
+        now = sources_sha16()
+    except Exception:
+        now = None
+    cur["running_sources_sha16"] = now
+    cur["matches_running_build"] = bool(now) and now == cur.get("sources_sha16")
+    return cur
+
+
+def hbm_traffic_from_profiles(kernel, cur):
+    """HBM bytes per launch of `kernel` as measured by rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this workload (one full-fleet launch
+    per kernel: tools/collect_profiles.sh runs --groups 1), from the CURRENT profile's <tag>_hbm_traffic.json."""
+    if not cur:
+        return None, None
+    f = os.path.join(ROOT, "profiles", f"{cur['tag']}_hbm_traffic.json")
+    try:
+        d = json.load(open(f))
         # MI355X_MICROARCH.md (HBM): gfx950 FETCH_SIZE tallies 128-B read requests at 64 B -> doubled; WRITE_SIZE is exact
-        return d["kernels"][kernel]["hbm_bytes_fetch_x2"], os.path.relpath(files[-1], ROOT)
+        return d["kernels"][kernel]["hbm_bytes_fetch_x2"], os.path.relpath(f, ROOT)
     except Exception:
         return None, None
 
 
-def pmc_summary_from_profiles():
-    """Newest profiles/*_pmc_summary.json (tools/collect_profiles.sh + tools/pmc_summary.py): the measured issue roofline."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    if not files:
+def pmc_summary_from_profiles(cur):
+    """The CURRENT profile's <tag>_pmc_summary.json (tools/collect_profiles.sh + tools/pmc_summary.py): the measured issue roofline."""
+    if not cur:
         return None, None
+    f = os.path.join(ROOT, "profiles", f"{cur['tag']}_pmc_summary.json")
     try:
-        return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+        return json.load(open(f)), os.path.relpath(f, ROOT)
     except Exception:
         return None, None
 
@@ -388,6 +405,18 @@ def spawn_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+def oracle_build_flags():
+    """How the CPU port was compiled (oracle/Makefile): -O2 without -march=native or FMA contraction - its doubles have to round like the
+    reference's default x86-64 build - where SURVEY 8(d) suggested -O3 -march=native."""
+    try:
+        for line in open(os.path.join(ROOT, "oracle", "Makefile")):
+            if line.startswith("CXXFLAGS"):
+                return "g++ " + line.split("=", 1)[1].strip() + " (no -march=native, no FMA contraction: the doubles must round like the reference's default x86-64 build)"
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(insts_sample, cfg, n_cells, masters):
     """Oracle ("port") timed on this box's host cores on a bounded sample of the same workload."""
     from oracle import pyoracle as orc
@@ -418,7 +447,7 @@ def cpu_baseline(insts_sample, cfg, n_cells, masters):
                 break
     except OSError:
         pass
-    return dict(value=scored.value / dt, unit="trajectories/s", cores=cores, kind="port",
+    return dict(value=scored.value / dt, unit="trajectories/s", cores=cores, kind="port", build=oracle_build_flags(),
                 per_core=scored.value / dt / cores, host_cpu=model, host_nproc=n_logical, host_cpu_quota=quota,
                 cores_note="threads = CPUs this process may use: affinity mask capped by the cgroup CPU quota (cpu.max)",
                 inflation_cells_per_s_per_core=n_inst * reps * n_cells * n_cells / dti / cores,
@@ -692,31 +721,43 @@ def main():
         launch_bytes = alg_bytes[dom] / G
         achieved = launch_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         achieved_serial = alg_bytes[dom] / (serial[dom] * 1e-3) / 1e9 if serial[dom] > 0 else 0.0
-        traffic, traffic_src = hbm_traffic_from_profiles(dom) if contract else (None, None)
-        pmc, pmc_src = pmc_summary_from_profiles() if contract else (None, None)
-        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic / G if traffic else None), "traffic_source": traffic_src,
-                "achieved_is": "ALGORITHMIC bytes (SURVEY 8d: 1000 B per scored trajectory) of one launch / its duration, HIP events on the launch's own "
-                               f"stream over the timed region - where {G} groups' kernels share the GPU, so a launch runs beside other streams' wavefront / "
-                               "scoring kernels and takes longer than alone (roofline.alone); a figure of merit, not HBM utilisation",
-                "algorithmic_bytes_per_launch": launch_bytes, "avg_launch_ms": launch_ms, "launches_timed": dom_n,
-                "alone": {"achieved": achieved_serial, "frac": achieved_serial / HBM_PEAK_GBS, "avg_launch_ms": serial[dom],
-                          "algorithmic_bytes_per_launch": alg_bytes[dom],
-                          "note": f"one launch over the whole fleet on one stream with nothing else on the GPU ({pre_steps} untimed cycles): the per-kernel figure"},
-                "frac_vs_measured_copy_peak_6290": achieved / 6290.0}
+        cur = current_profile() if contract else None
+        traffic, traffic_src = hbm_traffic_from_profiles(dom, cur)
+        pmc, pmc_src = pmc_summary_from_profiles(cur)
+        # roofline.frac: the dominant kernel's full-fleet launch ALONE (one stream, nothing overlapping; HIP events inside this run) -
+        # the per-kernel figure, comparable from round to round and with profiles/<tag>_kernel_stats.csv.  in_schedule: the same
+        # kernel's launches inside the timed region, where a launch covers 1 / G of the fleet and shares the GPU with the other
+        # groups' kernels.
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved_serial, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_serial / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "achieved_is": "ALGORITHMIC bytes (SURVEY 8d: 1000 B per scored trajectory) of one launch over the whole fleet / its duration alone on the GPU "
+                               f"(HIP events on the launch's stream, {pre_steps} untimed cycles on one stream inside this run).  A figure of merit, not HBM "
+                               "utilisation: the window, its screens and the heading tables live in LDS, and a fraction near or above 1 says the "
+                               "kernel does not move those bytes.  The ceiling it is graded against is frac_issue",
+                "algorithmic_bytes_per_launch": alg_bytes[dom], "avg_launch_ms": serial[dom],
+                "in_schedule": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "avg_launch_ms": launch_ms, "launches_timed": dom_n,
+                                "algorithmic_bytes_per_launch": launch_bytes,
+                                "note": f"the launches of the timed region: each covers 1 / {G} of the fleet and runs beside the other groups' wavefront / scoring kernels"},
+                "frac_vs_measured_copy_peak_6290": achieved_serial / 6290.0}
+        if cur:
+            roof["profile"] = {"tag": cur.get("tag"), "git_head": cur.get("git_head"), "sources_sha16": cur.get("sources_sha16"),
+                               "extra_flags": cur.get("extra_flags"), "running_sources_sha16": cur.get("running_sources_sha16"),
+                               "matches_running_build": cur.get("matches_running_build"),
+                               "note": "profiles/CURRENT.json: the rocprofv3 profile traffic / issue are quoted from; false = the library's sources have changed since it was taken"}
         if traffic and serial[dom] > 0:
             roof["hbm_measured"] = {"GBps": traffic / (serial[dom] * 1e-3) / 1e9, "frac_of_peak": traffic / (serial[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "bytes_per_launch": traffic, "note": "PMC FETCH_SIZE x2 + WRITE_SIZE (gfx950 correction), separate passes, --groups 1"}
         if pmc and dom in pmc.get("regions", {}):
             v = pmc["regions"][dom]
             roof["bound"] = v.get("bound", "latency")
-            roof["frac_issue"] = v.get("valu_issue_util")
-            roof["issue"] = {"valu_util": v.get("valu_issue_util"), "salu_util": v.get("salu_util"), "wait_any": v.get("wait_any"),
+            roof["frac_issue"] = v.get("cu_issue_util", v.get("valu_issue_util"))
+            roof["issue"] = {"cu_issue_util": v.get("cu_issue_util"), "valu_util": v.get("valu_issue_util"), "salu_util": v.get("salu_util"), "wait_any": v.get("wait_any"),
                              "wait_inst_any": v.get("wait_inst_any"), "active": v.get("active"), "lds_bank_conflict": v.get("lds_bank_conflict"),
-                             "insts_valu": v.get("insts_valu"), "insts_salu": v.get("insts_salu"), "kernel_time_ns": v.get("kernel_time_ns"),
+                             "insts_valu": v.get("insts_valu"), "insts_salu": v.get("insts_salu"), "insts_lds": v.get("insts_lds"), "kernel_time_ns": v.get("kernel_time_ns"),
                              "t_issue_ns": pmc.get("t_issue_ns"), "source": pmc_src,
-                             "note": "measured issue roofline of the full-fleet launch (--groups 1): SQ_INSTS_VALU x the box's own VALU issue time / "
-                                     "(1024 SIMDs x kernel time); wait shares of the resident waves' cycles (tools/pmc_summary.py)"}
+                             "note": "measured issue roofline of the full-fleet launch (--groups 1), tools/pmc_summary.py: cu_issue_util = (VALU + SALU + LDS + memory "
+                                     "wave-instructions) x the box's own issue time per instruction and CU / (256 CUs x kernel time) - a CU issues about as many "
+                                     "instructions per clock whatever their kind (tools/microbench/valu_rate); valu_util / salu_util are the two pipes alone"}
         costmap_ms = serial.get("k_obstacle", 0) + serial.get("k_merge", 0) + serial.get("k_inflate", 0)
         out = {
             "metric": "scored trajectories/sec (whole node) + costmap inflation cells/sec, 400x400 map",
@@ -753,11 +794,11 @@ def main():
         for k in serial:
             if serial[k] > 0 and alg_bytes.get(k, 0) > 0:
                 gbs = alg_bytes[k] / (serial[k] * 1e-3) / 1e9
-                tk, _ = hbm_traffic_from_profiles(k) if contract else (None, None)
+                tk, _ = hbm_traffic_from_profiles(k, cur)
                 per_kernel[k] = {"achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "avg_launch_ms_alone": serial[k], "traffic": tk,
                                  "algorithmic_bytes_per_launch": alg_bytes[k]}
                 if pmc and k in pmc.get("regions", {}):
-                    per_kernel[k]["frac_issue"] = pmc["regions"][k].get("valu_issue_util")
+                    per_kernel[k]["frac_issue"] = pmc["regions"][k].get("cu_issue_util", pmc["regions"][k].get("valu_issue_util"))
                     per_kernel[k]["bound"] = pmc["regions"][k].get("bound")
         out["roofline_all"] = per_kernel
         step_bytes = sum(alg_bytes.values())

@@ -115,7 +115,7 @@ def test_bench_two_ranks_stub_fleet_json_line():
     assert abs(d["value"] - d["trajectories_per_step"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     pr = d["per_rank_ms_per_step"]
     assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - d["ms_per_step"]) < 1e-6  # MAX over ranks is the job's time
-    assert d["roofline"]["kernel"] and "alone" in d["roofline"]
+    assert d["roofline"]["kernel"] and "in_schedule" in d["roofline"]
 
 
 def test_bench_refuses_ranks_that_share_a_device(monkeypatch):

@@ -48,7 +48,8 @@ def test_planner_configure_failure_keeps_previous_configuration(nav, orc):
         with pytest.raises(Exception):
             fl.configure_planner(large)
         _cycle_equals_oracle(fl, orc, small, insts, synth.FOOTPRINT, synth.RES)
-        # 2. a footprint whose window needs a larger image buffer than the limit allows: refused, the old footprint stays
+        # 2. a footprint whose window needs a larger image buffer (2 x ~28 KB) than the limit now allows: refused, the old footprint stays
+        fl.set_alloc_limit(40 << 10)
         big_fp = [[-1.2, -1.2], [1.2, -1.2], [1.2, 1.2], [-1.2, 1.2]]
         with pytest.raises(Exception):
             fl.set_footprint(big_fp)

@@ -35,3 +35,6 @@ done
 if [ ! -x tools/microbench/valu_rate ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/valu_rate.hip -o tools/microbench/valu_rate; fi
 ./tools/microbench/valu_rate > $out/${tag}_valu_rate_microbench.txt
 python3 tools/pmc_summary.py "$out" "$tag"
+# which build these numbers belong to (bench.py quotes the profile profiles/CURRENT.json names and flags it when the sources have moved on)
+python3 tools/profile_tag.py "$tag" > $out/${tag}_profile_tag.json
+echo "copy $out/${tag}_*.{csv,json,txt} into profiles/ and ${tag}_profile_tag.json to profiles/CURRENT.json"

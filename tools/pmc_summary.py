@@ -10,7 +10,9 @@ per region the instruction counts and a MEASURED issue roofline
                     resident wave's life: parked at s_waitcnt / barrier, stalled at issue, issuing)
   lds_bank_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
 
-`bound` is derived from those: "valu-issue" / "salu-issue" when that pipe is >= 60 % busy, otherwise the largest of the three
+  cu_issue_util   = all wave-instructions (VALU + SALU + LDS + SMEM + VMEM) x t_issue / (1024 SIMDs x kernel time)
+
+`bound` is derived from those: "valu-issue" / "salu-issue" when that pipe is >= 60 % busy, "issue" when all instructions together are, otherwise the largest of the three
 wave-cycle shares ("latency" = parked waves, "dependency" = issue stalls, "issue" = issuing but no single pipe saturated)."""
 import collections
 import csv
@@ -95,6 +97,12 @@ for g, members in GROUPS.items():
              device_kernels=[m for m in members if m in mix])
     v["valu_issue_util"] = v["insts_valu"] * t_issue_ns / (N_SIMD * t_ns) if t_ns else None
     v["salu_util"] = v["insts_salu"] / (N_CU * clk) if clk and v["insts_salu"] is not None else None
+    # every wave-instruction of whatever kind against the rate a SIMD issues at (round 4: a CU retires about as many instructions per
+    # clock whatever their mix - tools/microbench/valu_rate's scalar and mixed rows - and k_score_sweep takes the same time compiled
+    # for 4 or 6 waves per SIMD: what bounds it is the NUMBER of instructions)
+    n_all = sum(v[k] or 0.0 for k in ("insts_valu", "insts_salu", "insts_lds", "insts_smem", "insts_vmem_rd", "insts_vmem_wr"))
+    v["insts_all"] = n_all
+    v["cu_issue_util"] = n_all * t_issue_ns / (N_SIMD * t_ns) if t_ns else None
     wc = tot("SQ_WAVE_CYCLES")
     for name, c in (("wait_any", "SQ_WAIT_ANY"), ("wait_inst_any", "SQ_WAIT_INST_ANY"), ("active", "SQ_ACTIVE_INST_ANY"),
                     ("wait_inst_lds", "SQ_WAIT_INST_LDS")):
@@ -105,6 +113,8 @@ for g, members in GROUPS.items():
     v["wave_cycles_quadcycles"] = wc
     if (v["valu_issue_util"] or 0) >= 0.6:
         v["bound"] = "valu-issue"
+    elif (v["cu_issue_util"] or 0) >= 0.6:
+        v["bound"] = "issue"
     elif (v["salu_util"] or 0) >= 0.6:
         v["bound"] = "salu-issue"
     else:
@@ -115,11 +125,12 @@ json.dump(dict(source="rocprofv3 --pmc (three SQ counter passes, separate from t
                t_issue_ns=t_issue_ns, t_issue_source=t_src,
                valu_issue_util="SQ_INSTS_VALU x t_issue / (1024 SIMDs x kernel time from the --stats pass)",
                salu_util="SQ_INSTS_SALU / (256 CUs x GRBM_GUI_ACTIVE / 8)",
+               cu_issue_util="(SQ_INSTS_VALU + SALU + LDS + SMEM + VMEM_RD + VMEM_WR) x t_issue / (1024 SIMDs x kernel time)",
                wave_cycle_shares="SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES (MI355X_MICROARCH.md, PMC slots)",
                regions=regions), open(f"{out}/{tag}_pmc_summary.json", "w"), indent=1)
 rnd = lambda x: None if x is None else round(x, 3)
 for k, v in regions.items():
     print(k, dict(ms=rnd(v["kernel_time_ns"] / 1e6), valu_M=rnd(v["insts_valu"] / 1e6), salu_M=rnd((v["insts_salu"] or 0) / 1e6),
-                  valu_issue_util=rnd(v["valu_issue_util"]), salu_util=rnd(v["salu_util"]), wait_any=rnd(v["wait_any"]),
+                  valu_issue_util=rnd(v["valu_issue_util"]), salu_util=rnd(v["salu_util"]), cu_issue_util=rnd(v["cu_issue_util"]), wait_any=rnd(v["wait_any"]),
                   wait_inst_any=rnd(v["wait_inst_any"]), active=rnd(v["active"]), lds_conflict=rnd(v["lds_bank_conflict"]), bound=v["bound"]))
 print({k: (round(v["hbm_bytes_fetch_x2"] / 1e6, 1), "MB") for k, v in kern.items()})
