@@ -14,11 +14,17 @@ __device__ unsigned long long g_bfs_stats[16];  // shader clocks per wave: [0] p
 #define BFS_STAMP(v)
 #define BFS_ACC(i, x)
 #endif
+// An exchange record (a row's frontier and blocked words) is 2 x Wp words + 4: with records a multiple of 32 words apart, the uint4
+// accesses of the seven lanes that publish / take in neighbouring rows fell into the same four LDS banks (SQ_LDS_BANK_CONFLICT 0.50)
+#ifndef NAVGPU_ROWS_RECORD_PAD
+#define NAVGPU_ROWS_RECORD_PAD 4
+#endif
+constexpr uint32_t kRowsRecordPad = NAVGPU_ROWS_RECORD_PAD;
 template <int W>
 __host__ __device__ inline size_t bfs_rows_lds_words(uint32_t nx, uint32_t ny) {
   constexpr uint32_t Wp = (W + 3) & ~3u;
   const uint32_t nw = bfs_rows_waves(ny);
-  return (((size_t)nw * kRowsPerWave * ((nx + 31) >> 5) + 3) & ~(size_t)3) + (size_t)kCareRows * kCareWords + (size_t)(nw + 2) * 2 * kRowsHalo * 2 * Wp;
+  return (((size_t)nw * kRowsPerWave * ((nx + 31) >> 5) + 3) & ~(size_t)3) + (size_t)kCareRows * kCareWords + (size_t)(nw + 2) * 2 * kRowsHalo * (2 * Wp + kRowsRecordPad);
 }
 // One group of four words (A B C D, left neighbour word L, right neighbour word R) of one level, skipped as a whole when
 // bit g of the wave's active mask is clear.  Per word:
@@ -189,7 +195,8 @@ __device__ __forceinline__ void bfsRowsGrid(const PlannerDev& pl, const uint32_t
   uint32_t* seedm = sm;                                   // [rows_p][Wr], padded to whole 16 bytes
   uint32_t* care_l = sm + seed_words;                     // [kCareRows][kCareWords]
   uint32_t* edge = care_l + kCareRows * kCareWords;       // [nw + 2][top | bottom][D rows][frontier WP | blocked WP]; slot = wave + 1
-  const uint32_t edge_words = (nw + 2) * 2 * D * 2 * WP;
+  constexpr uint32_t RS = 2 * WP + kRowsRecordPad;  // record stride (words)
+  const uint32_t edge_words = (nw + 2) * 2 * D * RS;
   const uint8_t* master = pl.master + (size_t)inst * pl.cells_padded;
   const uint32_t* freew = bfsFreeBitmap(pl, which, inst, ny * Wr);
   uint32_t* dist = (which == 0 ? pl.path : (which == 1 ? pl.goal : pl.goal_front)) + (size_t)inst * pl.cells;
@@ -254,9 +261,9 @@ __device__ __forceinline__ void bfsRowsGrid(const PlannerDev& pl, const uint32_t
   //   own rows 0 .. D-1 (lanes D .. 2D-1) -> this wave's TOP record, read by the wave above into its lanes 64-D .. 63;
   //   own rows 50-D .. 49 (lanes 64-2D .. 63-D) -> BOTTOM record, read by the wave below into its lanes 0 .. D-1
   const bool pub_top = lane >= (uint32_t)D && lane < 2u * D, pub_bot = lane >= 64u - 2 * D && lane < 64u - D;
-  const uint32_t pub_wr = (((wave_id + 1) * 2 + (pub_top ? 0u : 1u)) * D + (pub_top ? lane - D : lane - (64u - 2 * D))) * 2 * WP;
+  const uint32_t pub_wr = (((wave_id + 1) * 2 + (pub_top ? 0u : 1u)) * D + (pub_top ? lane - D : lane - (64u - 2 * D))) * RS;
   const bool halo_top = lane < (uint32_t)D, halo_bot = lane >= 64u - D;
-  const uint32_t halo_rd = ((halo_top ? (wave_id * 2 + 1) : ((wave_id + 2) * 2)) * D + (halo_top ? lane : lane - (64u - D))) * 2 * WP;
+  const uint32_t halo_rd = ((halo_top ? (wave_id * 2 + 1) : ((wave_id + 2) * 2)) * D + (halo_top ? lane : lane - (64u - D))) * RS;
   constexpr uint32_t gmask = (1u << NG) - 1u;
 
   // which groups hold or border a frontier cell of this wave's 64 rows

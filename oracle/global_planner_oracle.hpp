@@ -269,6 +269,44 @@ struct GlobalPlannerOracle {
     cycles_used = cycle;
     return false;
   }
+  // AStarExpansion's RULE relaxed to its fixed point (astar.cpp:46-106): the potential of a cell from its neighbours' with the
+  // cost A* passes (costs + neutral_cost narrowed to unsigned char, :95 - no cost_factor), over the cells A* may enter (:90: below
+  // lethal_cost, or NO_INFORMATION when unknown is allowed - one cost value more than Dijkstra's getCost admits), from the start
+  // cell at 0.  A* itself sets a cell ONCE, when its first neighbour pops, and stops at the goal: its array lies at or above this
+  // one.  What a tiled wavefront for use_dijkstra = 0 would compute; tests/test_navfn.py holds it to the path-level contract.
+  bool astarFixedPoint(double start_x, double start_y, double end_x, double end_y) {
+    std::fill(potential.begin(), potential.end(), kPotHigh);
+    std::vector<int> fifo;
+    std::vector<uint8_t> queued(ns, 0);
+    size_t head = 0;
+    auto push = [&](int n) {
+      if (n >= nx && n < ns - nx && !queued[n] && !(costs[n] >= p.lethal_cost && !(p.allow_unknown && costs[n] == 255))) {
+        queued[n] = 1;
+        fifo.push_back(n);
+      }
+    };
+    const int k = (int)start_x + nx * (int)start_y;
+    potential[k] = 0;
+    for (int d : {k - 1, k + 1, k - nx, k + nx}) push(d);
+    while (head < fifo.size()) {
+      const int n = fifo[head++];
+      queued[n] = 0;
+      if (n == k) continue;
+      const float pot = calculatePotential((uint8_t)(costs[n] + p.neutral_cost), n);
+      if (pot < potential[n]) {
+        potential[n] = pot;
+        push(n - 1);
+        push(n + 1);
+        push(n - nx);
+        push(n + nx);
+      }
+      if (head > (1u << 22)) {
+        fifo.erase(fifo.begin(), fifo.begin() + head);
+        head = 0;
+      }
+    }
+    return potential[(int)end_x + nx * (int)end_y] < kPotHigh;
+  }
   // Expander::clearEndpoint (expander.h:76-89)
   void clearEndpoint(int gx, int gy, int s) {
     const int startCell = gx + nx * gy;
@@ -405,7 +443,9 @@ struct GlobalPlannerOracle {
     memcpy(costs.data(), cmap, (size_t)ns);
     if (p.outline_map) outlineMap(254);  // costmap_2d::LETHAL_OBSTACLE
     bool legal;
-    if (fixed_point)
+    if (fixed_point && !p.use_dijkstra)
+      legal = astarFixedPoint(start_x, start_y, goal_x, goal_y);
+    else if (fixed_point)
       legal = dijkstraFixedPoint(start_x, start_y, goal_x, goal_y, !p.old_navfn_behavior);
     else if (p.use_dijkstra)
       legal = dijkstra(start_x, start_y, goal_x, goal_y, nx * ny * 2, !p.old_navfn_behavior);  // setPreciseStart(true) unless old behaviour (planner_core.cpp:124-127)
