@@ -486,7 +486,9 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
                   }
                 }
               }
-              if ((en_gf && 2 < first_fail) || (en_al && 3 < first_fail)) {
+              // the forward point: on the map for sure while the point lies in the window and the window clear of the margin band
+              // (margin_on), and only the final point's cell is ever read - so most points that look closer skip its worldToMap
+              if (((en_gf && 2 < first_fail) || (en_al && 3 < first_fail)) && (last_pt || margin_on || !in_w)) {
                 double sx = x, sy = y;
                 if (fpd != 0.0) {
                   sx = x + fpd * cs;
