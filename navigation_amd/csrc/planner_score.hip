@@ -310,6 +310,28 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
         // and the generator's reject tests of the (vx, vy) pairs (a compensated fp64 square root each) - behind the image.
         uint8_t* rej = pl.prep + (size_t)inst * pl.prep_stride + score_prep_reject_offset(pl);
         int32_t* aux = reinterpret_cast<int32_t*>(rej - kScoreAuxBytes);
+        // d0: how far (Chebyshev, cells) from the robot's own cell - the window's centre - the nearest cell lies at which ANY screen is
+        // set (or the window ends).  A trajectory point fewer cells away than that passes every screen whatever else: the sweep skips
+        // its worldToMap and look-up for as many steps as the sample's speed cannot cover d0 cells in (k_score_sweep).
+        if (tid == 0) s_cnt[0] = win / 2;
+        __syncthreads();
+        {
+          const int c0 = win / 2;
+          int dmin = win;
+          for (int it = tid; it < win * nw; it += blockDim.x) {
+            const int y = it / nw, j = it - y * nw;
+            uint32_t m = (c.sum_scores ? s_fb[4 * it] : s_fb[4 * it + 1]) | s_fb[4 * it + 2] | s_fb[4 * it + 3];
+            const int dy = y > c0 ? y - c0 : c0 - y;
+            while (m) {
+              const int lx = 32 * j + __ffs(m) - 1;
+              m &= m - 1;
+              const int dx = lx > c0 ? lx - c0 : c0 - lx;
+              dmin = min(dmin, max(dx, dy));
+            }
+          }
+          atomicMin(&s_cnt[0], dmin);
+        }
+        __syncthreads();
         if (tid == 0) {
           const double inv_res = pl.inv_res, fpd = c.forward_point_distance;
           const bool en_fwd = pl.scale_goal != 0 || (pl.align_on[inst] && pl.scale_path != 0);  // goal_front or alignment critic on
@@ -328,7 +350,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           aux[4] = (int32_t)fwd_ny;
           aux[5] = need_margin ? 1 : 0;
           aux[6] = fwd_screen ? 1 : 0;
-          aux[7] = 0;
+          aux[7] = s_cnt[0];
         }
         // generateTrajectory's reject tests (simple_trajectory_generator.cpp:193-200), the part that depends on (vx, vy) only:
         // bit 0: vmag + eps < min_trans_vel (rejects together with the v_theta half), bit 1: vmag - eps > max_trans_vel

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   const int wx0 = aux[0], wy0 = aux[1];
   const uint32_t fwd_lo = (uint32_t)aux[2], fwd_nx = (uint32_t)aux[3], fwd_ny = (uint32_t)aux[4];
   const bool need_margin = aux[5] != 0, fwd_screen = aux[6] != 0;
+  const int free_cells = aux[7];  // Chebyshev distance from the robot's cell to the nearest cell with any screen set (or the window's edge)
   const uint32_t osc = pl.osc_flags[inst];
   const int32_t align_on = pl.align_on[inst];
   const int win_bytes = (win * win + 15) & ~15;
@@ -359,6 +360,30 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   const uint32_t scr_off = screen_on ? 0u : 0xFFFFFFFFu;
   SW_STAMP(sw2);
   SW_ACC(2, sw2 - sw1);
+  // k_free: the steps (0 .. k_free - 1) at which NO lane of the wave can be `free_cells` cells from the robot's cell yet.  A pose moves
+  // |v| dt per step (the rotated velocity's length; each float rounding adds < 1e-6 m), a cell index trails its pose by < 1 cell:
+  // point k is fewer than k s + 1 cells from the start cell, s = |v| dt / res rounded up - so k < (free_cells - 2) / s is safe.
+  // Only where the launch screens at all, the window lies clear of the map's margin band, and never the last point.
+  int k_free = 0;
+  {
+    const float spd = sqrtf(vs0 * vs0 + vs1 * vs1) * (float)(dt * inv_res) * 1.0001f + 1.0e-4f;
+    int kl = K - 1;  // (a lane that does not roll out does not hold the wave back)
+    if (alive_m != 0u) kl = (screen_on && !margin_on && free_cells >= 3) ? (int)fminf((float)(free_cells - 2) / spd, (float)(K - 1)) : 0;
+    for (int off = 32; off > 0; off >>= 1) kl = min(kl, __shfl_xor(kl, off));
+    k_free = __builtin_amdgcn_readfirstlane(kl);
+  }
+  // ---- the free run: the first k_free points of the whole wave - every screen is clear there, the point is in the window and not the
+  // last: nothing to look at, the pose just moves on (computeNewPositions :253-260; dead lanes compute along)
+  for (int k = 0; k < k_free; ++k) {
+    const int te = te0 + k;
+    const double cs = s_trig[4 * te], sn = s_trig[4 * te + 1], cs2 = s_trig[4 * te + 2], sn2 = s_trig[4 * te + 3];
+    const double tx = TRIGF ? (double)(vs[0] * (float)cs) : vxd * cs, ty = TRIGF ? (double)(vs[0] * (float)sn) : vxd * sn;
+    const float nxp = (float)(px + (tx + vyd * cs2) * dt);
+    const float nyp = (float)(py + (ty + vyd * sn2) * dt);
+    px = nxp;
+    py = nyp;
+  }
+  if (alive_m != 0u) step = k_free;
   for (uint32_t blk = 0;; ++blk) {
     SW_STAMP(sb0);
     // ---- sweep: up to kSweepBlockSteps points per lane.  The screened path is STRAIGHT-LINE for the whole wave - lanes whose
@@ -371,6 +396,11 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
         const int te = te0 + sc;
         const double x = px, y = py;
         const double cs = s_trig[4 * te], sn = s_trig[4 * te + 1];
+        // ---- advance (computeNewPositions :253-260): fp64 on fp32 state, rounded back to fp32 (the heading is the tables')
+        const double cs2 = s_trig[4 * te + 2], sn2 = s_trig[4 * te + 3];
+        const double tx = TRIGF ? (double)(vs[0] * (float)cs) : vxd * cs, ty = TRIGF ? (double)(vs[0] * (float)sn) : vxd * sn;
+        const float nxp = (float)(px + (tx + vyd * cs2) * dt);
+        const float nyp = (float)(py + (ty + vyd * sn2) * dt);
         uint32_t cx, cy;
         const bool ok_c = w2m(x, y, cx, cy);
         // ---- screen: on every point but the last a critic can only FAIL (its value is overwritten: aggregation Last; with
@@ -386,11 +416,6 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
         }
         const uint32_t fb_i = in_w ? ly * (uint32_t)nw + (lx >> 5) : 0u;
         const uint4 fbw = s_fb4[fb_i];
-        // ---- advance (computeNewPositions :253-260): fp64 on fp32 state, rounded back to fp32 (the heading is the tables')
-        const double cs2 = s_trig[4 * te + 2], sn2 = s_trig[4 * te + 3];
-        const double tx = TRIGF ? (double)(vs[0] * (float)cs) : vxd * cs, ty = TRIGF ? (double)(vs[0] * (float)sn) : vxd * sn;
-        const float nxp = (float)(px + (tx + vyd * cs2) * dt);
-        const float nyp = (float)(py + (ty + vyd * sn2) * dt);
         const uint32_t any = (scr_sum ? fbw.x : fbw.y) | (fbw.z & scr_z) | (fbw.w & scr_w) | force | (in_w ? 0u : 0xFFFFFFFFu);
         const bool unscr = ((any >> (lx & 31u)) & alive_m & 1u) != 0u;
         px = nxp;
