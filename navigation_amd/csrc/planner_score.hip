@@ -313,14 +313,20 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
         // d0: how far (Chebyshev, cells) from the robot's own cell - the window's centre - the nearest cell lies at which ANY screen is
         // set (or the window ends).  A trajectory point fewer cells away than that passes every screen whatever else: the sweep skips
         // its worldToMap and look-up for as many steps as the sample's speed cannot cover d0 cells in (k_score_sweep).
+        // The path / goal screen at the robot's own cell decides those critics for EVERY sample at step 0 (all rollouts start there):
+        // start_fail = 4 (the path critic fails there; the goal critic, later in the list, no longer counts either) or 5 (the goal
+        // critic does - e.g. a goal inside an inflated wall, 17 % of the benchmark's robots) or 0.  The distance is taken over the
+        // screens that still count after that.
+        const int c0 = win / 2;
+        const uint32_t w_c0 = (uint32_t)(c0 * nw + (c0 >> 5));
+        const int start_fail = ((s_fb[4 * w_c0 + 2] >> (c0 & 31)) & 1u) ? 4 : (((s_fb[4 * w_c0 + 3] >> (c0 & 31)) & 1u) ? 5 : 0);
         if (tid == 0) s_cnt[0] = win / 2;
         __syncthreads();
         {
-          const int c0 = win / 2;
           int dmin = win;
           for (int it = tid; it < win * nw; it += blockDim.x) {
             const int y = it / nw, j = it - y * nw;
-            uint32_t m = (c.sum_scores ? s_fb[4 * it] : s_fb[4 * it + 1]) | s_fb[4 * it + 2] | s_fb[4 * it + 3];
+            uint32_t m = (c.sum_scores ? s_fb[4 * it] : s_fb[4 * it + 1]) | (start_fail == 4 ? 0u : s_fb[4 * it + 2]) | (start_fail != 0 ? 0u : s_fb[4 * it + 3]);
             const int dy = y > c0 ? y - c0 : c0 - y;
             while (m) {
               const int lx = 32 * j + __ffs(m) - 1;
@@ -351,6 +357,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           aux[5] = need_margin ? 1 : 0;
           aux[6] = fwd_screen ? 1 : 0;
           aux[7] = s_cnt[0];
+          aux[8] = start_fail;
         }
         // generateTrajectory's reject tests (simple_trajectory_generator.cpp:193-200), the part that depends on (vx, vy) only:
         // bit 0: vmag + eps < min_trans_vel (rejects together with the v_theta half), bit 1: vmag - eps > max_trans_vel

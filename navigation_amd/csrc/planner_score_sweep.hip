@@ -91,7 +91,8 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   const int wx0 = aux[0], wy0 = aux[1];
   const uint32_t fwd_lo = (uint32_t)aux[2], fwd_nx = (uint32_t)aux[3], fwd_ny = (uint32_t)aux[4];
   const bool need_margin = aux[5] != 0, fwd_screen = aux[6] != 0;
-  const int free_cells = aux[7];  // Chebyshev distance from the robot's cell to the nearest cell with any screen set (or the window's edge)
+  const int free_cells = aux[7];  // Chebyshev distance from the robot's cell to the nearest cell with a screen set that still counts after step 0 (or the window's edge)
+  const int start_fail = aux[8];  // 4 / 5: the path / goal critic fails at the robot's own cell, i.e. for every sample at step 0; 0: neither
   const uint32_t osc = pl.osc_flags[inst];
   const int32_t align_on = pl.align_on[inst];
   const int win_bytes = (win * win + 15) & ~15;
@@ -384,6 +385,14 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
     py = nyp;
   }
   if (alive_m != 0u) step = k_free;
+  if (k_free > 0 && start_fail != 0 && alive_m != 0u) {  // what looking closer at point 0 would have found (the free run skipped it)
+    first_fail = start_fail;
+    fail_code = 0;
+    fail_cell = (uint32_t)(wy0 + win / 2) * g.nx + (uint32_t)(wx0 + win / 2);
+    scr_z = first_fail > 4 ? 0xFFFFFFFFu : 0u;
+    scr_w = 0u;
+    alive_m = first_fail > min_order ? 0xFFFFFFFFu : 0u;
+  }
   for (uint32_t blk = 0;; ++blk) {
     SW_STAMP(sb0);
     // ---- sweep: up to kSweepBlockSteps points per lane.  The screened path is STRAIGHT-LINE for the whole wave - lanes whose

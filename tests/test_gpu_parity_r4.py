@@ -155,3 +155,44 @@ def test_device_float_trig_against_host_libm(nav):
         ulp = np.abs(dev.view(np.int32).astype(np.int64) - host.view(np.int32).astype(np.int64))
         assert ulp.max() <= 1, ulp.max()
         assert (ulp != 0).mean() < 0.06
+
+
+# ----------------------------------------------------------------------------------------------
+# k_score_sweep's free run with a critic that fails at the robot's own cell: the goal (or the whole plan) sealed in a room of
+# lethal cells, the robot in open space - the goal (path) grid is unreachable where every rollout starts, so the critic fails for
+# every sample at point 0 (-2), which the launch takes as read before it skips the first points.  Every sample's cost, code, status.
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sealed", ["goal", "plan"])
+def test_score_sweep_free_run_with_critic_failing_at_start(nav, orc, sealed):
+    from navigation_amd import synth
+    N = L(nav)
+    n = 200
+    cfg = nav.DwaConfig(vx_samples=12, vy_samples=8, vth_samples=9, sim_time=2.0, sim_granularity=0.1, discretize_by_time=1)
+    ocfg = orc.DwaConfig(**cfg.as_dict())
+    m = np.zeros((n, n), np.uint8)
+    m[140:171, 140] = m[140:171, 170] = 254   # a sealed room, 30 cells square, far from the robot at (5 m, 5 m) = cell (100, 100)
+    m[140, 140:171] = m[170, 140:171] = 254
+    m[84, 60:140] = 254                       # and a wall 0.8 m from the robot: samples that run into it fail the obstacle critic first (-6)
+    master = orc.inflate(m, synth.RES, synth.INFLATION_RADIUS, synth.COST_SCALING, synth.inscribed_radius(synth.FOOTPRINT), exact=True)
+    pos = np.array([5.0, 5.0, -1.2], np.float32)  # heading for the wall
+    vel = np.array([0.2, 0.0, 0.1], np.float32)
+    t = np.linspace(0.0, 1.0, 120)
+    if sealed == "goal":   # the plan leaves the robot and ends in the room
+        plan = np.stack([5.0 + t * 2.75, 5.0 + t * 2.75], 1)
+    else:                  # the whole plan lies in the room
+        plan = np.stack([7.3 + t * 0.9, 7.3 + t * 0.9], 1)
+    fl = nav.Fleet(1, n, n, synth.RES, layers=N.LAYER_OBSTACLE, max_sim_steps=32, max_plan=256, keep_sample_costs=True)
+    fl.configure_planner(cfg)
+    fl.set_footprint(synth.FOOTPRINT)
+    fl.upload(N.GRID_MASTER, master[None])
+    fl.set_plan()
+    out = fl.find_best_path(pos[None], vel[None], plan[None])[0]
+    p = orc.DwaPlanner(master, synth.RES, 0.0, 0.0, ocfg)
+    p.set_plan()
+    o, _, _, cfull, ost = p.cycle(pos, vel, plan, synth.FOOTPRINT)
+    cost, status, _ = fl.samples(0)
+    assert np.array_equal(status, ost)
+    scored = ost == 1
+    assert scored.sum() > 100 and np.array_equal(cost[scored], cfull[scored])  # all failure codes here: equal as numbers
+    assert (cfull[scored] == -2.0).sum() > 50 and (cfull[scored] == -6.0).sum() > 10  # the sealed critic, and the obstacle critic before it
+    assert out.best_index == o.best_index == -1 and out.n_valid == o.n_valid == 0
