@@ -71,17 +71,12 @@ __device__ __forceinline__ void rowsGroup4(const int g, const uint32_t aw, uint3
       "s_cbranch_vccz 1f\n\t"
       "s_bitset1_b32 %[nz], %[g]\n\t"
       "v_cmp_ne_u32_e32 vcc, 0, %[hA]\n\t"
-      "s_nop 0\n\t"
-      "s_cmp_lg_u64 vcc, 0\n\t"
-      "s_cselect_b32 %[st], 1, 0\n\t"
-      "s_lshl_b32 %[st], %[st], %[g]\n\t"
-      "s_or_b32 %[lo], %[lo], %[st]\n\t"
+      "s_cbranch_vccz 3f\n\t"
+      "s_bitset1_b32 %[lo], %[g]\n\t"
+      "3:\n\t"
       "v_cmp_ne_u32_e32 vcc, 0, %[hD]\n\t"
-      "s_nop 0\n\t"
-      "s_cmp_lg_u64 vcc, 0\n\t"
-      "s_cselect_b32 %[st], 1, 0\n\t"
-      "s_lshl_b32 %[st], %[st], %[g]\n\t"
-      "s_or_b32 %[hi], %[hi], %[st]\n\t"
+      "s_cbranch_vccz 1f\n\t"
+      "s_bitset1_b32 %[hi], %[g]\n\t"
       "1:\n\t"
       : [bA] "+v"(bA), [bB] "+v"(bB), [bC] "+v"(bC), [bD] "+v"(bD), [hA] "=&v"(hA), [hB] "=&v"(hB), [hC] "=&v"(hC), [hD] "=&v"(hD), [nz] "+s"(nz),
         [lo] "+s"(lo), [hi] "+s"(hi), [tA] "=&v"(tA), [tB] "=&v"(tB), [tC] "=&v"(tC), [tD] "=&v"(tD),
@@ -576,17 +571,12 @@ __device__ __forceinline__ void rows2Group(const uint32_t aw, uint32_t& nz, uint
       "s_cbranch_vccz 1f\n\t"                                                                          \
       "s_bitset1_b32 %[nz], %[g]\n\t"                                                                  \
       "v_cmp_ne_u32_e32 vcc, 0, %[h0]\n\t"                                                             \
-      "s_nop 0\n\t"                                                                                    \
-      "s_cmp_lg_u64 vcc, 0\n\t"                                                                        \
-      "s_cselect_b32 %[st], 1, 0\n\t"                                                                  \
-      "s_lshl_b32 %[st], %[st], %[g]\n\t"                                                              \
-      "s_or_b32 %[lo], %[lo], %[st]\n\t"                                                               \
+      "s_cbranch_vccz 3f\n\t"                                                                          \
+      "s_bitset1_b32 %[lo], %[g]\n\t"                                                                  \
+      "3:\n\t"                                                                                         \
       "v_cmp_ne_u32_e32 vcc, 0, %[h3]\n\t"                                                             \
-      "s_nop 0\n\t"                                                                                    \
-      "s_cmp_lg_u64 vcc, 0\n\t"                                                                        \
-      "s_cselect_b32 %[st], 1, 0\n\t"                                                                  \
-      "s_lshl_b32 %[st], %[st], %[g]\n\t"                                                              \
-      "s_or_b32 %[hi], %[hi], %[st]\n\t"                                                               \
+      "s_cbranch_vccz 1f\n\t"                                                                          \
+      "s_bitset1_b32 %[hi], %[g]\n\t"                                                                  \
       "1:\n\t"                                                                                         \
       : [bA0] "+v"(bA[0]), [bA1] "+v"(bA[1]), [bA2] "+v"(bA[2]), [bA3] "+v"(bA[3]), [bB0] "+v"(bB[0]), [bB1] "+v"(bB[1]), [bB2] "+v"(bB[2]),  \
         [bB3] "+v"(bB[3]), [fA0] "+v"(fA[0]), [fA1] "+v"(fA[1]), [fA2] "+v"(fA[2]), [fA3] "+v"(fA[3]), [fB0] "+v"(fB[0]), [fB1] "+v"(fB[1]),   \
