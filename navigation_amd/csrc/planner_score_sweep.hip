@@ -28,10 +28,10 @@ namespace navgpu {
 
 constexpr int kSweepThreads = NAVGPU_SCORE_TAB_THREADS;
 #ifndef NAVGPU_SWEEP_BLOCK_STEPS
-#define NAVGPU_SWEEP_BLOCK_STEPS 5
+#define NAVGPU_SWEEP_BLOCK_STEPS 4  // A/B over 3..5 x 512..1024 on configs[2] and configs[4]: tools/ab_variants.sh, tools/ab_configs4.sh
 #endif
 #ifndef NAVGPU_SWEEP_QUEUE
-#define NAVGPU_SWEEP_QUEUE 512
+#define NAVGPU_SWEEP_QUEUE 768
 #endif
 constexpr int kSweepBlockSteps = NAVGPU_SWEEP_BLOCK_STEPS;  // trajectory points a lane sweeps between two walk phases
 constexpr int kSweepQueue = NAVGPU_SWEEP_QUEUE;             // walk entries a workgroup holds (12 B each)

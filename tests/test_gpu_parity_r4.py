@@ -64,7 +64,7 @@ def test_planner_configure_failure_keeps_previous_configuration(nav, orc):
 
 # ----------------------------------------------------------------------------------------------
 # k_score_sweep's walk queue under pressure: a robot boxed in by obstacles a few cells away has nearly every trajectory point
-# looked at closely, so the workgroup's queue (512 entries per block of 5 steps) overflows and lanes take points again in the next
+# looked at closely, so the workgroup's queue (768 entries per block of 4 steps) overflows and lanes take points again in the next
 # block; and one in the open never queues anything.  Both against the oracle, every sample's cost and status.
 # ----------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("sum_scores", [0, 1])
