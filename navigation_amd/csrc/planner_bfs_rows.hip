@@ -326,7 +326,9 @@ __device__ __forceinline__ void bfsRowsGrid(const PlannerDev& pl, const uint32_t
               for (int c = 0; c < 4; ++c) {
                 const int j = 4 * q + c;
                 if (j < W && j >= w0 && j <= w1) {
+#ifndef NAVGPU_BFS_X_NOSTORE  // (timing experiment, results garbage: the levels without their distance stores - 126 M -> 102 M wave-instructions, 0.33 -> 0.27 ms)
                   if (row_in_box && fr[j < W ? j : 0] != 0) storeCells(j, fr[j < W ? j : 0], level + 1);
+#endif
                 }
               }
             }

@@ -36,6 +36,16 @@ constexpr int kSweepThreads = NAVGPU_SCORE_TAB_THREADS;
 constexpr int kSweepBlockSteps = NAVGPU_SWEEP_BLOCK_STEPS;  // trajectory points a lane sweeps between two walk phases
 constexpr int kSweepQueue = NAVGPU_SWEEP_QUEUE;             // walk entries a workgroup holds (12 B each)
 constexpr uint32_t kWalkFailed = 0x80000000u;               // s_obs[owner]: a walked point failed; low bits: summed costs
+#ifdef NAVGPU_SWEEP_COUNTS  // experiment builds only (tools/probe_sweep_counts.py): how many points look closer, are walked, fail
+__device__ unsigned long long g_sweep_counts[16];
+#define SW_COUNT(slot_, n_)                                                                    \
+  do {                                                                                           \
+    const unsigned long long swc_ = (unsigned long long)(n_);                                    \
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&g_sweep_counts[slot_], swc_);                       \
+  } while (0)
+#else
+#define SW_COUNT(slot_, n_)
+#endif
 #ifdef NAVGPU_SWEEP_TIMING  // experiment builds only (tools/probe_sweep_timing.py): where a wave's time goes, one workgroup in 16 reports
 __device__ unsigned long long g_sweep_stats[16];
 #define SW_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
@@ -385,6 +395,8 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
     py = nyp;
   }
   if (alive_m != 0u) step = k_free;
+  SW_COUNT(9, k_free);
+  SW_COUNT(10, (unsigned)k_free * (unsigned)__popcll(__ballot(alive_m != 0u)));
   if (k_free > 0 && start_fail != 0 && alive_m != 0u) {  // what looking closer at point 0 would have found (the free run skipped it)
     first_fail = start_fail;
     fail_code = 0;
@@ -405,6 +417,8 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
         const int te = te0 + sc;
         const double x = px, y = py;
         const double cs = s_trig[4 * te], sn = s_trig[4 * te + 1];
+        SW_COUNT(4, 1);
+        SW_COUNT(8, __popcll(__ballot(alive_m != 0u)));
         // ---- advance (computeNewPositions :253-260): fp64 on fp32 state, rounded back to fp32 (the heading is the tables')
         const double cs2 = s_trig[4 * te + 2], sn2 = s_trig[4 * te + 3];
         const double tx = TRIGF ? (double)(vs[0] * (float)cs) : vxd * cs, ty = TRIGF ? (double)(vs[0] * (float)sn) : vxd * sn;
@@ -432,6 +446,8 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
         step -= (int)alive_m;  // (+1 while alive)
         if (__ballot(unscr) != 0ull) {  // (wave-uniform)
           SW_STAMP(ss0);
+          SW_COUNT(3, 1);
+          SW_COUNT(0, __popcll(__ballot(unscr)));
           if (unscr) {
             const bool last_pt = sc == K - 1;
             const bool on_map = cx < g.nx && cy < g.ny;  // (= ok_c)
@@ -463,6 +479,17 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
                 need_walk = false;
 #endif
                 const unsigned long long pm = __ballot(need_walk);
+#ifdef NAVGPU_SWEEP_COUNTS
+                {
+                  const unsigned long long pc = __ballot(need_walk && (scr_sum || last_pt)), pl_ = __ballot(need_walk && last_pt);
+                  const unsigned long long act = __ballot(true);
+                  if (lane == (uint32_t)(__ffsll((long long)act) - 1)) {
+                    atomicAdd(&g_sweep_counts[1], (unsigned long long)__popcll(pm & ~pc));
+                    atomicAdd(&g_sweep_counts[2], (unsigned long long)__popcll(pc));
+                    atomicAdd(&g_sweep_counts[11], (unsigned long long)__popcll(pl_));
+                  }
+                }
+#endif
                 if (pm != 0ull) {  // one LDS atomic per wave and step
                   const int leader = __ffsll((long long)pm) - 1;
                   uint32_t base = 0;
@@ -476,6 +503,9 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
                       s_qt[slot] = tid | ((uint32_t)sc << 10) | ((uint32_t)t_row << 17) | ((scr_sum || last_pt) ? 0x80000000u : 0u);
                     } else {
                       stall = true;  // the queue is full: this point is taken again in the next block
+#ifdef NAVGPU_SWEEP_COUNTS
+                      atomicAdd(&g_sweep_counts[12], 1ull);
+#endif
                     }
                   }
                 }
@@ -572,6 +602,12 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
       bool outside;
       const bool off = walkWindow(x, y, te, mx_cost, outside);
       if (__builtin_expect(outside && !off, 0)) mx_cost = walkCostmap(x, y, te);
+#ifdef NAVGPU_SWEEP_COUNTS
+      atomicAdd(&g_sweep_counts[5], 1ull);
+      if (off || mx_cost >= walk_fail) atomicAdd(&g_sweep_counts[6], 1ull);
+      if (!(off || mx_cost >= walk_fail) && !(tag >> 31)) atomicAdd(&g_sweep_counts[13], 1ull);  // walked for legality only, legal
+      if ((tid & 63u) == (uint32_t)(__ffsll((long long)__ballot(true)) - 1)) atomicAdd(&g_sweep_counts[7], 1ull);
+#endif
       if (off || mx_cost >= walk_fail) {  // footprint_cost < 0
         atomicOr(&s_obs[owner], kWalkFailed);
       } else if (tag >> 31) {
@@ -726,6 +762,16 @@ uint32_t launch_score_sweep(const PlannerDev& pl, uint32_t first, uint32_t count
   return blocks;
 }
 
+#ifdef NAVGPU_SWEEP_COUNTS
+extern "C" int navgpu_debug_sweep_counts(unsigned long long* out16, int reset) {
+  if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sweep_counts), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_counts), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 #ifdef NAVGPU_SWEEP_TIMING
 extern "C" int navgpu_debug_sweep_stats(unsigned long long* out16, int reset) {
   if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sweep_stats), sizeof(unsigned long long) * 16);
