@@ -152,6 +152,7 @@ struct PlannerDev {
   uint32_t* within;           // legacy planner: [n][ny][W] MapCell::within_robot bits of path_map_ on entry to launch_bfs, whose k_free_bits ORs the costmap's free bits in (= path_map_'s traversable-cell bitmap); else null
   uint32_t win;               // edge (cells) of the costmap window staged in LDS by k_score
   uint32_t fp_rcells;         // Chebyshev radius (cells) that contains every footprint cell around the centre cell
+  uint8_t fp_halfw[32];       // by |dy| <= fp_rcells: the largest |dx| at which a footprint cell can lie dy rows from the centre cell (a disc, planWindow); 0xFF: no such row
   uint32_t fp_chunk;          // cells of the longest footprint edge (+1): picks the k_score<CHUNK> instantiation
   uint32_t use_tables, tab_steps, tab_nfp, tab_nth;
   // MapGridCostFunction options beyond DWAPlanner's own wiring (navgpu_planner_set_map_grid_options), indexed

@@ -739,6 +739,17 @@ static void planWindow(const navgpu_fleet* f, PlannerDev& pl, const std::vector<
   uint32_t win = (uint32_t)std::min(cells * 2 + 1, 240.0);
   pl.win = win;
   pl.fp_rcells = (uint32_t)ceil(fp_radius / pl.res) + 1;  // vertex cells lie within this Chebyshev radius of the centre cell
+  {
+    // ... and every OUTLINE cell q within a disc around the centre cell c.  In cells: a vertex cell is floor(P + r_i) with |r_i| <= r =
+    // fp_radius / res, c = floor(P), so a_i - c lies within (-1, 1)^2 of r_i; LineIterator's cells keep within 1/2 cell (minor axis) of
+    // the segment between their end cells (line_iterator.h:110-127: offset floor((den / 2 + k numadd) / den) against k numadd / den);
+    // hence |q - c| < r + |(1, 1.5)| = r + 1.803.  The screens' structuring element is that disc clipped to the Chebyshev square.
+    const double rho = fp_radius / pl.res + 1.803 + 0.01;
+    for (uint32_t d = 0; d < 32; ++d) {
+      pl.fp_halfw[d] = 0xFF;
+      if (d <= pl.fp_rcells && (double)d <= rho) pl.fp_halfw[d] = (uint8_t)std::min<double>(pl.fp_rcells, floor(sqrt(rho * rho - (double)d * d)));
+    }
+  }
   {  // longest footprint edge in cells (both end cells included) over all instances
     double max_edge = 0.0;
     for (uint32_t i = 0; i < f->desc.n_instances; ++i) {
