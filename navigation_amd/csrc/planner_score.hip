@@ -30,6 +30,13 @@ __device__ unsigned long long g_score_stats[24];  // lane-steps, unscreened lane
 #else
 #define SCORE_STAT(i, v)
 #endif
+#ifdef NAVGPU_PREP_TIMING  // experiment builds only (tools/probe_prep_timing.py): where k_score_prep_tab's time goes (one workgroup in 16 reports)
+__device__ unsigned long long g_prep_stats[16];
+#define PREP_STAMP(i) \
+  if (PREP == 1) prep_t[i] = wall_clock64()
+#else
+#define PREP_STAMP(i)
+#endif
 template <bool EXPLICIT, bool TABLES, int THREADS, int PREP = 0, int CHUNK = 12, bool AGG = false>
 __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first, const float* explicit_sample) {
   extern __shared__ __align__(16) uint8_t s_dyn[];
@@ -42,6 +49,10 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
 
   const uint32_t inst = first + blockIdx.y;
   const uint32_t tid = threadIdx.x;
+#ifdef NAVGPU_PREP_TIMING
+  unsigned long long prep_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  PREP_STAMP(0);
 #ifdef NAVGPU_SCORE_TIMING
   const unsigned long long ts0 = wall_clock64();
 #endif
@@ -134,51 +145,62 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   const int rc = (int)pl.fp_rcells;
   const uint8_t fail_span_w = (pl.cfg.allow_unknown != 0) ? 0 : 1;
   if (PREP != 2) __syncthreads();
+  PREP_STAMP(1);  // staged: footprint, axis samples, window bytes
 #ifdef NAVGPU_SCORE_TIMING
   const unsigned long long ts0a = wall_clock64();
 #endif
   if (PREP != 2) {
-  for (int it = tid; it < win * nw; it += blockDim.x) {
-    const int y = it / nw, j = it - y * nw;
-    uint32_t nf = 0, fl = 0;
-    for (int b = 0; b < 32; ++b) {
-      const int lx = 32 * j + b;
-      uint32_t o = 1, f = 1;
+  {  // the raw bits: 64 consecutive cells of a (padded) window row per wave step, packed by ballot
+    const int row_cells = nw * 32;
+    const bool obst_off = pl.scale_obstacle == 0;  // obstacle critic off (scale 0: skipped, simple_scored_sampling_planner.cpp:55-57): nothing to screen
+    for (int base = (int)(tid & ~63u); base < win * row_cells; base += (int)blockDim.x) {
+      const int idx = base + (int)(tid & 63u);
+      const int y = idx / row_cells, lx = idx - y * row_cells;
       // cells off the MAP count as set like cells outside the window: a footprint vertex there fails
       // worldToMap, i.e. footprintCost = -1 (costmap_model.cpp:77-99), which only the polygon walk reports
       const int gx = wx0 + lx, gy = wy0 + y;
-      if (lx < win && gx >= 0 && gy >= 0 && gx < (int)g.nx && gy < (int)g.ny) {
-        const uint8_t cc = s_win[y * win + lx];
-        o = cc != 0 ? 1u : 0u;
-        f = (uint8_t)(cc - kLethal) <= fail_span_w ? 1u : 0u;
+      const bool in = lx < win && y < win && gx >= 0 && gy >= 0 && gx < (int)g.nx && gy < (int)g.ny;
+      const uint8_t cc = s_win[in ? y * win + lx : 0];
+      const bool o = !obst_off && (!in || cc != 0), f = !obst_off && (!in || (uint8_t)(cc - kLethal) <= fail_span_w);
+      const unsigned long long mo = __ballot(o), mf = __ballot(f);
+      if ((tid & 63u) == 0) {
+        const int w = idx >> 5;  // linear word index y * nw + j; a wave covers two words (possibly of two rows)
+        s_ba[2 * w] = (uint32_t)mo;
+        s_ba[2 * w + 1] = (uint32_t)mf;
+        if (w + 1 < win * nw) {
+          s_ba[2 * (w + 1)] = (uint32_t)(mo >> 32);
+          s_ba[2 * (w + 1) + 1] = (uint32_t)(mf >> 32);
+        }
       }
-      nf |= o << b;
-      fl |= f << b;
     }
-    if (pl.scale_obstacle == 0) nf = fl = 0;  // obstacle critic off (scale 0: skipped, simple_scored_sampling_planner.cpp:55-57): nothing to screen
-    s_ba[2 * it] = nf;
-    s_ba[2 * it + 1] = fl;
   }
   __syncthreads();
-  // the dilation: a DISC (PlannerDev::fp_halfw: per row offset dy the largest |dx| an outline cell can have), not the Chebyshev
-  // square around it - a fifth to a quarter fewer cells, and every cell less is trajectory points that need not be looked at
+  PREP_STAMP(2);  // raw bits
+  // The dilation: a DISC (PlannerDev::fp_halfw: per row offset dy the largest |dx| an outline cell can have), not the Chebyshev
+  // square around it - a fifth to a quarter fewer cells, and every cell less is trajectory points that need not be looked at.
+  // Grouped by dx: the rows that contribute at |dx| = d are |dy| <= Y(d) (the half widths fall with |dy|), so the rows are OR-ed
+  // in from the centre outwards (the word and its two neighbours) and row offset Y shifts the running OR by the d's it is the
+  // last row for: halfw[Y + 1] < d <= halfw[Y].  One shift pair per d instead of one per cell of the disc.
   for (int it = tid; it < 2 * win * nw; it += blockDim.x) {
     const int cell = it >> 1;
     const int y = cell / nw, j = cell - y * nw;
     uint32_t m = (y - rc < 0 || y + rc >= win || rc > 31) ? 0xFFFFFFFFu : 0u;  // (reach beyond the neighbouring words: no shortcut)
     if (!m) {
-      for (int dy = -rc; dy <= rc; ++dy) {
-        const int w = (int)pl.fp_halfw[dy < 0 ? -dy : dy];
-        if (w == 0xFF) continue;
-        const int src = it + 2 * dy * nw;
-        const uint32_t cur = s_ba[src];
-        const uint32_t left = j > 0 ? s_ba[src - 2] : 0xFFFFFFFFu, right = j + 1 < nw ? s_ba[src + 2] : 0xFFFFFFFFu;
-        m |= cur;
-        for (int d = 1; d <= w; ++d) m |= __builtin_amdgcn_alignbit(cur, left, 32 - d) | __builtin_amdgcn_alignbit(right, cur, d);
+      uint32_t vc = 0, vl = j > 0 ? 0u : 0xFFFFFFFFu, vr = j + 1 < nw ? 0u : 0xFFFFFFFFu;
+      for (int Y = 0; Y <= rc; ++Y) {
+        const int w = (int)pl.fp_halfw[Y];
+        if (w == 0xFF) break;
+        const int up = it + 2 * Y * nw, dn = it - 2 * Y * nw;
+        vc |= s_ba[up] | s_ba[dn];
+        if (j > 0) vl |= s_ba[up - 2] | s_ba[dn - 2];
+        if (j + 1 < nw) vr |= s_ba[up + 2] | s_ba[dn + 2];
+        const int wn = (Y + 1 <= rc && pl.fp_halfw[Y + 1] != 0xFF) ? (int)pl.fp_halfw[Y + 1] : -1;  // (the outermost row: every d down to 0)
+        for (int d = wn + 1; d <= w; ++d) m |= d == 0 ? vc : (__builtin_amdgcn_alignbit(vc, vl, 32 - d) | __builtin_amdgcn_alignbit(vr, vc, d));
       }
     }
     s_fb[4 * cell + (it & 1)] = m;
   }
+  PREP_STAMP(3);  // dilation
   {  // MapGrid screens: 64 consecutive cells of a (padded) window row per wave step, packed by ballot
     const uint32_t n_obst = pl.cells, n_unreach = pl.cells + 1;
     const int row_cells = nw * 32;
@@ -266,6 +288,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
   }
   if (TABLES && PREP != 2) {
     __syncthreads();  // s_axis, s_fp staged
+    PREP_STAMP(4);  // MapGrid screens (+ walk-order swap)
     const double dt_t = c.sim_time / K;
     if ((int)tid < nth_s) {
       float pth = st.pos[2];
@@ -276,6 +299,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
       }
     }
     __syncthreads();
+    PREP_STAMP(5);  // heading sequences
     for (int e = tid; e < nth_s * K; e += blockDim.x) {
       const double th = s_th[e];
       double sn, cs, sn2, cs2;
@@ -293,6 +317,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
     }
   }
   if (PREP != 2) __syncthreads();
+  PREP_STAMP(6);  // trig + rotated footprints
 #ifdef NAVGPU_SCORE_TIMING
   const unsigned long long ts0b = wall_clock64();
 #endif
@@ -319,18 +344,18 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
         const int start_fail = ((s_fb[4 * w_c0 + 2] >> (c0 & 31)) & 1u) ? 4 : (((s_fb[4 * w_c0 + 3] >> (c0 & 31)) & 1u) ? 5 : 0);
         if (tid == 0) s_cnt[0] = win / 2;
         __syncthreads();
+        PREP_STAMP(7);  // image stored
         {
           int dmin = win;
           for (int it = tid; it < win * nw; it += blockDim.x) {
             const int y = it / nw, j = it - y * nw;
             uint32_t m = (c.sum_scores ? s_fb[4 * it] : s_fb[4 * it + 1]) | (start_fail == 4 ? 0u : s_fb[4 * it + 2]) | (start_fail != 0 ? 0u : s_fb[4 * it + 3]);
             const int dy = y > c0 ? y - c0 : c0 - y;
-            while (m) {
-              const int lx = 32 * j + __ffs(m) - 1;
-              m &= m - 1;
-              const int dx = lx > c0 ? lx - c0 : c0 - lx;
-              dmin = min(dmin, max(dx, dy));
-            }
+            // the set cell nearest to column c0: the lowest set bit at or right of it, the highest left of it (no loop over the bits)
+            const int p = c0 - 32 * j;  // c0's bit position in this word (may lie outside it)
+            const uint32_t right = p <= 0 ? m : (p >= 32 ? 0u : m & (0xFFFFFFFFu << p)), left = m & ~right;
+            if (right) dmin = min(dmin, max(32 * j + __ffs(right) - 1 - c0, dy));
+            if (left) dmin = min(dmin, max(c0 - (32 * j + 31 - __clz(left)), dy));
           }
           atomicMin(&s_cnt[0], dmin);
         }
@@ -365,6 +390,13 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           const double eps = 1e-4;
           rej[i] = (uint8_t)(((c.min_trans_vel >= 0 && vmag + eps < c.min_trans_vel) ? 1 : 0) | ((c.max_trans_vel >= 0 && vmag - eps > c.max_trans_vel) ? 2 : 0));
         }
+#ifdef NAVGPU_PREP_TIMING
+        PREP_STAMP(8);  // free distance, scalars, reject bytes
+        if (PREP == 1 && tid == 0 && (blockIdx.y & 15u) == 3u) {
+          for (int i = 0; i < 8; ++i) atomicAdd(&g_prep_stats[i], prep_t[i + 1] - prep_t[i]);
+          atomicAdd(&g_prep_stats[15], 1ull);
+        }
+#endif
       }
       return;
     }
@@ -1126,6 +1158,16 @@ uint32_t launch_score(const PlannerDev& pl_in, uint32_t first, uint32_t count, c
   return gen_blocks;
 }
 
+#ifdef NAVGPU_PREP_TIMING
+extern "C" int navgpu_debug_prep_stats(unsigned long long* out16, int reset) {
+  if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_prep_stats), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_prep_stats), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 #if defined(NAVGPU_SCORE_STATS) || defined(NAVGPU_SCORE_TIMING)
 extern "C" int navgpu_debug_score_stats(unsigned long long* out8, int reset) {
   if (out8) hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_score_stats), sizeof(unsigned long long) * 24);
