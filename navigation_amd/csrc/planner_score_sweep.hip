@@ -153,17 +153,20 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
     const int n_trig = ncopy * K * 2, n_rot = ncopy * K * tnfp;  // 32 B per entry, 16 B per vertex
     const int l_trig = n16w + r0 * K * 2, g_trig = n16w + (t_row_base + r0) * K * 2;
     const int l_rot = n16w + lrows * K * 2 + r0 * K * tnfp, g_rot = n16w + (int)pl.tab_nth * K * 2 + (t_row_base + r0) * K * tnfp;
-    const int n16t = n16w + n_trig + n_rot;
-    auto srcOf = [&](int i) { return i < n16w ? i : (i < n16w + n_trig ? g_trig + (i - n16w) : g_rot + (i - n16w - n_trig)); };
-    auto dstOf = [&](int i) { return i < n16w ? i : (i < n16w + n_trig ? l_trig + (i - n16w) : l_rot + (i - n16w - n_trig)); };
-    constexpr int kBatch = 4;  // 16-byte loads a lane has in flight (4 x 256 lanes x 16 B = 16 KB: a configs[2] image whole)
-    uint4 v[kBatch];
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u) v[u] = img[srcOf(min((int)tid + u * THREADS, n16t - 1))];
-#pragma unroll
-    for (int u = 0; u < kBatch; ++u)
-      if ((int)tid + u * THREADS < n16t) lds[dstOf((int)tid + u * THREADS)] = v[u];
-    for (int i = (int)tid + kBatch * THREADS; i < n16t; i += THREADS) lds[dstOf(i)] = img[srcOf(i)];  // larger images: the rest
+    // three plain block copies (window + screens; the trig rows; the rotated-footprint rows), their first 2 + 1 + 1 loads per lane
+    // issued together (a configs[2] image whole: 375 + 80 + 160 sixteen-byte words); what is larger follows in loops
+    const int ia0 = (int)tid, ia1 = (int)tid + THREADS;
+    const uint4 va0 = img[min(ia0, n16w - 1)], va1 = img[min(ia1, n16w - 1)];
+    const uint4 vb = img[g_trig + min((int)tid, n_trig - 1)], vc = img[g_rot + min((int)tid, max(n_rot, 1) - 1)];
+    if (ia0 < n16w) lds[ia0] = va0;
+    if (ia1 < n16w) lds[ia1] = va1;
+    if ((int)tid < n_trig) lds[l_trig + (int)tid] = vb;
+    if ((int)tid < n_rot) lds[l_rot + (int)tid] = vc;
+    if (n16w > 2 * THREADS || n_trig > THREADS || n_rot > THREADS) {  // (one wave-uniform test instead of three loop headers)
+      for (int i = (int)tid + 2 * THREADS; i < n16w; i += THREADS) lds[i] = img[i];
+      for (int i = (int)tid + THREADS; i < n_trig; i += THREADS) lds[l_trig + i] = img[g_trig + i];
+      for (int i = (int)tid + THREADS; i < n_rot; i += THREADS) lds[l_rot + i] = img[g_rot + i];
+    }
   }
   SW_STAMP(sw1a);
   __syncthreads();
