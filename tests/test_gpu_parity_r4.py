@@ -196,3 +196,70 @@ def test_score_sweep_free_run_with_critic_failing_at_start(nav, orc, sealed):
     assert scored.sum() > 100 and np.array_equal(cost[scored], cfull[scored])  # all failure codes here: equal as numbers
     assert (cfull[scored] == -2.0).sum() > 50 and (cfull[scored] == -6.0).sum() > 10  # the sealed critic, and the obstacle critic before it
     assert out.best_index == o.best_index == -1 and out.n_valid == o.n_valid == 0
+
+
+# ----------------------------------------------------------------------------------------------
+# The obstacle screens' structuring element is a DISC of r + 1.803 cells around the centre cell (navgpu_host.cpp planWindow: every cell
+# LineIterator can put on the outline lies inside it), no longer the Chebyshev square around that disc: a screen that is one cell too
+# tight shows as a missed collision (-6) or a missed cost.  Footprints whose far vertices sweep the rim of the disc - a needle, a
+# triangle with one long arm, the five-vertex one - among single lethal cells scattered at every distance and bearing, every
+# sample's status, failure code and cost against the oracle.
+# ----------------------------------------------------------------------------------------------
+_RIM_FOOTPRINTS = {
+    "needle": [[0.5, 0.05], [0.5, -0.05], [-0.5, -0.05], [-0.5, 0.05]],
+    "arm": [[0.62, 0.0], [-0.15, 0.2], [-0.15, -0.2]],
+    "poly5": [[-0.325, -0.325], [-0.325, 0.325], [0.325, 0.325], [0.46, 0.0], [0.325, -0.325]],
+    "square": [[0.2, 0.2], [0.2, -0.2], [-0.2, -0.2], [-0.2, 0.2]],
+}
+
+
+@pytest.mark.parametrize("shape", sorted(_RIM_FOOTPRINTS))
+@pytest.mark.parametrize("sum_scores", [0, 1])
+def test_score_screens_at_the_rim_of_the_footprint_disc(nav, orc, shape, sum_scores):
+    from navigation_amd import synth
+    N = L(nav)
+    n, nI = 200, 4
+    fp = _RIM_FOOTPRINTS[shape]
+    r_cells = max(np.hypot(x, y) for x, y in fp) / synth.RES
+    cfg = nav.DwaConfig(vx_samples=12, vy_samples=8, vth_samples=15, sim_time=2.0, sim_granularity=0.1, discretize_by_time=1, sum_scores=sum_scores,
+                        occdist_scale=0.02, max_rot_vel=2.0, acc_lim_theta=20.0, allow_unknown=1 - sum_scores)
+    ocfg = orc.DwaConfig(**cfg.as_dict())
+    insts, masters = [], []
+    for k in range(nI):
+        ins = _inflated_instance(orc, n, 300 + 7 * k, synth)
+        rs = np.random.RandomState(900 + k)
+        m = np.zeros_like(ins["master"])
+        cx, cy = int(ins["pos"][0] / synth.RES), int(ins["pos"][1] / synth.RES)
+        yy, xx = np.mgrid[0:n, 0:n]
+        d = np.hypot(xx - cx, yy - cy)
+        posts = (rs.rand(n, n) < (0.004 + 0.004 * k)) & (d > r_cells + 2.5) & (d < 60)   # the start pose is legal, the rollouts graze posts
+        m[posts] = 254
+        if k % 2:  # NO_INFORMATION cells: they fail pointCost with allow_unknown off (the sum_scores runs), cost 255 with it on
+            m[(rs.rand(n, n) < 0.002) & (d > r_cells + 2.5) & (d < 60)] = 255
+        insts.append(dict(ins, master=m))
+        masters.append(m)
+    fl = nav.Fleet(nI, n, n, synth.RES, layers=N.LAYER_OBSTACLE, max_sim_steps=32, max_plan=256, keep_sample_costs=True)
+    fl.configure_planner(cfg)
+    fl.set_footprint(fp)
+    fl.upload(N.GRID_MASTER, np.stack(masters))
+    fl.set_plan()
+    vel = np.stack([i["vel"] for i in insts]).astype(np.float32)
+    out = fl.find_best_path(np.stack([i["pos"] for i in insts]).astype(np.float32), vel, np.stack([i["plan"] for i in insts]))
+    n_fail = n_ok = 0
+    for k, ins in enumerate(insts):
+        p = orc.DwaPlanner(ins["master"], synth.RES, 0.0, 0.0, ocfg)
+        p.set_plan()
+        o, _, _, cfull, ost = p.cycle(ins["pos"], ins["vel"], ins["plan"], fp)
+        cost, status, _ = fl.samples(k)
+        assert np.array_equal(status, ost)
+        scored = ost == 1
+        assert np.array_equal(cost[scored] < 0, cfull[scored] < 0), (shape, k)
+        neg = scored & (cfull < 0)
+        assert np.array_equal(cost[neg], cfull[neg]), (shape, k)             # failure codes
+        pos_ = scored & (cfull >= 0)
+        assert np.abs(cost[pos_] - cfull[pos_]).max(initial=0.0) <= 1e-5, (shape, k)
+        assert out[k].best_index == o.best_index and abs(out[k].cost - o.cost) <= 1e-5
+        n_fail += int((cfull[scored] == -6).sum())
+        n_ok += int(pos_.sum())
+    assert n_fail > 50 and n_ok > 50, (n_fail, n_ok)  # the scene exercises both outcomes
+    fl.close()
