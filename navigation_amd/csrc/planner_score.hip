@@ -332,7 +332,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
         // and the generator's reject tests of the (vx, vy) pairs (a compensated fp64 square root each) - behind the image.
         uint8_t* rej = pl.prep + (size_t)inst * pl.prep_stride + score_prep_reject_offset(pl);
         int32_t* aux = reinterpret_cast<int32_t*>(rej - kScoreAuxBytes);
-        // d0: how far (Chebyshev, cells) from the robot's own cell - the window's centre - the nearest cell lies at which ANY screen is
+        // d0: how far (Euclidean, cells, rounded down) from the robot's own cell - the window's centre - the nearest cell lies at which ANY screen is
         // set (or the window ends).  A trajectory point fewer cells away than that passes every screen whatever else: the sweep skips
         // its worldToMap and look-up for as many steps as the sample's speed cannot cover d0 cells in (k_score_sweep).
         // The path / goal screen at the robot's own cell decides those critics for EVERY sample at step 0 (all rollouts start there):
@@ -342,11 +342,11 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
         const int c0 = win / 2;
         const uint32_t w_c0 = (uint32_t)(c0 * nw + (c0 >> 5));
         const int start_fail = ((s_fb[4 * w_c0 + 2] >> (c0 & 31)) & 1u) ? 4 : (((s_fb[4 * w_c0 + 3] >> (c0 & 31)) & 1u) ? 5 : 0);
-        if (tid == 0) s_cnt[0] = win / 2;
+        if (tid == 0) s_cnt[0] = (win / 2) * (win / 2);  // (squared: the distance is Euclidean - a pose moves |v| dt whatever its bearing)
         __syncthreads();
         PREP_STAMP(7);  // image stored
         {
-          int dmin = win;
+          int dmin = win * win;
           for (int it = tid; it < win * nw; it += blockDim.x) {
             const int y = it / nw, j = it - y * nw;
             uint32_t m = (c.sum_scores ? s_fb[4 * it] : s_fb[4 * it + 1]) | (start_fail == 4 ? 0u : s_fb[4 * it + 2]) | (start_fail != 0 ? 0u : s_fb[4 * it + 3]);
@@ -354,8 +354,8 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
             // the set cell nearest to column c0: the lowest set bit at or right of it, the highest left of it (no loop over the bits)
             const int p = c0 - 32 * j;  // c0's bit position in this word (may lie outside it)
             const uint32_t right = p <= 0 ? m : (p >= 32 ? 0u : m & (0xFFFFFFFFu << p)), left = m & ~right;
-            if (right) dmin = min(dmin, max(32 * j + __ffs(right) - 1 - c0, dy));
-            if (left) dmin = min(dmin, max(c0 - (32 * j + 31 - __clz(left)), dy));
+            if (right) dmin = min(dmin, (32 * j + __ffs(right) - 1 - c0) * (32 * j + __ffs(right) - 1 - c0) + dy * dy);
+            if (left) dmin = min(dmin, (c0 - (32 * j + 31 - __clz(left))) * (c0 - (32 * j + 31 - __clz(left))) + dy * dy);
           }
           atomicMin(&s_cnt[0], dmin);
         }
@@ -378,7 +378,7 @@ __device__ __forceinline__ void score_body(const PlannerDev& pl, uint32_t first,
           aux[4] = (int32_t)fwd_ny;
           aux[5] = need_margin ? 1 : 0;
           aux[6] = fwd_screen ? 1 : 0;
-          aux[7] = s_cnt[0];
+          aux[7] = (int)floor(sqrt((double)s_cnt[0]));
           aux[8] = start_fail;
         }
         // generateTrajectory's reject tests (simple_trajectory_generator.cpp:193-200), the part that depends on (vx, vy) only:

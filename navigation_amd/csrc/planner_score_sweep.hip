@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   const int wx0 = aux[0], wy0 = aux[1];
   const uint32_t fwd_lo = (uint32_t)aux[2], fwd_nx = (uint32_t)aux[3], fwd_ny = (uint32_t)aux[4];
   const bool need_margin = aux[5] != 0, fwd_screen = aux[6] != 0;
-  const int free_cells = aux[7];  // Chebyshev distance from the robot's cell to the nearest cell with a screen set that still counts after step 0 (or the window's edge)
+  const int free_cells = aux[7];  // Euclidean distance (rounded down) from the robot's cell to the nearest cell with a screen set that still counts after step 0 (or the window's edge)
   const int start_fail = aux[8];  // 4 / 5: the path / goal critic fails at the robot's own cell, i.e. for every sample at step 0; 0: neither
   const uint32_t osc = pl.osc_flags[inst];
   const int32_t align_on = pl.align_on[inst];
@@ -374,10 +374,10 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   const uint32_t scr_off = screen_on ? 0u : 0xFFFFFFFFu;
   SW_STAMP(sw2);
   SW_ACC(2, sw2 - sw1);
-  // k_free: the steps (0 .. k_free - 1) at which NO lane of the wave can be `free_cells` cells from the robot's cell yet.  A pose moves
-  // |v| dt per step (the rotated velocity's length; each float rounding adds < 1e-6 m), a cell index trails its pose by < 1 cell:
-  // point k is fewer than k s + 1 cells from the start cell, s = |v| dt / res rounded up - so k < (free_cells - 2) / s is safe.
-  // Only where the launch screens at all, the window lies clear of the map's margin band, and never the last point.
+  // k_free: the steps (0 .. k_free - 1) at which NO lane of the wave can be `free_cells` cells (Euclidean) from the robot's cell yet.  A pose
+  // moves |v| dt per step (the rotated velocity's length; each float rounding adds < 1e-6 m), a cell index trails its pose by < 1 cell
+  // in x and in y, as the start cell does: point k's cell is fewer than k s + sqrt(2) cells from the start cell, s = |v| dt / res rounded
+  // up - so k < (free_cells - 2) / s is safe.  Only where the launch screens at all, the window lies clear of the map's margin band, and never the last point.
   int k_free = 0;
   {
     const float spd = sqrtf(vs0 * vs0 + vs1 * vs1) * (float)(dt * inv_res) * 1.0001f + 1.0e-4f;
