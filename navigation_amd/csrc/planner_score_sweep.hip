@@ -451,111 +451,113 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
           SW_STAMP(ss0);
           SW_COUNT(3, 1);
           SW_COUNT(0, __popcll(__ballot(unscr)));
-          if (unscr) {
-            const bool last_pt = sc == K - 1;
-            const bool on_map = cx < g.nx && cy < g.ny;  // (= ok_c)
-            const int lxw = (int)lx;
-            bool stall = false;
-            // ---- obstacle critic: decide here, walk later
-            if (en_obs) {
-              if (!on_map) {  // CostmapModel::footprintCost: centre off the map -> -1 -> -6 (obstacle_cost_function.cpp:127-131)
-                fail_code = -6;
-                first_fail = 1;
-              } else if (nfp < 3) {  // the centre cell alone (costmap_model.cpp:63-72)
+          // ---- looking closer, in the same style as the screened path: every lane computes along, WHO is concerned is a mask (u: the
+          // lanes that look closer; all-ones / zero words combined with integer ops, picked with sel), the rare cases - a footprint of
+          // fewer than three points, a point outside the LDS window, the forward point's worldToMap - sit behind one wave-uniform
+          // ballot each.  (As nested per-lane ifs this block compiled to ~400 instructions of which a wave that entered it ran
+          // most: a sixth of the kernel.)
+          auto sel = [](uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); };
+          const uint32_t u = unscr ? 0xFFFFFFFFu : 0u;
+          const uint32_t m_last = sc == K - 1 ? 0xFFFFFFFFu : 0u;
+          const uint32_t m_on = ok_c ? 0xFFFFFFFFu : 0u;  // the centre is on the map (cx < nx && cy < ny)
+          const uint32_t m_inw = in_w ? 0xFFFFFFFFu : 0u;
+          const uint32_t bit = lx & 31u;
+          const uint32_t b_nf = 0u - ((fbw.x >> bit) & 1u), b_cf = 0u - ((fbw.y >> bit) & 1u), b_z = 0u - ((fbw.z >> bit) & 1u), b_w = 0u - ((fbw.w >> bit) & 1u);
+          uint32_t m_stall = 0u;
+          // ---- obstacle critic: decide here, walk later
+          if (en_obs) {  // (uniform)
+            const uint32_t m_off = u & ~m_on;  // CostmapModel::footprintCost: centre off the map -> -1 -> -6 (obstacle_cost_function.cpp:127-131)
+            first_fail = (int)sel(m_off, 1u, (uint32_t)first_fail);
+            fail_code = (int)sel(m_off, (uint32_t)-6, (uint32_t)fail_code);
+            if (nfp < 3) {  // (uniform, rare) the centre cell alone (costmap_model.cpp:63-72)
+              if ((u & m_on) != 0u) {
                 const uint8_t cc = cellCost(cx, cy);
                 if (cc == kLethal || cc == kInscribed || (cc == kNoInfo && c.allow_unknown == 0)) {
                   fail_code = -6;
                   first_fail = 1;
-                } else if (scr_sum || last_pt) {
+                } else if (scr_sum || m_last != 0u) {
                   atomicAdd(&s_obs[tid], (uint32_t)cc);  // occ = max(f_cost, centre cell) = the cell's cost
                 }
-              } else {
-                // all_free: every cell the footprint can touch is FREE_SPACE -> the point costs exactly 0.  Without sum_scores
-                // only the LAST point's footprint cost survives (cost = f_cost), the earlier points only have to be legal: no
-                // failing cell in reach is enough.
-                bool need_walk = true;
-                if (in_w) {
-                  const bool not_free = (fbw.x >> (lxw & 31)) & 1u, can_fail = (fbw.y >> (lxw & 31)) & 1u;
-                  need_walk = not_free && (scr_sum || last_pt || can_fail);
-                }
+              }
+            } else {
+              // all_free: every cell the footprint can touch is FREE_SPACE -> the point costs exactly 0.  Without sum_scores only the
+              // LAST point's footprint cost survives (cost = f_cost), the earlier points only have to be legal: no failing cell in
+              // reach is enough.  Outside the window there is no screen: walk.
+              uint32_t m_need = u & m_on & ((b_nf & ((scr_sum ? 0xFFFFFFFFu : 0u) | m_last | b_cf)) | ~m_inw);
 #ifdef NAVGPU_SWEEP_X_NOWALK  // timing experiment: the sweep alone
-                need_walk = false;
+              m_need = 0u;
 #endif
-                const unsigned long long pm = __ballot(need_walk);
+              const unsigned long long pm = __ballot(m_need != 0u);
 #ifdef NAVGPU_SWEEP_COUNTS
-                {
-                  const unsigned long long pc = __ballot(need_walk && (scr_sum || last_pt)), pl_ = __ballot(need_walk && last_pt);
-                  const unsigned long long act = __ballot(true);
-                  if (lane == (uint32_t)(__ffsll((long long)act) - 1)) {
-                    atomicAdd(&g_sweep_counts[1], (unsigned long long)__popcll(pm & ~pc));
-                    atomicAdd(&g_sweep_counts[2], (unsigned long long)__popcll(pc));
-                    atomicAdd(&g_sweep_counts[11], (unsigned long long)__popcll(pl_));
+              {
+                const unsigned long long pc = __ballot(m_need != 0u && (scr_sum || m_last != 0u)), pl_ = __ballot(m_need != 0u && m_last != 0u);
+                if (lane == 0) {
+                  atomicAdd(&g_sweep_counts[1], (unsigned long long)__popcll(pm & ~pc));
+                  atomicAdd(&g_sweep_counts[2], (unsigned long long)__popcll(pc));
+                  atomicAdd(&g_sweep_counts[11], (unsigned long long)__popcll(pl_));
+                }
+              }
+#endif
+              if (pm != 0ull) {  // one LDS atomic per wave and step
+                const int leader = __ffsll((long long)pm) - 1;
+                uint32_t base = 0;
+                if ((int)lane == leader) base = atomicAdd(&s_qn[blk & 1u], (uint32_t)__popcll(pm));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                const uint32_t slot = base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
+                m_stall = m_need & (slot >= (uint32_t)kSweepQueue ? 0xFFFFFFFFu : 0u);  // the queue is full: this point is taken again in the next block
+                if ((m_need & ~m_stall) != 0u) {
+                  s_qx[slot] = (float)x;
+                  s_qy[slot] = (float)y;
+                  s_qt[slot] = tid | ((uint32_t)sc << 10) | ((uint32_t)t_row << 17) | (((scr_sum ? 0xFFFFFFFFu : 0u) | m_last) & 0x80000000u);
+                }
+#ifdef NAVGPU_SWEEP_COUNTS
+                if (m_stall != 0u) atomicAdd(&g_sweep_counts[12], 1ull);
+#endif
+              }
+            }
+          }
+          // ---- the other critics, for the lanes that did not stall and have not failed the obstacle critic
+          const uint32_t m_go = u & ~m_stall & (first_fail > 1 ? 0xFFFFFFFFu : 0u);
+          {
+            // path / goal: a point of the window whose screen bit is clear cannot fail that critic (the bit IS the failure test, taken
+            // from this cycle's grid by the prep launch); a set bit fails it: -3 or -2, the grid says which after the rollout.  The last
+            // point's cell is remembered (aggregation Last: its distances survive).  Off the map: -4.
+            const uint32_t live_p = (en_path && 4 < first_fail) ? 0xFFFFFFFFu : 0u, live_g = (en_goal && 5 < first_fail) ? 0xFFFFFFFFu : 0u;
+            const uint32_t m_pg = m_go & (live_p | live_g);
+            const uint32_t m_pgoff = m_pg & ~m_on, m_pgon = m_pg & m_on;
+            const uint32_t cell = cy * g.nx + cx;
+            last_c = sel(m_pgon & m_last, cell, last_c);
+            const uint32_t m_scr = m_pgon & ~m_last & m_inw;
+            const uint32_t hz = m_scr & live_p & b_z, hw = m_scr & ~hz & live_g & b_w;
+            const uint32_t ff_off = sel(live_p, 4u, 5u);
+            first_fail = (int)sel(m_pgoff, ff_off, sel(hz, 4u, sel(hw, 5u, (uint32_t)first_fail)));
+            fail_code = (int)sel(m_pgoff, (uint32_t)-4, sel(hz | hw, 0u, (uint32_t)fail_code));
+            fail_cell = sel(hz | hw, cell, fail_cell);
+            const uint32_t m_out = m_pgon & ~m_last & ~m_inw;  // outside the LDS window (never, with a correctly sized one): look the grids up here
+            if (__ballot(m_out != 0u) != 0ull) {
+              if (m_out != 0u) {
+                if (en_path && 4 < first_fail) {
+                  const uint32_t d = dpath[cell];
+                  if (d == N_obst || d == N_unreach) {
+                    fail_code = d == N_obst ? -3 : -2;
+                    first_fail = 4;
                   }
                 }
-#endif
-                if (pm != 0ull) {  // one LDS atomic per wave and step
-                  const int leader = __ffsll((long long)pm) - 1;
-                  uint32_t base = 0;
-                  if ((int)lane == leader) base = atomicAdd(&s_qn[blk & 1u], (uint32_t)__popcll(pm));
-                  base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-                  const uint32_t slot = base + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull));
-                  if (need_walk) {
-                    if (slot < (uint32_t)kSweepQueue) {
-                      s_qx[slot] = (float)x;
-                      s_qy[slot] = (float)y;
-                      s_qt[slot] = tid | ((uint32_t)sc << 10) | ((uint32_t)t_row << 17) | ((scr_sum || last_pt) ? 0x80000000u : 0u);
-                    } else {
-                      stall = true;  // the queue is full: this point is taken again in the next block
-#ifdef NAVGPU_SWEEP_COUNTS
-                      atomicAdd(&g_sweep_counts[12], 1ull);
-#endif
-                    }
+                if (en_goal && 5 < first_fail) {
+                  const uint32_t d = dgoal[cell];
+                  if (d == N_obst || d == N_unreach) {
+                    fail_code = d == N_obst ? -3 : -2;
+                    first_fail = 5;
                   }
                 }
               }
             }
-            if (!stall && first_fail > 1) {
-              if ((en_path && 4 < first_fail) || (en_goal && 5 < first_fail)) {
-                if (!on_map) {
-                  fail_code = -4;
-                  first_fail = (en_path && 4 < first_fail) ? 4 : 5;
-                } else {
-                  const uint32_t cell = cy * g.nx + cx;
-                  if (last_pt) {
-                    last_c = cell;  // aggregation Last: the final point's distances survive (read after the rollout)
-                  } else if (in_w) {
-                    // A point of the window whose path / goal screen bit is clear cannot fail that critic (the bit IS the failure
-                    // test, taken from this cycle's grid by the prep launch); a set bit fails it: -3 or -2, the grid says which
-                    if (en_path && 4 < first_fail && ((fbw.z >> (lxw & 31)) & 1u)) {
-                      fail_code = 0;
-                      first_fail = 4;
-                      fail_cell = cell;
-                    } else if (en_goal && 5 < first_fail && ((fbw.w >> (lxw & 31)) & 1u)) {
-                      fail_code = 0;
-                      first_fail = 5;
-                      fail_cell = cell;
-                    }
-                  } else {  // outside the LDS window (never, with a correctly sized one): look the grids up here
-                    if (en_path && 4 < first_fail) {
-                      const uint32_t d = dpath[cell];
-                      if (d == N_obst || d == N_unreach) {
-                        fail_code = d == N_obst ? -3 : -2;
-                        first_fail = 4;
-                      }
-                    }
-                    if (en_goal && 5 < first_fail) {
-                      const uint32_t d = dgoal[cell];
-                      if (d == N_obst || d == N_unreach) {
-                        fail_code = d == N_obst ? -3 : -2;
-                        first_fail = 5;
-                      }
-                    }
-                  }
-                }
-              }
-              // the forward point: on the map for sure while the point lies in the window and the window clear of the margin band
-              // (margin_on), and only the final point's cell is ever read - so most points that look closer skip its worldToMap
-              if (((en_gf && 2 < first_fail) || (en_al && 3 < first_fail)) && (last_pt || margin_on || !in_w)) {
+            // the forward point: on the map for sure while the point lies in the window and the window clear of the margin band
+            // (margin_on), and only the final point's cell is ever read - so most points that look closer skip its worldToMap
+            const uint32_t live_f = ((en_gf && 2 < first_fail) || (en_al && 3 < first_fail)) ? 0xFFFFFFFFu : 0u;
+            const uint32_t m_fwd = m_go & live_f & (m_last | (margin_on ? 0xFFFFFFFFu : 0u) | ~m_inw);
+            if (__ballot(m_fwd != 0u) != 0ull) {
+              if (m_fwd != 0u) {
                 double sx = x, sy = y;
                 if (fpd != 0.0) {
                   sx = x + fpd * cs;
@@ -565,22 +567,20 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
                 if (!w2m(sx, sy, ux, uy)) {
                   fail_code = -4;
                   first_fail = (en_gf && 2 < first_fail) ? 2 : 3;
-                } else if (last_pt) {
+                } else if (m_last != 0u) {
                   last_f = uy * g.nx + ux;
                 }
-              } else if (last_pt) {
-                last_f = 0;  // (reached; no forward critic to read for)
               }
-              scr_z = first_fail > 4 ? 0xFFFFFFFFu : 0u;  // (first_fail only changes in here)
-              scr_w = first_fail > 5 ? 0xFFFFFFFFu : 0u;
             }
-            if (stall) {  // back to the point as it was: (float)x is the old px exactly
-              px = (float)x;
-              py = (float)y;
-              step = sc;
-            }
-            alive_m = first_fail > min_order ? 0xFFFFFFFFu : 0u;
+            last_f = sel(m_go & ~m_fwd & m_last, 0u, last_f);  // (reached; no forward critic to read for)
           }
+          scr_z = first_fail > 4 ? 0xFFFFFFFFu : 0u;  // (always the lane's first_fail put as masks: it only changes in here)
+          scr_w = first_fail > 5 ? 0xFFFFFFFFu : 0u;
+          // a stalled lane goes back to the point as it was: (float)x is the old px exactly
+          px = m_stall != 0u ? (float)x : px;
+          py = m_stall != 0u ? (float)y : py;
+          step = (int)sel(m_stall, (uint32_t)sc, (uint32_t)step);
+          alive_m &= first_fail > min_order ? 0xFFFFFFFFu : 0u;
           SW_STAMP(ss1);
           SW_ACC(4, ss1 - ss0);
           SW_ACC(9, 1);
