@@ -70,6 +70,7 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   __shared__ uint32_t s_qt[kSweepQueue];
   __shared__ uint32_t s_obs[THREADS];
   __shared__ uint32_t s_qn[2];
+  __shared__ uint32_t s_more[3];  // rotating by block: any lane of the workgroup still rolling out?
 
   const uint32_t inst = first + blockIdx.z;  // grid: x = workgroup within its row group, y = row group, z = robot (a robot's workgroups are dispatched together)
   const uint32_t tid = threadIdx.x;
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
   // ---- stage (one batch of loads, one barrier): the robot's image; the lane's own sample and reject byte come straight from HBM
   if (tid == 0) s_cnt[0] = s_cnt[1] = 0;
   if (tid < 2) s_qn[tid] = 0;
+  if (tid < 3) s_more[tid] = 0;
   s_obs[tid] = 0;
   // the robot's scalars, worked out once by k_score_prep_tab (planner_score.hip): window origin (robot cell - win / 2), the
   // forward point's margin band, whether this launch can screen at all; and the loads the lanes need later, issued now
@@ -590,11 +592,26 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
     }
     SW_STAMP(sb1);
     SW_ACC(3, sb1 - sb0);
-    __syncthreads();  // the block's entries are in the queue
+    // One barrier ends the block: the queue is complete, and s_more says whether any lane of the workgroup goes on.  The NEXT block's
+    // counter and flag are cleared before it.  The counter alternates: a wave that reads the last block's count late (that block
+    // skipped its second barrier) reads the 0 that is being written - its queue was empty.  The flag rotates through THREE words: the
+    // one cleared here was last read two blocks ago, and every wave has passed a barrier since.
+    const uint32_t mi = blk % 3u;
+    if (__ballot(alive_m != 0u) != 0ull && lane == 0) s_more[mi] = 1;
+    if (tid == 0) {
+      s_qn[(blk + 1u) & 1u] = 0;
+      s_more[mi == 2u ? 0u : mi + 1u] = 0;
+    }
+    __syncthreads();
     SW_STAMP(sb2);
     SW_ACC(5, sb2 - sb1);
-    // ---- walk: the workgroup's lanes take the entries, whoever pushed them
     const int nq = (int)min(s_qn[blk & 1u], (uint32_t)kSweepQueue);
+    const uint32_t more = s_more[mi];
+    if (nq == 0) {  // (uniform over the workgroup) nothing to walk, no results to wait for
+      if (!more) break;
+      continue;
+    }
+    // ---- walk: the workgroup's lanes take the entries, whoever pushed them
     for (int e = (int)tid; e < nq; e += THREADS) {
       const uint32_t tag = s_qt[e];
       const double x = s_qx[e], y = s_qy[e];
@@ -623,10 +640,9 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
         atomicAdd(&s_obs[owner], (uint32_t)occ);
       }
     }
-    if (tid == 0) s_qn[(blk + 1u) & 1u] = 0;  // (last touched before the previous block's second barrier)
     SW_STAMP(sb3);
     SW_ACC(6, sb3 - sb2);
-    const int more = __syncthreads_or(alive_m != 0u);
+    __syncthreads();  // the owners' words are complete
     SW_STAMP(sb4);
     SW_ACC(7, sb4 - sb3);
     if ((s_obs[tid] & kWalkFailed) != 0u && first_fail > 1) {  // a walked point of this lane failed: footprint_cost < 0 -> -6 (also after its last point)
@@ -634,7 +650,7 @@ __global__ __launch_bounds__(kSweepThreads, NAVGPU_SCORE_TAB_WAVES) void k_score
       first_fail = 1;
       alive_m = 0;
     }
-    if (!more) break;
+    if (!more) break;  // (taken before the walks: a workgroup whose last live lanes they have just ended comes round once more, finds nobody alive and leaves)
   }
 
   {  // ---- the distance grids, once: every load in flight before the first is used (clamped addresses; unused ones are ignored)
