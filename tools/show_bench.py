@@ -2,6 +2,8 @@ import json, sys
 d=json.load(open(sys.argv[1]))
 print("value %.4g ms_per_step %.4f" % (d["value"], d["ms_per_step"]))
 print("kernel_ms", d["kernel_ms"])
+r2=d.get("roofline_second")
+if r2: print("roofline_second", {k:r2[k] for k in ("kernel","achieved","frac","avg_launch_ms","bound","frac_issue") if k in r2})
 r=d["roofline"]; print("roofline (alone)", {k:r[k] for k in ("kernel","achieved","frac","avg_launch_ms","bound","frac_issue") if k in r}, "in_schedule", {k: r["in_schedule"][k] for k in ("achieved","frac","avg_launch_ms")}, "profile", {k: r.get("profile",{}).get(k) for k in ("tag","matches_running_build")})
 for k in ("pcie_inclusive","resident_inputs","value_over_resident","cycle_latency","cycle_latency_resident_inputs","one_stream","inflation_cells_per_s"):
     v=d.get(k)
