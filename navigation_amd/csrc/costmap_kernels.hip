@@ -956,16 +956,19 @@ __global__ __launch_bounds__(256) void k_inflate_bits(CostmapDev cm, uint32_t fi
   __shared__ uint32_t s_hd[kOct + 1][kBX];  // nibble-packed nearest-seed |dx| per (row octet, column)
   __shared__ uint8_t s_lut2[256];           // cost by squared distance
   __shared__ int s_any;
+  __shared__ uint32_t s_rowany[2];                // bit r: halo row r of the tile holds a seed (pass B skips the others)
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int HR = kBY + 2 * R;
   uint8_t* master = cm.master + (size_t)inst * cm.cells_padded;
   if (tid == 0) s_any = 0;
+  if (tid < 2) s_rowany[tid] = 0;
   s_lut2[tid] = cm.lut2[tid];
   __syncthreads();
   // ---- seed bitmaps by ballot: wave w takes halo rows w, w+4, ...
   // (all of a wave's loads are issued before the first ballot needs one: in a rolled loop every load is waited for on
   // its own, 28 latencies in a row - that was most of this kernel's 57 us)
   int any = 0;
+  uint32_t rows_lo = 0, rows_hi = 0;  // (wave-uniform) this wave's halo rows that hold a seed
   constexpr int kSeedIt = (kMaxHR + 3) / 4;
   // The loads are unconditional (clamped coordinates; a conditional load is waited for inside its branch) and the
   // conditions are applied to what they return.
@@ -998,10 +1001,20 @@ __global__ __launch_bounds__(256) void k_inflate_bits(CostmapDev cm, uint32_t fi
           s_rows[r][2 * half + 1] = (uint32_t)(m >> 32);
         }
         any |= m != 0ull;
+        if (m != 0ull) {
+          if (r < 32)
+            rows_lo |= 1u << r;
+          else
+            rows_hi |= 1u << (r - 32);
+        }
       }
     }
   }
-  if (any && lane == 0) s_any = 1;
+  if (any && lane == 0) {
+    s_any = 1;
+    if (rows_lo) atomicOr(&s_rowany[0], rows_lo);
+    if (rows_hi) atomicOr(&s_rowany[1], rows_hi);
+  }
   __syncthreads();
   if (!s_any) return;
   // ---- pass A: nearest seed |dx| (nibble, 15 = none within R) for every (halo row, column)
@@ -1039,19 +1052,34 @@ __global__ __launch_bounds__(256) void k_inflate_bits(CostmapDev cm, uint32_t fi
   if (__ballot((hw[0] & hw[1] & hw[2] & hw[3] & hw[4]) != 0xFFFFFFFFu) == 0ull) return;
   const int gx = tx0 + (int)lane;
   const int R2 = R * R;
+  // R known at compile time: the halo rows outermost, and only those that hold a seed (wave-uniform: s_rowany) - a row's h^2 is worked
+  // out once and goes into the (up to 8) output rows it is within R of: 2 instructions per (row, output row) pair instead of 3 per
+  // pair of ALL 8 + 2R rows
+  uint32_t bestr[8] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+  if (RT > 0) {
+    const unsigned long long rowany = (((unsigned long long)s_rowany[1] << 32) | s_rowany[0]) >> (8u * wave);  // bit p: this wave's halo row p
+    const uint32_t ra_lo = __builtin_amdgcn_readfirstlane((uint32_t)rowany), ra_hi = __builtin_amdgcn_readfirstlane((uint32_t)(rowany >> 32));
+#pragma unroll
+    for (int p = 0; p < 8 + 2 * RT; ++p) {
+      if (((p < 32 ? ra_lo >> (p & 31) : ra_hi >> (p & 31)) & 1u) != 0u) {  // (wave-uniform)
+        const uint32_t h = (hw[p >> 3] >> (4 * (p & 7))) & 15u;
+        const uint32_t hh = h * h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int dy = p - RT - j;
+          if (dy >= -RT && dy <= RT) {
+            const uint32_t d2 = hh + (uint32_t)(dy * dy);
+            bestr[j] = d2 < bestr[j] ? d2 : bestr[j];
+          }
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int gy = ty0 + (int)wave * 8 + j;
-    uint32_t best = 0xFFFFu;
-    if (RT > 0) {
-#pragma unroll
-      for (int dy = -RT; dy <= RT; ++dy) {
-        const int p = j + RT + dy;  // halo row relative to the first loaded word
-        const uint32_t h = (hw[p >> 3] >> (4 * (p & 7))) & 15u;
-        const uint32_t d2 = h * h + (uint32_t)(dy * dy);
-        best = d2 < best ? d2 : best;
-      }
-    } else {
+    uint32_t best = bestr[j];
+    if (RT == 0) {
       for (int dy = -R; dy <= R; ++dy) {
         const int p = j + R + dy;
         const uint32_t wsel = p >> 3;

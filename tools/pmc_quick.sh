@@ -13,7 +13,7 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open("$out/r_counter_collection.csv")):
     k=r["Kernel_Name"].split("(")[0].replace("void ","").replace("navgpu::","").split("<")[0]
     acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k in ("k_score_sweep","k_score_tab","k_score_prep_tab","k_bfs_rows","k_bfs_rows2"):
+for k in ("k_score_sweep","k_score_tab","k_score_prep_tab","k_bfs_rows","k_bfs_rows2","k_inflate_bits","k_merge"):
     if k in acc:
         print("$name", k, {c: round(sum(v)/len(v)/1e6,2) for c,v in acc[k].items()}, "M per launch", flush=True)
 PY
