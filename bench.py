@@ -858,9 +858,9 @@ def main():
         cyc.sort()
         out["pcie_inclusive"] = {"ms_per_step": sum(cyc) / len(cyc) * 1e3, "cycle_ms_median": cyc[len(cyc) // 2] * 1e3,
                                  "cycle_ms_p99": cyc[min(len(cyc) - 1, int(0.99 * len(cyc)))] * 1e3, "cycle_ms_max": cyc[-1] * 1e3, "cycle_ms_second_max": cyc[-2] * 1e3,
-                                 "max_note": "one hipMemcpyAsync of a process stalls ~8 ms inside the HIP runtime, once, about 2 400 async copies in (around the "
-                                             "130th cycle of the four groups; tools/probe_cycle_outliers.py, rocprofv3 --hip-runtime-trace): it falls into "
-                                             "these 300 cycles, not into the timed region of the default run (53 cycles); second_max is the largest other cycle",
+                                 "max_note": "a hipMemcpyAsync stalls ~8 ms inside the HIP runtime (the SDMA path: HSA_ENABLE_SDMA=0 removes it and makes every copy "
+                                             "a kernel) every 2 500 - 3 000 async copies of the process, about every 150 fleet cycles "
+                                             "(tools/probe_cycle_outliers.py, rocprofv3 --hip-runtime-trace); second_max is the largest other cycle",
                                  "cycles": len(cyc),
                                  "h2d_bytes_per_step": sum(g.h2d_bytes for g in groups), "d2h_bytes_per_step": n_inst * 72,
                                  "note": "= the protocol of `value` (the timed region), host-side time per step over 300 more cycles; caller buffers are pageable, "

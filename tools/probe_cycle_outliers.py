@@ -7,6 +7,22 @@ import bench
 import navigation_amd as nav
 from navigation_amd.sharding import shard_range as split
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+preburn = sys.argv[2] if len(sys.argv) > 2 else ""  # "tiny" / "big": that many async copies through torch first (is the stall count- or byte-bound?)
+if preburn:
+    import torch
+    n = 4 if preburn == "tiny" else 553000
+    src = torch.zeros(n, dtype=torch.uint8).pin_memory()
+    dst = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+    st = torch.cuda.Stream()
+    t0 = time.perf_counter()
+    worst = 0.0
+    with torch.cuda.stream(st):
+        for i in range(3000):
+            t1 = time.perf_counter()
+            dst.copy_(src, non_blocking=True)
+            worst = max(worst, time.perf_counter() - t1)
+    st.synchronize()
+    print("preburn %s: 3000 copies in %.1f ms, slowest call %.3f ms" % (preburn, (time.perf_counter() - t0) * 1e3, worst * 1e3))
 groups = []
 for gi in range(4):
     g0, gn = split(256, gi, 4)
