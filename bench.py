@@ -31,6 +31,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# A HIP runtime setting of this PROCESS (read when the runtime starts, i.e. before anything below touches the GPU): host-to-device copies
+# of up to 2 MiB go through the runtime's copy kernels instead of the SDMA engines.  Every hand-over of the step is such a copy (a group's
+# packed scan block is 0.6 MB), and through SDMA one hipMemcpyAsync in ~2 500 stalls for ~8 ms inside the runtime - about every 150 fleet
+# cycles (tools/probe_cycle_outliers.py).  Not set when the caller has set it; the line says what was in force (config.env).
+os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "2048")
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 T_STEPS, P_PERIM, G_GRIDS = 20, 32, 4
 BYTES_PER_TRAJ = 20 + T_STEPS * (P_PERIM + 1) + T_STEPS * G_GRIDS * 4  # = 1000 B
@@ -805,7 +811,8 @@ def main():
                                       else f"N GPUs = N x {n_inst} instances (N=8 is configs[3])"),
                        "instances_per_gpu": n_inst, "groups_per_gpu": G, "cycles_in_flight_per_group": depth, "costmap": f"{n_cells}x{n_cells}@0.05", "vsamples": "x".join(str(v) for v in vs),
                        "sim_steps": T_STEPS, "critics": "oscillation+obstacle+goal_front+alignment+path+goal",
-                       "parallelism": f"fleet-shard x{world}, {G} stream groups per GPU x {depth} cycle(s) in flight each"},
+                       "parallelism": f"fleet-shard x{world}, {G} stream groups per GPU x {depth} cycle(s) in flight each",
+                       "env": {"GPU_FORCE_BLIT_COPY_SIZE": os.environ.get("GPU_FORCE_BLIT_COPY_SIZE")}},
             "value_is": "SURVEY 8(d)'s protocol: every timed cycle hands over its own new scan cloud, pose / velocity and plan from host memory "
                         f"(H2D, {sum(g.h2d_bytes for g in groups)} B per step) and reads its results back (D2H); costmaps resident.  The transfers of one "
                         "group hide behind the other groups' kernels; resident_inputs is the same loop without them",
@@ -858,9 +865,9 @@ def main():
         cyc.sort()
         out["pcie_inclusive"] = {"ms_per_step": sum(cyc) / len(cyc) * 1e3, "cycle_ms_median": cyc[len(cyc) // 2] * 1e3,
                                  "cycle_ms_p99": cyc[min(len(cyc) - 1, int(0.99 * len(cyc)))] * 1e3, "cycle_ms_max": cyc[-1] * 1e3, "cycle_ms_second_max": cyc[-2] * 1e3,
-                                 "max_note": "a hipMemcpyAsync stalls ~8 ms inside the HIP runtime (the SDMA path: HSA_ENABLE_SDMA=0 removes it and makes every copy "
-                                             "a kernel) every 2 500 - 3 000 async copies of the process, about every 150 fleet cycles "
-                                             "(tools/probe_cycle_outliers.py, rocprofv3 --hip-runtime-trace); second_max is the largest other cycle",
+                                 "max_note": "with the HIP runtime's default copy path (SDMA) one hipMemcpyAsync in ~2 500 stalls ~8 ms inside the runtime, about "
+                                             "every 150 fleet cycles; this process runs with GPU_FORCE_BLIT_COPY_SIZE (config.env): copies up to that many KiB "
+                                             "are kernels, and the stall is gone (tools/probe_cycle_outliers.py)",
                                  "cycles": len(cyc),
                                  "h2d_bytes_per_step": sum(g.h2d_bytes for g in groups), "d2h_bytes_per_step": n_inst * 72,
                                  "note": "= the protocol of `value` (the timed region), host-side time per step over 300 more cycles; caller buffers are pageable, "

@@ -285,6 +285,9 @@ def lib():
     if not os.path.exists(path):
         raise NavgpuError(f"{path} is missing: build it with navigation_amd.build() / __graft_entry__.build(); "
                           "there is no CPU fallback")
+    # (see bench.py / INTEGRATION.md 4: small host-to-device copies through the runtime's copy kernels - its SDMA path stalls ~8 ms once
+    # in ~2 500 async copies; a no-op when the HIP runtime of this process has already started or the caller has set the variable)
+    os.environ.setdefault("GPU_FORCE_BLIT_COPY_SIZE", "2048")
     L = C.CDLL(path)
     for name, res, args in SYMBOLS:
         fn = getattr(L, name)  # AttributeError if the header and the library ever diverge
